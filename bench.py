@@ -1,0 +1,182 @@
+"""bench.py -- 512x512 tiles/sec of the U-Net hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S]
+
+Workload (BASELINE.json configs[1]): ``rs predict`` of the ResNet-50 U-Net, batch 16 x 3x512x512 fp32 per GPU, 2
+classes: layout conversion -> 61 convolutions -> fused final 1x1 + softmax, i.e. everything ``rs predict`` runs on the
+device per batch (reference tools/predict.py:83-87).  Inputs are synthetic and already resident in HBM when the timed
+region starts.  Tiles shard across ranks with no data-path collective ("weak" scaling: B tiles per GPU per step).
+
+One JSON line on stdout (rank 0): metric/value/unit..., plus
+  "roofline"     -- dominant kernel, algorithmic FLOPs / HIP-event time over the launches of one pass, vs the fp32
+                    MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
+  "cpu_baseline" -- the CPU oracle (oracle/robosat_ref.py, kind "port") timed on this box's host cores on a bounded
+                    sample of the same workload (N=1, rank 0 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
+    ap.add_argument("--layers-json", type=str, default="", help="also dump the per-layer roofline table here")
+    return ap.parse_args()
+
+
+def build_model(classes, device):
+    from robosat_amd.unet import UNet
+
+    torch.manual_seed(0)
+    net = UNet(classes, pretrained=False)  # random init of the reference architecture (no network for checkpoints)
+    g = torch.Generator().manual_seed(1)
+    for name, buf in net.named_buffers():  # non-trivial BatchNorm statistics (fresh init would make BN an identity)
+        if name.endswith("running_mean"):
+            buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+        elif name.endswith("running_var"):
+            buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+    return net.to(device).eval()
+
+
+def roofline(net, x):
+    """HIP events around every convolution launch of one predict pass (same stream as the launches)."""
+
+    from robosat_amd import ops
+
+    net.predict_probs(x)
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    net.predict_probs(x)
+    torch.cuda.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    per_kernel, layers = {}, []
+    for name, flops, shape, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        k = per_kernel.setdefault(name, [0.0, 0.0, 0])
+        k[0] += flops
+        k[1] += ms
+        k[2] += 1
+        layers.append({"kernel": name, "cin_cout_k_stride_ups_ho_wo": list(shape), "gflop": flops / 1e9, "ms": ms,
+                       "tflops": flops / ms / 1e9 if ms > 0 else 0.0})
+    dom = max(per_kernel, key=lambda n: per_kernel[n][1])
+    flops, ms, launches = per_kernel[dom]
+    total_ms = sum(v[1] for v in per_kernel.values())
+    total_fl = sum(v[0] for v in per_kernel.values())
+    achieved = flops / ms / 1e9
+    out = {
+        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": launches,
+        "avg_launch_ms": round(ms / launches, 4), "gflop_per_launch": round(flops / launches / 1e9, 3),
+        "all_convs": {"tflops": round(total_fl / total_ms / 1e9, 2), "frac": round(total_fl / total_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+                      "ms": round(total_ms, 3), "gflop": round(total_fl / 1e9, 2)},
+        "per_kernel": {n: {"tflops": round(v[0] / v[1] / 1e9, 2), "ms": round(v[1], 3), "launches": v[2]} for n, v in per_kernel.items()},
+    }
+    return out, layers
+
+
+def cpu_baseline(classes, size, budget_s):
+    """The CPU oracle on this box's host cores: bounded sample of the same workload (tiles of the same size)."""
+
+    from oracle import robosat_ref as R
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = R.UNetRef(classes).eval()
+    x = torch.randn(1, 3, size, size)
+    R.predict_probs(net, x)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        R.predict_probs(net, x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": round(n / el, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "{} tiles of 3x{}x{} (batch 1), fp32, oracle/robosat_ref.py UNetRef+softmax on {} host cores".format(n, size, size, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    net = build_model(args.classes, device)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM
+
+    def step():
+        return net.predict_probs(x)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        roof, layers = roofline(net, x)
+        if args.layers_json:
+            with open(args.layers_json, "w") as fp:
+                json.dump(layers, fp, indent=1)
+        line = {
+            "metric": "512x512 tiles/sec train+predict, 1/2/4/8 MI355X; mIoU vs CPU ref",
+            "value": round(world * args.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rs predict ResNet50-UNet, bs={} 3x{}x{} fp32 per GPU, {} classes (BASELINE configs[1])".format(
+                args.batch, args.size, args.size, args.classes), "phase": "predict", "tiles_per_gpu_per_step": args.batch,
+                "tile": args.size, "parallelism": "tiles sharded over {} rank(s), no collective".format(world)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+/*
+ * robosat_hip.h -- C ABI of librobosat_hip.so: the MI355X (gfx950) implementation of the RoboSat U-Net hot path.
+ *
+ * The reference (mapbox/robosat v1.2.0) has no FFI of its own: its hot path is Python calling torch ops
+ * (SURVEY.md section 0.1).  This header is therefore the boundary a maintainer binds *beneath* the reference's
+ * Python operator surface; every entry point names the reference call it replaces (file:line under
+ * /root/reference).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain device pointers + sizes, no torch types; `stream` is a hipStream_t passed as void*.
+ *   - every function only ENQUEUES work on `stream` (no allocation, no implicit sync) and returns a hipError_t
+ *     as int (0 = success); argument errors return RS_EINVAL (-22) before anything is enqueued.
+ *   - activations are NHWC fp32 ("channels last"): x[n][y][x][c].  Convolution weights are KRSC fp32
+ *     (w[cout][ky][kx][cin]) == a torch [Cout,Cin,kh,kw] tensor in channels_last memory format.
+ *   - logits / probabilities / loss inputs are NCHW fp32, label maps are [N][H][W] int64: exactly the tensors the
+ *     reference's losses and predict tool see (robosat/losses.py, robosat/tools/predict.py:87).
+ */
+#ifndef ROBOSAT_HIP_H
+#define ROBOSAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_EINVAL (-22)
+
+typedef void* rs_stream_t;
+
+/* Version of this ABI (bumped on any signature change). */
+int rs_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on v_mfma_f32_32x32x2_f32; exact fp32).
+ *
+ * One descriptor covers every convolution in UNet.forward (robosat/unet.py:122-141):
+ *   - resnet.conv1 7x7/2 stem                      (unet.py:122)   stem = 1
+ *   - Bottleneck 1x1, 3x3 (stride 1|2), downsample (unet.py:127-130; torchvision 0.3.0 resnet50)
+ *   - ConvRelu 3x3 + ReLU                          (unet.py:32,44)
+ *   - DecoderBlock = interpolate(nearest, x2) then ConvRelu (unet.py:73), with the torch.cat of the skip tensor
+ *     (unet.py:134-137) folded in: src1 = skip (first C1 channels), src2 = previous decoder output (next C2).
+ *     Neither the upsampled nor the concatenated tensor is ever materialised.
+ * and, by symmetry, every data-gradient convolution of loss.backward() (robosat/tools/train.py:186):
+ *   ups = 2 reads the source through a zero-inserted x2 grid (the adjoint of a stride-2 convolution).
+ *
+ * out[n][oy][ox][co] = epilogue( sum_{ky,kx,ci} in[n][oy*stride-pad+ky][ox*stride-pad+kx][ci] * w[co][ky][kx][ci] )
+ * epilogue(v) = relu?( v * scale[co] + shift[co] + residual[n][oy][ox][co] )   (each part optional / NULL)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct rs_conv_desc {
+  int32_t N;          /* batch */
+  int32_t Hs, Ws;     /* spatial size of the source tensor(s) as stored */
+  int32_t C1, C2;     /* channels of src1 / src2 (C2 = 0: single source); C1, C2 multiples of 32 unless stem */
+  int32_t ups;        /* 0: none; 1: nearest x2 upsample fused into the gather; 2: zero-insert x2 (stride-2 dgrad) */
+  int32_t kh, kw, stride, pad;
+  int32_t Ho, Wo;     /* output spatial size */
+  int32_t Cout;       /* multiple of 32 */
+  int32_t relu;       /* 1: ReLU in the epilogue */
+  int32_t stem;       /* 1: src1 is NHWC with 4 channels, weights packed [Cout][kh][8][4] (see rs_pack_stem_weight) */
+} rs_conv_desc;
+
+int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const float* src2, const float* weight,
+                  const float* scale, const float* shift, const float* residual, float* out, rs_stream_t stream);
+
+/* Which tile configuration rs_conv2d_fwd picks for `d` (index into rs_conv2d_tile_name); for the roofline report. */
+int rs_conv2d_tile(const rs_conv_desc* d);
+const char* rs_conv2d_tile_name(int tile);
+
+/* resnet.conv1 weight [Cout][kh][kw][Cin<=4] (KRSC) -> [Cout][kh][8][4], zero padded (unet.py:122). */
+int rs_pack_stem_weight(const float* w_krsc, float* packed, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Layout / elementwise / pooling
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* images.to(device) as UNet.forward receives them (train.py:172, predict.py:83): NCHW [N][C<=4][H][W] -> NHWC4,
+ * channel 3 zero-filled when C == 3. */
+int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream);
+
+/* F.max_pool2d on NHWC: resnet.maxpool 3x3/2 pad 1 (unet.py:125) and the 2x2/2 before `center` (unet.py:132).
+ * Padding behaves as -inf (torch semantics).  C multiple of 4.  `argmax` (optional, uint8 [N][Ho][Wo][C]) receives
+ * the winning tap ky*k+kx (first maximum in row-major window order, as torch picks) for the backward pass. */
+int rs_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride, int pad,
+                     int Ho, int Wo, rs_stream_t stream);
+
+/* Eval-mode BatchNorm2d folded to per-channel scale/shift for the conv epilogue (resnet bn*, eps as torch):
+ * scale = gamma / sqrt(var + eps), shift = beta - mean * scale. */
+int rs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+               float* shift, int C, rs_stream_t stream);
+
+/* self.final (unet.py:108,141): 1x1 conv Cin=32..128 (multiple of 4, <= 128) -> C classes (<= 8) with bias, reading
+ * NHWC and writing NCHW.  softmax = 1 additionally applies nn.functional.softmax(dim=1) (predict.py:87). */
+int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
+                     int C, int softmax, rs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBOSAT_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of ``librobosat_hip.so`` (C ABI declared in ``include/robosat_hip.h``).
+
+There is NO fallback: if the library is missing or fails to load, importing the compute path raises.  PyTorch is
+imported first on purpose -- it loads its bundled ``libamdhip64.so.7``; our library's NEEDED entry has the same
+SONAME and therefore binds to the SAME HIP runtime, so torch's streams and device pointers are valid in our kernels.
+"""
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_void_p
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
+
+RS_EINVAL = -22
+ABI_VERSION = 1
+
+
+class ConvDesc(ctypes.Structure):
+    """``rs_conv_desc`` (include/robosat_hip.h)."""
+
+    _fields_ = [
+        ("N", c_int32), ("Hs", c_int32), ("Ws", c_int32), ("C1", c_int32), ("C2", c_int32), ("ups", c_int32),
+        ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad", c_int32), ("Ho", c_int32), ("Wo", c_int32),
+        ("Cout", c_int32), ("relu", c_int32), ("stem", c_int32),
+    ]
+
+
+P = c_void_p  # device pointers and the stream travel as void*
+
+# name -> (restype, argtypes); must list every symbol declared in include/robosat_hip.h
+SIGNATURES = {
+    "rs_abi_version": (c_int, []),
+    "rs_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "rs_conv2d_tile": (c_int, [POINTER(ConvDesc)]),
+    "rs_conv2d_tile_name": (c_char_p, [c_int]),
+    "rs_pack_stem_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_nchw_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_maxpool2d_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_bn_fold": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),
+    "rs_final_conv1x1": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Returns the loaded library; raises (never falls back) if it is not there."""
+
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "robosat_amd: {} is missing -- the MI355X kernels are not built and there is no CPU fallback. "
+                "Build with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C robosat_amd/csrc`).".format(LIB_PATH)
+            )
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == header and library disagree
+            fn.restype, fn.argtypes = restype, argtypes
+        got = handle.rs_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError("robosat_amd: librobosat_hip.so ABI {} != expected {}".format(got, ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc == RS_EINVAL:
+            raise ValueError("{}: invalid arguments (RS_EINVAL)".format(what))
+        raise RuntimeError("{}: HIP error {}".format(what, rc))

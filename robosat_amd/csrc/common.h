@@ -1,0 +1,35 @@
+// Shared device helpers for the gfx950 kernels.  wave = 64 lanes, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/robosat_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RS_LAUNCH_RESULT() ((int)hipGetLastError())
+
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; speed only, never
+// correctness).  Remap so each XCD works on a contiguous run of tile indices and neighbouring tiles (which share
+// input halos and weight panels) hit the same private L2.  Bijective for any grid size.
+__device__ __forceinline__ int rs_xcd_remap(int b, int nwg) {
+  const int xcd = b & 7, k = b >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+__device__ __forceinline__ float rs_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double rs_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int rs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,190 @@
+// HBM-bound layout / pooling / head kernels of the U-Net forward (reference robosat/unet.py:122-141,
+// robosat/tools/predict.py:87).  All are streaming kernels: 16-byte accesses, coalesced on the NHWC channel axis.
+#include "common.h"
+
+namespace {
+
+// images.to(device): NCHW [N][C][H][W] -> NHWC4 (channel 3 zero when C == 3).  One thread per pixel: three/four
+// coalesced plane reads, one 16-byte store.
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, long HW, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long n = i / HW, hw = i - n * HW;
+  const float* px = x + n * C * HW + hw;
+  f32x4 v;
+  v[0] = px[0];
+  v[1] = C > 1 ? px[HW] : 0.f;
+  v[2] = C > 2 ? px[2 * HW] : 0.f;
+  v[3] = C > 3 ? px[3 * HW] : 0.f;
+  *reinterpret_cast<f32x4*>(y + i * 4) = v;
+}
+
+// F.max_pool2d on NHWC, 4 channels per thread.  Window scanned row-major with a strict '>' so the FIRST maximum
+// wins, as torch's max_pool2d_with_indices does; padding is -inf (never selected when any tap is valid).
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ amax, int H,
+                                    int W, int C4, int k, int stride, int pad, int Ho, int Wo, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  long pix = i / C4;
+  const int ox = (int)(pix % Wo);
+  pix /= Wo;
+  const int oy = (int)(pix % Ho);
+  const long n = pix / Ho;
+  const float ninf = -__builtin_huge_valf();
+  f32x4 best = {ninf, ninf, ninf, ninf};
+  int bi[4] = {0, 0, 0, 0};
+  bool first = true;
+  for (int r = 0; r < k; ++r) {
+    const int iy = oy * stride - pad + r;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int s = 0; s < k; ++s) {
+      const int ix = ox * stride - pad + s;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
+      const int tap = r * k + s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (first || v[e] > best[e] || v[e] != v[e]) {  // torch: (val > maxval) || isnan(val)
+          best[e] = v[e];
+          bi[e] = tap;
+        }
+      }
+      first = false;
+    }
+  }
+  *reinterpret_cast<f32x4*>(y + i * 4) = best;
+  if (amax) {
+    const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    *reinterpret_cast<uint32_t*>(amax + i * 4) = packed;
+  }
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                               float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(var[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - mean[c] * sc;
+}
+
+// self.final (+ optional softmax): 256 pixels per block.  The block's [256][Cin] slab is read with fully coalesced
+// 16-byte loads into LDS (row stride Cin+1: conflict-free per-pixel reads), then one thread owns one pixel, keeps
+// the C class sums in registers and writes C coalesced NCHW planes.
+template <int C>
+__global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            long P, long HW, int Cin, int softmax) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = Cin + 1;
+  float* xs = sm;             // [256][Cin+1]
+  float* ws = sm + 256 * ld;  // [C][Cin] then bias[C]
+  const int tid = threadIdx.x;
+  const long p0 = (long)blockIdx.x * 256;
+  const int q = Cin >> 2;  // float4 per pixel
+  for (int f = tid; f < 256 * q; f += 256) {
+    const int px = f / q, c4 = f - px * q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p0 + px < P) v = *reinterpret_cast<const f32x4*>(x + (p0 + px) * Cin + c4 * 4);
+    float* d = xs + px * ld + c4 * 4;
+    d[0] = v[0];
+    d[1] = v[1];
+    d[2] = v[2];
+    d[3] = v[3];
+  }
+  for (int f = tid; f < C * Cin; f += 256) ws[f] = w[f];
+  if (tid < C) ws[C * Cin + tid] = bias ? bias[tid] : 0.f;
+  __syncthreads();
+  const long pix = p0 + tid;
+  if (pix >= P) return;
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  const float* xr = xs + tid * ld;
+  for (int k = 0; k < Cin; ++k) {
+    const float xv = xr[k];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = fmaf(xv, ws[c * Cin + k], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] += ws[C * Cin + c];
+  if (softmax) {
+    float mx = acc[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, acc[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      acc[c] = expf(acc[c] - mx);
+      sum += acc[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = acc[c] / sum;
+  }
+  const long n = pix / HW, hw = pix - n * HW;
+  float* o = out + n * C * HW + hw;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c * HW] = acc[c];
+}
+
+template <int C>
+int launch_final(const float* x, const float* w, const float* bias, float* out, long P, long HW, int Cin, int softmax,
+                 hipStream_t s) {
+  const size_t smem = (size_t)(256 * (Cin + 1) + C * Cin + C) * sizeof(float);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_conv1x1_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  final_conv1x1_kernel<C><<<rs_cdiv(P, 256), 256, smem, s>>>(x, w, bias, out, P, HW, Cin, softmax);
+  return RS_LAUNCH_RESULT();
+}
+
+}  // namespace
+
+extern "C" int rs_abi_version(void) { return 1; }
+
+extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
+  const long HW = (long)H * W, total = (long)N * HW;
+  nchw_to_nhwc4_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, C, HW, total);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride,
+                                int pad, int Ho, int Wo, rs_stream_t stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k <= 0 || k > 15 || stride <= 0 || pad < 0 ||
+      Ho <= 0 || Wo <= 0)
+    return RS_EINVAL;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  maxpool_nhwc_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, argmax, H, W, C / 4, k, stride, pad, Ho,
+                                                                            Wo, total);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* shift, int C, rs_stream_t stream) {
+  if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) return RS_EINVAL;
+  bn_fold_kernel<<<rs_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, mean, var, eps, scale, shift, C);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
+                                int C, int softmax, rs_stream_t stream) {
+  if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cin > 128 || C <= 0 || C > 8)
+    return RS_EINVAL;
+  const long HW = (long)H * W, P = (long)N * HW;
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 1: return launch_final<1>(x, w, bias, out, P, HW, Cin, softmax, s);
+    case 2: return launch_final<2>(x, w, bias, out, P, HW, Cin, softmax, s);
+    case 3: return launch_final<3>(x, w, bias, out, P, HW, Cin, softmax, s);
+    case 4: return launch_final<4>(x, w, bias, out, P, HW, Cin, softmax, s);
+    case 5: return launch_final<5>(x, w, bias, out, P, HW, Cin, softmax, s);
+    case 6: return launch_final<6>(x, w, bias, out, P, HW, Cin, softmax, s);
+    case 7: return launch_final<7>(x, w, bias, out, P, HW, Cin, softmax, s);
+    default: return launch_final<8>(x, w, bias, out, P, HW, Cin, softmax, s);
+  }
+}

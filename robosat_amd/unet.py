@@ -1,0 +1,270 @@
+"""MI355X-native U-Net with a ResNet-50 encoder: drop-in for the reference's ``robosat.unet`` module.
+
+Same public surface as reference ``robosat/unet.py`` -- ``UNet(num_classes, num_filters=32, pretrained=True)``,
+``forward(x[N,3,H,W]) -> logits[N,C,H,W]``, the same assertion on ``H, W % 32`` (unet.py:119-120) and the same
+sub-module names, hence the same 329 state-dict keys in the same order (``resnet.conv1.weight`` ...
+``final.bias``), so checkpoints written by either side load in the other.
+
+What differs is everything underneath: the modules below only HOLD parameters.  All arithmetic of the forward (and
+backward) pass runs in the hand-written gfx950 kernels of ``librobosat_hip.so`` (``include/robosat_hip.h``):
+NHWC activations, KRSC weights (conv parameters are kept in ``torch.channels_last`` memory format, which *is* KRSC,
+so no per-step weight transform exists), nearest-x2 upsample and skip concatenation folded into the convolution's
+gather, eval-mode BatchNorm + residual + ReLU folded into the convolution epilogue.  There is no CPU path: calling the
+model on a CPU tensor raises.
+"""
+
+import math
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+# torchvision 0.3.0 caches the ImageNet weights under this name (reference docker/Dockerfile.*:21)
+_RESNET50_FILE = "resnet50-19c8e357.pth"
+
+
+class _Conv(nn.Module):
+    """Parameter holder for a bias-free/biased convolution; weight is [Cout,Cin,kh,kw] in channels_last (= KRSC)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=False, init="default"):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        fan_in, fan_out = cin * k * k, cout * k * k
+        if init == "resnet":  # torchvision: kaiming_normal_(mode="fan_out", nonlinearity="relu")
+            nn.init.normal_(w, 0.0, math.sqrt(2.0 / fan_out))
+        else:  # nn.Conv2d default: kaiming_uniform_(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            nn.init.uniform_(w, -1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+        self.weight = nn.Parameter(w)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in)))
+        else:
+            self.register_parameter("bias", None)
+
+    def krsc(self):
+        """The weight as a contiguous [Cout,kh,kw,Cin] view (no copy while the parameter stays channels_last)."""
+
+        w = self.weight.detach().permute(0, 2, 3, 1)
+        return w if w.is_contiguous() else w.contiguous()
+
+    def extra_repr(self):
+        return "{}, {}, kernel_size={}, stride={}, padding={}".format(self.cin, self.cout, self.k, self.stride, self.padding)
+
+
+class _BatchNorm(nn.Module):
+    """Parameter/buffer holder with nn.BatchNorm2d's names and defaults (eps 1e-5, momentum 0.1)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._folded = None
+
+    def folded(self):
+        """Eval-mode scale/shift for the conv epilogue; cached until a parameter or buffer is modified."""
+
+        ts = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._folded is None or self._folded[0] != key:
+            scale, shift = ops.bn_fold(self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var, self.eps)
+            self._folded = (key, scale, shift)
+        return self._folded[1], self._folded[2]
+
+    def extra_repr(self):
+        return "{}, eps={}, momentum={}".format(self.num_features, self.eps, self.momentum)
+
+
+class _Linear(nn.Module):
+    """``resnet.fc``: never used by UNet.forward, but part of every reference checkpoint (unet.py:94)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        bound = 1.0 / math.sqrt(cin)
+        self.weight = nn.Parameter(torch.empty(cout, cin).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+
+
+class _Bottleneck(nn.Module):
+    """torchvision-0.3.0 Bottleneck parameters: 1x1 -> 3x3 (stride) -> 1x1 (x4); attribute order = key order."""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = _Conv(inplanes, planes, 1, init="resnet")
+        self.bn1 = _BatchNorm(planes)
+        self.conv2 = _Conv(planes, planes, 3, stride=stride, padding=1, init="resnet")
+        self.bn2 = _BatchNorm(planes)
+        self.conv3 = _Conv(planes, planes * 4, 1, init="resnet")
+        self.bn3 = _BatchNorm(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _ResNet50(nn.Module):
+    def __init__(self, in_channels=3):
+        super().__init__()
+        self.conv1 = _Conv(in_channels, 64, 7, stride=2, padding=3, init="resnet")
+        self.bn1 = _BatchNorm(64)
+        inplanes = 64
+        for i, (planes, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+            layer = []
+            for b in range(blocks):
+                s = stride if b == 0 else 1
+                down = None
+                if b == 0 and (s != 1 or inplanes != planes * 4):
+                    down = nn.Sequential(_Conv(inplanes, planes * 4, 1, stride=s, init="resnet"), _BatchNorm(planes * 4))
+                layer.append(_Bottleneck(inplanes, planes, s, down))
+                inplanes = planes * 4
+            setattr(self, "layer{}".format(i + 1), nn.Sequential(*layer))
+        self.fc = _Linear(2048, 1000)
+
+
+class ConvRelu(nn.Module):
+    """3x3 convolution (padding 1, no bias) + ReLU; parameters under ``block`` (reference unet.py:18-44)."""
+
+    def __init__(self, num_in, num_out):
+        super().__init__()
+        self.block = _Conv(num_in, num_out, 3, padding=1)
+
+
+class DecoderBlock(nn.Module):
+    """Nearest x2 upsample then ``ConvRelu``; parameters under ``block.block`` (reference unet.py:47-73)."""
+
+    def __init__(self, num_in, num_out):
+        super().__init__()
+        self.block = ConvRelu(num_in, num_out)
+
+
+def _find_pretrained():
+    cands = [os.environ.get("ROBOSAT_RESNET50_WEIGHTS")]
+    home = os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch"))
+    cands += [os.path.join(home, "checkpoints", _RESNET50_FILE), os.path.join(home, "hub", "checkpoints", _RESNET50_FILE)]
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
+class UNet(nn.Module):
+    """ResNet-50-encoder U-Net ("AlbuNet"), computed by hand-written gfx950 kernels.
+
+    Args (reference unet.py:82): ``num_classes``; ``num_filters`` (32); ``pretrained`` -- load ImageNet encoder
+    weights from ``$ROBOSAT_RESNET50_WEIGHTS`` or torch's cache (there is no network access here; if no file is found
+    the encoder keeps its random init and a warning is issued).  ``in_channels`` (extension, default 3)."""
+
+    def __init__(self, num_classes, num_filters=32, pretrained=True, in_channels=3):
+        super().__init__()
+        assert 1 <= in_channels <= 4, "the stem kernel packs up to 4 input bands"
+        nf = num_filters
+        self.num_classes, self.in_channels = num_classes, in_channels
+
+        self.resnet = _ResNet50(in_channels)
+
+        self.center = DecoderBlock(2048, nf * 8)
+
+        self.dec0 = DecoderBlock(2048 + nf * 8, nf * 8)
+        self.dec1 = DecoderBlock(1024 + nf * 8, nf * 8)
+        self.dec2 = DecoderBlock(512 + nf * 8, nf * 2)
+        self.dec3 = DecoderBlock(256 + nf * 2, nf * 2 * 2)
+        self.dec4 = DecoderBlock(nf * 2 * 2, nf)
+        self.dec5 = ConvRelu(nf, nf)
+
+        self.final = _Conv(nf, num_classes, 1, bias=True)
+
+        if pretrained:
+            path = _find_pretrained()
+            if path is None:
+                warnings.warn("robosat_amd.UNet(pretrained=True): no local {} found; encoder stays randomly initialised".format(_RESNET50_FILE))
+            else:
+                state = torch.load(path, map_location="cpu")
+                if in_channels != 3:
+                    state.pop("conv1.weight", None)
+                self.resnet.load_state_dict(state, strict=in_channels == 3)
+
+    # -- plumbing -----------------------------------------------------------------------------------------------
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        for m in self.modules():  # .to()/.cuda() may drop the KRSC layout of size-1-dim weights: restore it
+            if isinstance(m, _Conv) and not m.weight.is_contiguous(memory_format=torch.channels_last):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+            if isinstance(m, _BatchNorm):
+                m._folded = None
+        return out
+
+    def _blocks(self):
+        r = self.resnet
+        return [list(r.layer1), list(r.layer2), list(r.layer3), list(r.layer4)]
+
+    # -- forward ------------------------------------------------------------------------------------------------
+
+    def forward(self, x):
+        """Logits [N,num_classes,H,W] (NCHW fp32), as reference unet.py:110-141."""
+
+        size = x.size()
+        assert size[-1] % 32 == 0 and size[-2] % 32 == 0, "image resolution has to be divisible by 32 for resnet"
+        if self.training and torch.is_grad_enabled():
+            from .autograd import unet_train_forward
+
+            return unet_train_forward(self, x)
+        if self.training:
+            raise NotImplementedError("robosat_amd.UNet: train-mode forward under no_grad is not supported (the reference never does this: validate() calls net.eval())")
+        return self._forward_eval(x, softmax=False)
+
+    @torch.no_grad()
+    def predict_probs(self, x):
+        """softmax(forward(x), dim=1) with the softmax fused into the last kernel (tools/predict.py:84-87)."""
+
+        size = x.size()
+        assert size[-1] % 32 == 0 and size[-2] % 32 == 0, "image resolution has to be divisible by 32 for resnet"
+        assert not self.training, "predict_probs is an eval-mode call"
+        return self._forward_eval(x, softmax=True)
+
+    def _forward_eval(self, x, softmax):
+        if not x.is_cuda:
+            raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
+        assert x.size(1) == self.in_channels
+        r = self.resnet
+        x = x.detach().float().contiguous()
+
+        h = ops.nchw_to_nhwc4(x)
+        sc, sh = r.bn1.folded()
+        h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7)
+        h = ops.maxpool2d(h, 3, 2, 1)
+
+        enc = []
+        for layer in self._blocks():
+            for blk in layer:
+                sc, sh = blk.bn1.folded()
+                o = ops.conv2d(h, blk.conv1.krsc(), scale=sc, shift=sh, relu=True)
+                sc, sh = blk.bn2.folded()
+                o = ops.conv2d(o, blk.conv2.krsc(), stride=blk.stride, pad=1, scale=sc, shift=sh, relu=True)
+                if blk.downsample is not None:
+                    sc, sh = blk.downsample[1].folded()
+                    idt = ops.conv2d(h, blk.downsample[0].krsc(), stride=blk.stride, scale=sc, shift=sh)
+                else:
+                    idt = h
+                sc, sh = blk.bn3.folded()
+                h = ops.conv2d(o, blk.conv3.krsc(), scale=sc, shift=sh, residual=idt, relu=True)
+            enc.append(h)
+        enc1, enc2, enc3, enc4 = enc
+
+        def up(block, skip, prev=None):
+            return ops.conv2d(skip, block.block.block.krsc(), src2=prev, ups=1, pad=1, relu=True)
+
+        center = up(self.center, ops.maxpool2d(enc4, 2, 2, 0))
+        dec0 = up(self.dec0, enc4, center)
+        dec1 = up(self.dec1, enc3, dec0)
+        dec2 = up(self.dec2, enc2, dec1)
+        dec3 = up(self.dec3, enc1, dec2)
+        dec4 = up(self.dec4, dec3)
+        dec5 = ops.conv2d(dec4, self.dec5.block.krsc(), pad=1, relu=True)
+
+        wf = self.final.weight.detach().reshape(self.num_classes, -1)
+        return ops.final_conv1x1(dec5, wf, self.final.bias.detach(), softmax=softmax)

@@ -1,0 +1,163 @@
+"""Per-kernel parity on the MI355X: every C-ABI op against plain PyTorch fp32 on the host CPU (the same ATen ops the
+reference path dispatches).  fp32 MFMA is an exact-fp32 fma chain, so only the summation
+order differs: tolerance 2e-4 relative to the output scale."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def nhwc(t):  # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().to(_dev())
+
+
+def nchw(t):  # NHWC gpu -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def krsc(w):  # OIHW cpu -> KRSC gpu
+    return w.permute(0, 2, 3, 1).contiguous().to(_dev())
+
+
+def close(got, want, tol=2e-4):
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, "max abs err {} (scale {})".format(err, scale)
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+CASES = [
+    # name,            N, Cin, H,  W,  Cout, k, stride, pad  (tile the C ABI picks)
+    ("3x3_c32_tail", 2, 32, 17, 19, 32, 3, 1, 1),  # 128x32, M tail
+    ("3x3_c64_small", 2, 64, 16, 16, 64, 3, 1, 1),  # 64x64
+    ("3x3_c64_s2", 2, 64, 18, 22, 64, 3, 2, 1),  # stride 2, 64x64
+    ("3x3_c64_big", 2, 32, 192, 192, 64, 3, 1, 1),  # 128x64
+    ("3x3_c128_big", 1, 32, 256, 256, 128, 3, 1, 1),  # 128x128
+    ("1x1_c256", 2, 64, 20, 12, 256, 1, 1, 0),
+    ("1x1_s2", 2, 128, 20, 12, 256, 1, 2, 0),
+    ("3x3_c96in", 1, 96, 9, 33, 160, 3, 1, 1),  # Cout 160 -> 128x32 tiles
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_plain(case):
+    from robosat_amd import ops
+
+    _, n, cin, h, w, cout, k, stride, pad = case
+    x, wt = rnd(n, cin, h, w, seed=1), rnd(cout, cin, k, k, seed=2) * (2.0 / (cin * k * k)) ** 0.5
+    want = F.conv2d(x, wt, stride=stride, padding=pad)
+    got = nchw(ops.conv2d(nhwc(x), krsc(wt), stride=stride, pad=pad))
+    close(got, want)
+
+
+def test_conv_epilogue():
+    from robosat_amd import ops
+
+    n, cin, h, w, cout = 2, 64, 24, 24, 128
+    x, wt = rnd(n, cin, h, w, seed=3), rnd(cout, cin, 3, 3, seed=4) * 0.06
+    sc, sh, res = rnd(cout, seed=5), rnd(cout, seed=6), rnd(n, cout, h, w, seed=7)
+    want = F.relu(F.conv2d(x, wt, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    got = nchw(ops.conv2d(nhwc(x), krsc(wt), pad=1, scale=sc.to(_dev()), shift=sh.to(_dev()), residual=nhwc(res), relu=True))
+    close(got, want)
+
+
+@pytest.mark.parametrize("c1,c2,cout,h,w", [(64, 32, 64, 10, 14), (32, 0, 32, 16, 16), (256, 64, 128, 8, 8)])
+def test_conv_upsample_concat(c1, c2, cout, h, w):
+    """DecoderBlock: conv3x3(interpolate(cat[skip, prev], x2 nearest)) + ReLU (reference unet.py:73,134-137)."""
+    from robosat_amd import ops
+
+    n = 2
+    a = rnd(n, c1, h, w, seed=8)
+    b = rnd(n, c2, h, w, seed=9) if c2 else None
+    wt = rnd(cout, c1 + c2, 3, 3, seed=10) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    cat = torch.cat([a, b], 1) if c2 else a
+    want = F.relu(F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1))
+    got = nchw(ops.conv2d(nhwc(a), krsc(wt), src2=nhwc(b) if c2 else None, ups=1, pad=1, relu=True))
+    close(got, want)
+
+
+@pytest.mark.parametrize("k,pad,hin", [(3, 1, 16), (1, 0, 16), (3, 1, 15)])
+def test_conv_zero_insert_is_stride2_adjoint(k, pad, hin):
+    """ups=2 gather == data gradient of a stride-2 convolution (checked against autograd)."""
+    from robosat_amd import ops
+
+    n, cin, cout = 2, 64, 96
+    x = rnd(n, cin, hin, hin, seed=11).requires_grad_(True)
+    wt = rnd(cout, cin, k, k, seed=12) * 0.05
+    y = F.conv2d(x, wt, stride=2, padding=pad)
+    gy = rnd(*y.shape, seed=13)
+    y.backward(gy)
+    # dgrad weights: [Cin][k][k][Cout], taps flipped
+    wd = wt.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(_dev())
+    got = nchw(ops.conv2d(nhwc(gy), wd, ups=2, pad=k - 1 - pad, out_hw=(hin, hin)))
+    close(got, x.grad)
+
+
+def test_stem():
+    from robosat_amd import ops
+
+    for cin in (3, 4):
+        x, wt = rnd(2, cin, 64, 96, seed=14), rnd(64, cin, 7, 7, seed=15) * 0.1
+        want = F.conv2d(x, wt, stride=2, padding=3)
+        x4 = ops.nchw_to_nhwc4(x.to(_dev()))
+        assert x4.shape == (2, 64, 96, 4)
+        close(x4[..., :cin].cpu(), x.permute(0, 2, 3, 1))
+        if cin == 3:
+            assert float(x4[..., 3].abs().max()) == 0.0
+        got = nchw(ops.conv2d(x4, ops.pack_stem_weight(krsc(wt)), stride=2, pad=3, stem=7))
+        close(got, want)
+
+
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (2, 2, 0)])
+def test_maxpool(k, s, p):
+    from robosat_amd import ops
+
+    x = rnd(2, 64, 18, 22, seed=16)
+    x[0, :, 3:6, 3:6] = 0.5  # ties: first maximum in window order must win (as torch)
+    want, idx = F.max_pool2d(x, k, s, p, return_indices=True)
+    got, amax = ops.maxpool2d(nhwc(x), k, s, p, want_argmax=True)
+    assert torch.equal(nchw(got), want)
+    # decode our tap index to torch's flat input index
+    ho, wo = want.shape[2:]
+    oy = torch.arange(ho).view(1, 1, ho, 1)
+    ox = torch.arange(wo).view(1, 1, 1, wo)
+    tap = amax.permute(0, 3, 1, 2).cpu().long()
+    flat = (oy * s - p + tap // k) * x.shape[3] + (ox * s - p + tap % k)
+    assert torch.equal(flat, idx)
+
+
+def test_bn_fold_and_final():
+    from robosat_amd import ops
+
+    c = 256
+    g, b, m, v = rnd(c, seed=17), rnd(c, seed=18), rnd(c, seed=19), torch.rand(c) + 0.5
+    sc, sh = ops.bn_fold(g.to(_dev()), b.to(_dev()), m.to(_dev()), v.to(_dev()), 1e-5)
+    want_sc = g / torch.sqrt(v + 1e-5)
+    close(sc.cpu(), want_sc, 1e-6)
+    close(sh.cpu(), b - m * want_sc, 1e-6)
+
+    for ncls in (2, 4):
+        x, w, bias = rnd(2, 32, 32, 40, seed=20), rnd(ncls, 32, 1, 1, seed=21) * 0.3, rnd(ncls, seed=22)
+        want = F.conv2d(x, w, bias)
+        got = ops.final_conv1x1(nhwc(x), w.view(ncls, 32).to(_dev()), bias.to(_dev()))
+        close(got.cpu(), want, 1e-5)
+        gotp = ops.final_conv1x1(nhwc(x), w.view(ncls, 32).to(_dev()), bias.to(_dev()), softmax=True)
+        close(gotp.cpu(), F.softmax(want, 1), 1e-5)
+
+
+def test_cpu_tensor_is_an_error():
+    from robosat_amd import ops
+
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 32), torch.zeros(32, 1, 1, 32))

@@ -1,0 +1,70 @@
+"""Whole-network parity on the MI355X: robosat_amd.UNet (HIP kernels) vs the golden vectors produced by the
+unmodified reference and vs the CPU oracle.  Bar (BASELINE.json north_star): per-pixel class probabilities within
+1e-3 (fp32) of the reference CPU path on identical inputs."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import robosat_ref as R, seeded
+
+pytestmark = pytest.mark.gpu
+
+TOL_PROBS = 1e-3  # north_star tolerance
+
+
+def _pair(num_classes, seed, in_channels=3):
+    from robosat_amd.unet import UNet
+
+    ref = R.UNetRef(num_classes, in_channels=in_channels)
+    sd = seeded.seeded_state_dict(ref.state_dict(), seed)
+    ref.load_state_dict(sd)
+    net = UNet(num_classes, pretrained=False, in_channels=in_channels)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    return ref.eval(), net.to("cuda:0").eval()
+
+
+@pytest.mark.parametrize("tag", ["c2_64", "c3_64x128"])
+def test_probs_match_reference_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "unet_fwd_{}.npz".format(tag)))
+    n, c, h, w, k, seed = [int(v) for v in g["shape"]]
+    _, net = _pair(k, seed)
+    x = seeded.synthetic_images(n, c, h, w, seed).to("cuda:0")
+    with torch.no_grad():
+        logits = net(x)
+        probs = net.predict_probs(x)
+    assert logits.shape == (n, k, h, w) and logits.is_contiguous()
+    err_l = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    err_p = np.abs(probs.cpu().numpy() - g["probs"]).max()
+    print("golden", tag, "max|dlogit|", err_l, "max|dprob|", err_p)
+    assert err_p <= TOL_PROBS
+    assert err_l <= 1e-3 * max(1.0, np.abs(g["logits"]).max())
+
+
+@pytest.mark.parametrize("shape,k,cin", [((2, 3, 256, 256), 2, 3), ((1, 4, 128, 192), 4, 4)])
+def test_probs_match_oracle(shape, k, cin):
+    ref, net = _pair(k, 11, cin)
+    x = seeded.synthetic_images(*shape, seed=5)
+    want = R.predict_probs(ref, x)
+    got = net.predict_probs(x.to("cuda:0")).cpu()
+    err = float((got - want).abs().max())
+    print("oracle", shape, "max|dprob|", err)
+    assert err <= TOL_PROBS
+    # decisions agree wherever the oracle's margin is not razor thin
+    wa, ga = want.argmax(1), got.argmax(1)
+    top2 = want.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * TOL_PROBS
+    assert bool((wa[safe] == ga[safe]).all())
+
+
+def test_resolution_assert_and_no_cpu_path():
+    from robosat_amd.unet import UNet
+
+    net = UNet(2, pretrained=False).eval()
+    with pytest.raises(AssertionError, match="divisible by 32"):
+        net(torch.zeros(1, 3, 48, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 64, 64))

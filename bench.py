@@ -37,13 +37,16 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--phase", choices=["predict", "train"], default="predict",
+                    help="predict = BASELINE configs[1] (default); train = fwd + loss + bwd + grad all-reduce + Adam")
+    ap.add_argument("--loss", choices=["CrossEntropy", "Lovasz", "Focal"], default="Lovasz", help="train phase criterion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
     ap.add_argument("--layers-json", type=str, default="", help="also dump the per-layer roofline table here")
     return ap.parse_args()
 
 
-def build_model(classes, device):
+def build_model(classes, device, train=False):
     from robosat_amd.unet import UNet
 
     torch.manual_seed(0)
@@ -54,18 +57,19 @@ def build_model(classes, device):
             buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
         elif name.endswith("running_var"):
             buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
-    return net.to(device).eval()
+    net = net.to(device)
+    return net.train() if train else net.eval()
 
 
-def roofline(net, x):
+def roofline(step):
     """HIP events around every convolution launch of one predict pass (same stream as the launches)."""
 
     from robosat_amd import ops
 
-    net.predict_probs(x)
+    step()
     torch.cuda.synchronize()
     ops.PROFILE = []
-    net.predict_probs(x)
+    step()
     torch.cuda.synchronize()
     recs, ops.PROFILE = ops.PROFILE, None
     per_kernel, layers = {}, []
@@ -93,26 +97,57 @@ def roofline(net, x):
     return out, layers
 
 
-def cpu_baseline(classes, size, budget_s):
-    """The CPU oracle on this box's host cores: bounded sample of the same workload (tiles of the same size)."""
+def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
+    """The CPU oracle on this box's host cores: bounded sample of the same workload (tiles of the same size).
+
+    torch's intra-op pool does not scale to every core of a 2-socket host for these convolutions, so the thread count
+    is chosen by a short sweep on a quarter-size tile and reported as ``cores``."""
 
     from oracle import robosat_ref as R
 
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
-    net = R.UNetRef(classes).eval()
-    x = torch.randn(1, 3, size, size)
-    R.predict_probs(net, x)  # warm-up
+    net = R.UNetRef(classes)
+    net = net.train() if phase == "train" else net.eval()
+    crit = R.LOSSES[loss_name]
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4) if phase == "train" else None
+
+    def run(x, t):
+        if phase == "predict":
+            R.predict_probs(net, x)
+        else:
+            opt.zero_grad()
+            out = net(x)
+            l = crit(out, t) if loss_name == "Lovasz" else crit(out, t, weight=torch.ones(classes))
+            l.backward()
+            opt.step()
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({c for c in (8, 16, 32, 64, 128) if c <= avail} | {min(avail, 8)})
+    bs = 2 if phase == "train" else 1  # BatchNorm needs > 1 sample per channel at the 16x16 bottleneck
+    xs, ts = torch.randn(bs, 3, size // 2, size // 2), torch.randint(0, classes, (bs, size // 2, size // 2))
+    best, best_t = cands[0], float("inf")
+    for c in cands:
+        torch.set_num_threads(c)
+        run(xs, ts)
+        t0 = time.perf_counter()
+        run(xs, ts)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = c, dt
+    torch.set_num_threads(best)
+    x, t = torch.randn(bs, 3, size, size), torch.randint(0, classes, (bs, size, size))
+    run(x, t)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        R.predict_probs(net, x)
-        n += 1
+        run(x, t)
+        n += bs
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
-    return {"value": round(n / el, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "{} tiles of 3x{}x{} (batch 1), fp32, oracle/robosat_ref.py UNetRef+softmax on {} host cores".format(n, size, size, os.cpu_count())}
+    what = "UNetRef+softmax" if phase == "predict" else "UNetRef train step (fwd+{}+bwd+Adam)".format(loss_name)
+    return {"value": round(n / el, 3), "unit": "tiles/s", "cores": best, "kind": "port",
+            "sample": "{} tiles of 3x{}x{} (batch {}), fp32, oracle/robosat_ref.py {} with {} of {} host cores (best of {})".format(
+                n, size, size, bs, what, best, avail, cands)}
 
 
 def main():
@@ -129,12 +164,32 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    net = build_model(args.classes, device)
+    train = args.phase == "train"
+    net = build_model(args.classes, device, train)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM
 
-    def step():
-        return net.predict_probs(x)
+    if train:
+        from robosat_amd import losses
+        from robosat_amd.parallel import GradReducer
+
+        tgt = torch.randint(0, args.classes, (args.batch, args.size, args.size), generator=g).to(device)
+        crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=torch.ones(args.classes)),
+                "Focal": lambda: losses.FocalLoss2d(weight=torch.ones(args.classes)),
+                "Lovasz": lambda: losses.LovaszLoss2d()}[args.loss]().to(device)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        if dist:
+            net.grad_reducer = GradReducer()  # bucketed RCCL all-reduce overlapped with the backward kernels
+
+        def step():
+            opt.zero_grad()
+            loss = crit(net(x), tgt)
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        def step():
+            return net.predict_probs(x)
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,7 +211,7 @@ def main():
         el = float(t.item())
 
     if rank == 0:
-        roof, layers = roofline(net, x)
+        roof, layers = roofline(step)
         if args.layers_json:
             with open(args.layers_json, "w") as fp:
                 json.dump(layers, fp, indent=1)
@@ -165,13 +220,15 @@ def main():
             "value": round(world * args.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "rs predict ResNet50-UNet, bs={} 3x{}x{} fp32 per GPU, {} classes (BASELINE configs[1])".format(
-                args.batch, args.size, args.size, args.classes), "phase": "predict", "tiles_per_gpu_per_step": args.batch,
-                "tile": args.size, "parallelism": "tiles sharded over {} rank(s), no collective".format(world)},
+            "config": {"workload": ("rs predict ResNet50-UNet, bs={} 3x{}x{} fp32 per GPU, {} classes (BASELINE configs[1])" if not train else
+                                    "rs train ResNet50-UNet, bs={} 3x{}x{} fp32 per GPU, {} classes, " + args.loss + " loss + Adam (BASELINE configs[2] at fp32)").format(
+                args.batch, args.size, args.size, args.classes), "phase": args.phase, "tiles_per_gpu_per_step": args.batch,
+                "tile": args.size, "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
+                                                   "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds, args.phase, args.loss)
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

@@ -46,6 +46,8 @@ int rs_abi_version(void);
  *
  * out[n][oy][ox][co] = epilogue( sum_{ky,kx,ci} in[n][oy*stride-pad+ky][ox*stride-pad+kx][ci] * w[co][ky][kx][ci] )
  * epilogue(v) = relu?( v * scale[co] + shift[co] + residual[n][oy][ox][co] )   (each part optional / NULL)
+ * and, when relu_mask != NULL, the result is zeroed wherever relu_mask[n][oy][ox][co] <= 0 (the ReLU backward of the
+ * layer whose output `relu_mask` is, fused into the data-gradient convolution that produces its gradient).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct rs_conv_desc {
   int32_t N;          /* batch */
@@ -60,7 +62,8 @@ typedef struct rs_conv_desc {
 } rs_conv_desc;
 
 int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const float* src2, const float* weight,
-                  const float* scale, const float* shift, const float* residual, float* out, rs_stream_t stream);
+                  const float* scale, const float* shift, const float* residual, const float* relu_mask, float* out,
+                  rs_stream_t stream);
 
 /* Which tile configuration rs_conv2d_fwd picks for `d` (index into rs_conv2d_tile_name); for the roofline report. */
 int rs_conv2d_tile(const rs_conv_desc* d);
@@ -92,6 +95,84 @@ int rs_bn_fold(const float* gamma, const float* beta, const float* mean, const f
  * NHWC and writing NCHW.  softmax = 1 additionally applies nn.functional.softmax(dim=1) (predict.py:87). */
 int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
                      int C, int softmax, rs_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Training path: what autograd synthesises for loss.backward() (robosat/tools/train.py:186) and train-mode
+ * BatchNorm (net.train(), tools/train.py:169).  Workspaces are caller-provided; query sizes with *_workspace_bytes.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Filter gradient of the convolution described by `d` (same descriptor as the forward call; `relu` is ignored):
+ *   dw[co][ky][kx][ci] = sum_{n,oy,ox} dy[n][oy][ox][co] * in[n][oy*stride-pad+ky][ox*stride-pad+kx][ci]
+ * with `in` read through the forward gather (upsample / concat / stem packing).  dw is KRSC (packed [Cout][kh][8][4]
+ * for the stem -> rs_unpack_stem_weight).  Split-P partials live in `workspace`; deterministic (no atomics). */
+long rs_conv2d_wgrad_workspace_bytes(const rs_conv_desc* d);
+int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const float* src1, const float* src2, float* dw,
+                    void* workspace, rs_stream_t stream);
+int rs_unpack_stem_weight(const float* packed, float* w_krsc, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
+
+/* Forward KRSC weights [Cout][kh][kw][Cin] -> data-gradient weights [Cin][kh][kw][Cout] with flipped taps.  The data
+ * gradient of a convolution is rs_conv2d_fwd on dy with these weights, pad' = k-1-pad, and ups = 2 when the forward
+ * stride was 2. */
+int rs_pack_dgrad_weight(const float* w_krsc, float* out, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
+
+/* Train-mode BatchNorm2d over y [M = N*H*W][C] (torchvision resnet50 bn*, eps 1e-5, momentum 0.1):
+ * rs_bn_train_stats: batch mean / biased variance -> mean, invstd = 1/sqrt(var+eps), scale = gamma*invstd,
+ *   shift = beta - mean*scale; running_mean/var (optional, both or neither) updated with the UNBIASED variance;
+ *   *num_batches_tracked (optional, int64) += 1.
+ * rs_bn_apply: out = relu?( y*scale + shift (+ residual) ).
+ * rs_bn_bwd: g = dz * (zmask > 0) (zmask optional = the ReLU output); dgamma = sum g*xhat, dbeta = sum g,
+ *   dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dmasked (optional) receives g (gradient of the residual branch).
+ * workspace: rs_bn_workspace_bytes(M, C) + 3*C*sizeof(float) bytes. */
+long rs_bn_workspace_bytes(long M, int C);
+int rs_bn_train_stats(const float* y, long M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                      float* mean, float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, void* workspace, rs_stream_t stream);
+int rs_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, long M, int C,
+                int relu, rs_stream_t stream);
+int rs_bn_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
+              const float* gamma, float* dy, float* dmasked, float* dgamma, float* dbeta, long M, int C, void* workspace,
+              rs_stream_t stream);
+
+/* Backward of F.max_pool2d given the argmax taps recorded by rs_maxpool2d_fwd; accumulate = 1 adds into dx. */
+int rs_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W, int C, int k, int stride,
+                     int pad, int Ho, int Wo, int accumulate, rs_stream_t stream);
+
+/* Backward of interpolate(nearest, x2) + torch.cat split: dup [N][2H][2W][C1+C2] -> d1 [N][H][W][C1] (+= when
+ * accumulate1), d2 [N][H][W][C2]; mask1/mask2 (optional): ReLU outputs whose backward is fused (zero where <= 0). */
+int rs_upsample2x_bwd(const float* dup, float* d1, float* d2, const float* mask1, const float* mask2, int N, int H, int W,
+                      int C1, int C2, int accumulate1, rs_stream_t stream);
+
+/* Backward of self.final (unet.py:108,141): x NHWC [N][H][W][Cin<=64], dlogits NCHW -> dx (zeroed where x <= 0 when
+ * relu_mask: x is the ReLU output dec5), dw [C][Cin], db [C]. */
+long rs_final_conv1x1_bwd_workspace_bytes(int Cin, int C);
+int rs_final_conv1x1_bwd(const float* x, const float* w, const float* dlogits, float* dx, float* dw, float* db, int N, int H,
+                         int W, int Cin, int C, int relu_mask, void* workspace, rs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses (robosat/losses.py) and metrics (robosat/metrics.py) on NCHW logits + int64 [N][H][W] targets
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* mode 0: CrossEntropyLoss2d (losses.py:8-25); mode 1: FocalLoss2d with `gamma` (losses.py:28-50).  `weight` [C]
+ * optional.  loss[0] = sum w*l / sum w; stats[0..1] = (loss, sum w) is consumed by the backward:
+ * dlogits = grad_out[0] * w[t] * dl/dx / sum w  (grad_out NULL = 1). */
+long rs_nll_loss_workspace_bytes(void);
+int rs_nll_loss_fwd(const float* logits, const long long* targets, const float* weight, float* loss, float* stats, int N,
+                    int C, int H, int W, int mode, float gamma, void* workspace, rs_stream_t stream);
+int rs_nll_loss_bwd(const float* logits, const long long* targets, const float* weight, const float* stats,
+                    const float* grad_out, float* dlogits, int N, int C, int H, int W, int mode, float gamma,
+                    rs_stream_t stream);
+
+/* LovaszLoss2d (losses.py:86-119): batched radix sort + scans.  loss[0] = mean over images; grad_unit (optional,
+ * NCHW like logits) receives d loss / d logits for grad_out = 1 (multiply with rs_scale_by_scalar). */
+long rs_lovasz_workspace_bytes(int N, int C, int H, int W);
+int rs_lovasz_fwd(const float* logits, const long long* targets, float* loss, float* grad_unit, int N, int C, int H, int W,
+                  void* workspace, rs_stream_t stream);
+int rs_scale_by_scalar(const float* src, const float* scalar, float* dst, long n, rs_stream_t stream);
+
+/* Metrics.add over a whole batch (metrics.py:27-41): counts[0..3] += (tn, fn, fp, tp) in the reference's naming. */
+int rs_confusion_counts(const float* scores, const long long* targets, unsigned long long* counts, int N, int C, int H,
+                        int W, rs_stream_t stream);
 
 #ifdef __cplusplus
 }

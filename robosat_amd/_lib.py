@@ -7,7 +7,7 @@ SONAME and therefore binds to the SAME HIP runtime, so torch's streams and devic
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_void_p
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -33,7 +33,7 @@ P = c_void_p  # device pointers and the stream travel as void*
 # name -> (restype, argtypes); must list every symbol declared in include/robosat_hip.h
 SIGNATURES = {
     "rs_abi_version": (c_int, []),
-    "rs_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "rs_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     "rs_conv2d_tile": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_tile_name": (c_char_p, [c_int]),
     "rs_pack_stem_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
@@ -41,6 +41,27 @@ SIGNATURES = {
     "rs_maxpool2d_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_bn_fold": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),
     "rs_final_conv1x1": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    # training path
+    "rs_conv2d_wgrad_workspace_bytes": (c_long, [POINTER(ConvDesc)]),
+    "rs_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    "rs_unpack_stem_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_pack_dgrad_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_bn_workspace_bytes": (c_long, [c_long, c_int]),
+    "rs_bn_train_stats": (c_int, [P, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "rs_bn_apply": (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
+    "rs_bn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, P, P]),
+    "rs_maxpool2d_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_upsample2x_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_final_conv1x1_bwd_workspace_bytes": (c_long, [c_int, c_int]),
+    "rs_final_conv1x1_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    # losses / metrics
+    "rs_nll_loss_workspace_bytes": (c_long, []),
+    "rs_nll_loss_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
+    "rs_nll_loss_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "rs_lovasz_workspace_bytes": (c_long, [c_int, c_int, c_int, c_int]),
+    "rs_lovasz_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "rs_scale_by_scalar": (c_int, [P, P, P, c_long, P]),
+    "rs_confusion_counts": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
 }
 
 _lib = None

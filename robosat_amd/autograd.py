@@ -1,0 +1,255 @@
+"""Train-mode forward + hand-scheduled backward of the U-Net as ONE ``torch.autograd.Function``.
+
+PyTorch's role here is bookkeeping only: it sees a single differentiable node ``logits = f(x, *parameters)``, calls our
+``backward`` when the reference-style training loop does ``loss.backward()`` (robosat/tools/train.py:186) and hands
+the returned gradients to ``Adam``.  Every FLOP of the 61 convolutions, 53 BatchNorms, pools and the head -- forward,
+data-gradient and weight-gradient -- runs in the HIP kernels behind ``robosat_amd.ops``.
+
+Backward structure (no tensor is ever upsampled or concatenated in memory, in either direction):
+  * weight gradients: ``rs_conv2d_wgrad`` re-reads the forward input through the forward gather;
+  * data gradients:   ``rs_conv2d_fwd`` on dy with tap-flipped, transposed weights (``ups=2`` = stride-2 adjoint);
+    the ReLU backward of the producing layer and the residual/skip gradient sums ride in that kernel's epilogue;
+  * decoder: the data gradient lands at the upsampled resolution and ``rs_upsample2x_bwd`` folds 2x2 sums + the
+    ``torch.cat`` split + the ReLU masks into one pass.
+"""
+
+import torch
+
+from . import ops
+
+
+class GradArena:
+    """All parameter gradients of one backward pass live in ONE flat fp32 buffer, carved sequentially in the order
+    the backward produces them (head, decoder, layer4 ... stem).  The kernels write straight into their slice, so a
+    finished prefix of the buffer is a ready-made all-reduce bucket: ``flush()`` hands the newly completed range to the
+    data-parallel reducer (``robosat_amd.parallel.GradReducer``), which sums it over RCCL while the rest of the
+    backward keeps computing -- no flatten/unflatten copies, no per-tensor collectives."""
+
+    def __init__(self, params, device, reducer=None):
+        total = sum((p.numel() + 3) // 4 * 4 for p in params if p.requires_grad)
+        self.flat = torch.empty(total, device=device, dtype=torch.float32)
+        self.off = 0
+        self.sent = 0
+        self.reducer = reducer
+        self.grads = {}
+
+    def take(self, param, shape):
+        """Next 16-byte aligned slice, shaped ``shape`` (the kernel's layout, e.g. KRSC), registered for ``param``."""
+
+        n = 1
+        for d in shape:
+            n *= d
+        assert n == param.numel() and self.off + n <= self.flat.numel()
+        v = self.flat[self.off:self.off + n].view(shape)
+        self.off += (n + 3) // 4 * 4
+        self.grads[param] = v
+        return v
+
+    def conv(self, conv):
+        """Slice for a conv weight gradient in KRSC; autograd receives the logical [Cout,Cin,kh,kw] view of it."""
+
+        w = conv.weight
+        v = self.take(w, (w.shape[0], w.shape[2], w.shape[3], w.shape[1]))
+        self.grads[w] = v.permute(0, 3, 1, 2)
+        return v
+
+    def flush(self):
+        if self.reducer is not None and self.off > self.sent:
+            self.reducer.reduce_async(self.flat[self.sent:self.off])
+            self.sent = self.off
+
+    def finish(self):
+        self.flush()
+        if self.reducer is not None:
+            self.reducer.wait()
+
+
+class _Tape:
+    """Forward state kept for the backward pass."""
+
+    def __init__(self):
+        self.blocks = []  # one dict per bottleneck, forward order
+        self.t = {}
+
+
+def _bn_train(bn, y, residual=None, relu=True):
+    mean, invstd, scale, shift = ops.bn_train_stats(
+        y, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+    bn._folded = None
+    z = ops.bn_apply(y, scale, shift, residual=residual, relu=relu)
+    return z, (mean, invstd)
+
+
+def _forward(net, x, tape):
+    r = net.resnet
+    t = tape.t
+    x4 = ops.nchw_to_nhwc4(x)
+    t["x4"] = x4
+    y0 = ops.conv2d(x4, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, stem=7)
+    z0, st0 = _bn_train(r.bn1, y0)
+    p0, am0 = ops.maxpool2d(z0, 3, 2, 1, want_argmax=True)
+    t.update(y0=y0, st0=st0, z0=z0, am0=am0)
+
+    h = p0
+    enc = []
+    for layer in net._blocks():
+        for blk in layer:
+            rec = {"blk": blk, "h": h}
+            y1 = ops.conv2d(h, blk.conv1.krsc())
+            z1, rec["st1"] = _bn_train(blk.bn1, y1)
+            y2 = ops.conv2d(z1, blk.conv2.krsc(), stride=blk.stride, pad=1)
+            z2, rec["st2"] = _bn_train(blk.bn2, y2)
+            y3 = ops.conv2d(z2, blk.conv3.krsc())
+            if blk.downsample is not None:
+                yd = ops.conv2d(h, blk.downsample[0].krsc(), stride=blk.stride)
+                idt, rec["std"] = _bn_train(blk.downsample[1], yd, relu=False)
+                rec["yd"] = yd
+            else:
+                idt = h
+            z3, rec["st3"] = _bn_train(blk.bn3, y3, residual=idt, relu=True)
+            rec.update(y1=y1, z1=z1, y2=y2, z2=z2, y3=y3, z3=z3)
+            tape.blocks.append(rec)
+            h = z3
+        enc.append(h)
+    enc1, enc2, enc3, enc4 = enc
+
+    def up(block, skip, prev=None):
+        return ops.conv2d(skip, block.block.block.krsc(), src2=prev, ups=1, pad=1, relu=True)
+
+    pooled, amc = ops.maxpool2d(enc4, 2, 2, 0, want_argmax=True)
+    center = up(net.center, pooled)
+    dec0 = up(net.dec0, enc4, center)
+    dec1 = up(net.dec1, enc3, dec0)
+    dec2 = up(net.dec2, enc2, dec1)
+    dec3 = up(net.dec3, enc1, dec2)
+    dec4 = up(net.dec4, dec3)
+    dec5 = ops.conv2d(dec4, net.dec5.block.krsc(), pad=1, relu=True)
+    t.update(enc=enc, pooled=pooled, amc=amc, center=center, dec0=dec0, dec1=dec1, dec2=dec2, dec3=dec3, dec4=dec4, dec5=dec5)
+    wf = net.final.weight.detach().reshape(net.num_classes, -1)
+    return ops.final_conv1x1(dec5, wf, net.final.bias.detach())
+
+
+def _dgrad(dy, conv, out_hw, residual=None, relu_mask=None):
+    """Data gradient of ``conv`` (a parameter holder with .k/.stride/.padding) evaluated at dy."""
+
+    wd = ops.pack_dgrad_weight(conv.krsc())
+    return ops.conv2d(dy, wd, ups=2 if conv.stride == 2 else 0, pad=conv.k - 1 - conv.padding, out_hw=out_hw,
+                      residual=residual, relu_mask=relu_mask)
+
+
+def _backward(net, tape, dlogits, arena):
+    t = tape.t
+    enc1, enc2, enc3, enc4 = t["enc"]
+
+    def bn_grads(bn):
+        return {"dgamma": arena.take(bn.weight, (bn.num_features,)), "dbeta": arena.take(bn.bias, (bn.num_features,))}
+
+    # ---- head + decoder -----------------------------------------------------------------------------------
+    wf = net.final.weight.detach().reshape(net.num_classes, -1)
+    dwf = arena.take(net.final.weight, tuple(wf.shape))
+    arena.grads[net.final.weight] = dwf.view(net.num_classes, -1, 1, 1)
+    d5, _, _ = ops.final_conv1x1_bwd(t["dec5"], wf, dlogits, relu_mask=True, dw=dwf,
+                                     db=arena.take(net.final.bias, (net.num_classes,)))
+
+    c5 = net.dec5.block
+    ops.conv2d_wgrad(d5, t["dec4"], 3, 3, pad=1, out=arena.conv(c5))
+    d4 = ops.conv2d(d5, ops.pack_dgrad_weight(c5.krsc()), pad=1, relu_mask=t["dec4"])
+    del d5
+
+    def up_bwd(block, dz, skip, prev, mask_skip, mask_prev, skip_grad_out=None):
+        """dz = gradient at the block's conv output (ReLU already applied).  Returns (d skip, d prev)."""
+        conv = block.block.block
+        ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=arena.conv(conv))
+        dup = ops.conv2d(dz, ops.pack_dgrad_weight(conv.krsc()), pad=1)
+        c1 = skip.shape[3]
+        c2 = 0 if prev is None else prev.shape[3]
+        return ops.upsample2x_bwd(dup, c1, c2, mask1=mask_skip, mask2=mask_prev, out1=skip_grad_out)
+
+    d3, _ = up_bwd(net.dec4, d4, t["dec3"], None, t["dec3"], None)
+    del d4
+    g_enc1, d2 = up_bwd(net.dec3, d3, enc1, t["dec2"], None, t["dec2"])
+    del d3
+    g_enc2, d1 = up_bwd(net.dec2, d2, enc2, t["dec1"], None, t["dec1"])
+    del d2
+    g_enc3, d0 = up_bwd(net.dec1, d1, enc3, t["dec0"], None, t["dec0"])
+    del d1
+    g_enc4, dcen = up_bwd(net.dec0, d0, enc4, t["center"], None, t["center"])
+    del d0
+    dpooled, _ = up_bwd(net.center, dcen, t["pooled"], None, None, None)
+    del dcen
+    g = ops.maxpool2d_bwd(dpooled, t["amc"], tuple(enc4.shape), 2, 2, 0, out=g_enc4)  # accumulates into g_enc4
+    del dpooled
+    arena.flush()  # bucket 1: head + decoder (13.8 M gradients)
+
+    # ---- encoder, last bottleneck first ----------------------------------------------------------------------
+    # gradient a block's INPUT additionally receives from the decoder skip (only the first block of layers 2..4)
+    r = net.resnet
+    skip_grad = {id(r.layer2[0]): g_enc1, id(r.layer3[0]): g_enc2, id(r.layer4[0]): g_enc3}
+    layer_heads = {id(r.layer1[0]), id(r.layer2[0]), id(r.layer3[0]), id(r.layer4[0])}
+
+    for rec in reversed(tape.blocks):
+        blk, h = rec["blk"], rec["h"]
+        hw_in = (h.shape[1], h.shape[2])
+        dy3, _, _, gm = ops.bn_bwd(g, rec["z3"], rec["y3"], rec["st3"][0], rec["st3"][1], blk.bn3.weight.detach(),
+                                   want_masked=True, **bn_grads(blk.bn3))
+        del g
+        ops.conv2d_wgrad(dy3, rec["z2"], 1, 1, out=arena.conv(blk.conv3))
+        dz2 = _dgrad(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]))
+        del dy3
+        dy2, _, _ = ops.bn_bwd(dz2, rec["z2"], rec["y2"], rec["st2"][0], rec["st2"][1], blk.bn2.weight.detach(),
+                               **bn_grads(blk.bn2))
+        del dz2
+        ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=arena.conv(blk.conv2))
+        dz1 = _dgrad(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]))
+        del dy2
+        dy1, _, _ = ops.bn_bwd(dz1, rec["z1"], rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(),
+                               **bn_grads(blk.bn1))
+        del dz1
+        ops.conv2d_wgrad(dy1, h, 1, 1, out=arena.conv(blk.conv1))
+        extra = skip_grad.get(id(blk))
+        if blk.downsample is not None:
+            dconv, dbn = blk.downsample[0], blk.downsample[1]
+            dyd, _, _ = ops.bn_bwd(gm, None, rec["yd"], rec["std"][0], rec["std"][1], dbn.weight.detach(), **bn_grads(dbn))
+            ops.conv2d_wgrad(dyd, h, 1, 1, stride=blk.stride, out=arena.conv(dconv))
+            res = _dgrad(dyd, dconv, hw_in, residual=extra)
+            del dyd
+        else:
+            assert extra is None
+            res = gm
+        g = _dgrad(dy1, blk.conv1, hw_in, residual=res)
+        del dy1, res, gm
+        if id(blk) in layer_heads:
+            arena.flush()  # one bucket per finished ResNet layer
+
+    # ---- stem -------------------------------------------------------------------------------------------------
+    dz0 = ops.maxpool2d_bwd(g, t["am0"], tuple(t["z0"].shape), 3, 2, 1)
+    dy0, _, _ = ops.bn_bwd(dz0, t["z0"], t["y0"], t["st0"][0], t["st0"][1], r.bn1.weight.detach(), **bn_grads(r.bn1))
+    dwp = ops.conv2d_wgrad(dy0, t["x4"], 7, 7, stride=2, pad=3, stem=7)
+    ops.unpack_stem_weight(dwp, 7, net.in_channels, out=arena.conv(r.conv1))
+    arena.finish()
+    return arena.grads
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        if not x.is_cuda:
+            raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
+        tape = _Tape()
+        logits = _forward(net, x.detach().float().contiguous(), tape)
+        ctx.net, ctx.tape, ctx.params = net, tape, params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        # a fresh arena per step: autograd may adopt the returned views as .grad, so the memory must not be reused
+        arena = GradArena(ctx.params, dlogits.device, getattr(ctx.net, "grad_reducer", None))
+        grads = _backward(ctx.net, ctx.tape, dlogits.contiguous(), arena)
+        ctx.tape = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+def unet_train_forward(net, x):
+    assert x.size(1) == net.in_channels
+    params = tuple(net.parameters())
+    return _UNetTrainFn.apply(net, x, *params)

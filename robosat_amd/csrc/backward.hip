@@ -1,0 +1,270 @@
+// Streaming (HBM-bound) backward kernels that autograd synthesises for the non-GEMM ops of UNet.forward when the
+// reference calls loss.backward() (robosat/tools/train.py:186): max-pool, nearest x2 upsample (+ torch.cat split),
+// and the 1x1 `final` convolution with bias.  16-byte accesses on the NHWC channel axis throughout; reductions are
+// deterministic (partials + second stage, no floating-point atomics).
+#include "common.h"
+
+namespace {
+
+// d/dx of F.max_pool2d (unet.py:125,132) in gather form: every input element sums the gradients of the windows that
+// selected it (the forward kernel recorded the winning tap per window, first maximum as torch).
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax, float* __restrict__ dx,
+                                   int H, int W, int C4, int k, int stride, int pad, int Ho, int Wo, long total,
+                                   int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  long pix = i / C4;
+  const int ix = (int)(pix % W);
+  pix /= W;
+  const int iy = (int)(pix % H);
+  const long n = pix / H;
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  if (accumulate) g = *reinterpret_cast<const f32x4*>(dx + i * 4);
+  int ny = iy + pad - (k - 1), nx = ix + pad - (k - 1);
+  const int oy0 = ny <= 0 ? 0 : (ny + stride - 1) / stride;
+  const int ox0 = nx <= 0 ? 0 : (nx + stride - 1) / stride;
+  int oy1 = (iy + pad) / stride, ox1 = (ix + pad) / stride;
+  if (oy1 > Ho - 1) oy1 = Ho - 1;
+  if (ox1 > Wo - 1) ox1 = Wo - 1;
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    const int r = iy + pad - oy * stride;
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const int s = ix + pad - ox * stride;
+      const uint32_t tap = (uint32_t)(r * k + s);
+      const long o = ((n * Ho + oy) * Wo + ox) * (long)C4 + c;
+      const uint32_t sel = *reinterpret_cast<const uint32_t*>(amax + o * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dy + o * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (((sel >> (8 * e)) & 0xffu) == tap) g[e] += v[e];
+    }
+  }
+  *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+}
+
+// d/dx of F.interpolate(scale_factor=2, mode="nearest") (unet.py:73) followed by the split of torch.cat
+// (unet.py:134-137): 2x2 sum of the gradient at the upsampled resolution, channels [0,C1) -> d1, [C1,C1+C2) -> d2.
+// mask1/mask2 (optional) are the ReLU outputs the gradients flow into: result zeroed where mask <= 0.
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dup, float* __restrict__ d1, float* __restrict__ d2,
+                                      const float* __restrict__ mask1, const float* __restrict__ mask2, int H, int W,
+                                      int C1, int C2, long total, int accumulate1) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Ct = C1 + C2, Q = Ct >> 2;
+  const int q = (int)(i % Q);
+  long pix = i / Q;  // (n*H + y)*W + x
+  const int x = (int)(pix % W);
+  const long ny = pix / W;  // n*H + y
+  const long W2 = 2L * W;
+  const long base = ((2 * ny) * W2 + 2 * x) * Ct + q * 4;  // row 2*(n*H+y) of the [N*2H][2W] image == n*2H + 2y
+  f32x4 s = *reinterpret_cast<const f32x4*>(dup + base);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(dup + base + Ct);
+  const f32x4 c = *reinterpret_cast<const f32x4*>(dup + base + W2 * Ct);
+  const f32x4 d = *reinterpret_cast<const f32x4*>(dup + base + W2 * Ct + Ct);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = (s[e] + b[e]) + (c[e] + d[e]);
+  const int ch = q * 4;
+  if (ch < C1) {
+    const long o = pix * C1 + ch;
+    if (mask1) {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(mask1 + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = z[e] > 0.f ? s[e] : 0.f;
+    }
+    if (accumulate1) {
+      const f32x4 old = *reinterpret_cast<const f32x4*>(d1 + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += old[e];
+    }
+    *reinterpret_cast<f32x4*>(d1 + o) = s;
+  } else {
+    const long o = pix * C2 + (ch - C1);
+    if (mask2) {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(mask2 + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = z[e] > 0.f ? s[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(d2 + o) = s;
+  }
+}
+
+// Backward of self.final (unet.py:108,141): x [P][Cin] NHWC (the ReLU output dec5), dlogits NCHW [N][C][HW].
+//   dx[p][k]  = (x[p][k] > 0) * sum_c dlogits[c][p] * w[c][k]      (ReLU backward of dec5 fused: relu_mask = 1)
+//   dW[c][k]  = sum_p dlogits[c][p] * x[p][k],   db[c] = sum_p dlogits[c][p]
+// Blocks stride over 256-pixel tiles; per-thread partial dW/db live in registers across tiles (wave w owns pixels
+// [64w, 64w+64) of each tile), then waves and blocks are combined in two deterministic stages.
+template <int C>
+__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ dl, float* __restrict__ dx,
+                                                        float* __restrict__ partial, long P, long HW, int Cin, long ntiles,
+                                                        int relu_mask) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = Cin + 1;
+  float* xs = sm;                 // [256][Cin+1]
+  float* dls = xs + 256 * ld;     // [C][256]
+  float* ws = dls + C * 256;      // [C][Cin]
+  float* red = ws + C * Cin;      // [4][npairs]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = Cin >> 2;
+  const int npairs = C * (Cin + 1);  // (c,k) for k < Cin, plus the bias column k == Cin
+  constexpr int MAXPASS = 9;         // C*(Cin+1) <= 8*65 = 520 <= 9*64
+  float acc[MAXPASS];
+#pragma unroll
+  for (int i = 0; i < MAXPASS; ++i) acc[i] = 0.f;
+
+  for (int f = tid; f < C * Cin; f += 256) ws[f] = w[f];
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long p0 = tile * 256;
+    __syncthreads();  // previous tile fully consumed
+    for (int f = tid; f < 256 * q; f += 256) {
+      const int px = f / q, c4 = f - px * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p0 + px < P) v = *reinterpret_cast<const f32x4*>(x + (p0 + px) * Cin + c4 * 4);
+      float* d = xs + px * ld + c4 * 4;
+      d[0] = v[0];
+      d[1] = v[1];
+      d[2] = v[2];
+      d[3] = v[3];
+    }
+    {
+      const long pix = p0 + tid;
+      const long n = pix / HW, hw = pix - n * HW;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dls[c * 256 + tid] = pix < P ? dl[(n * C + c) * HW + hw] : 0.f;
+    }
+    __syncthreads();
+    // dx: thread -> (pixel, float4 of channels); coalesced 16-byte stores
+    for (int f = tid; f < 256 * q; f += 256) {
+      const int px = f / q, c4 = f - px * q;
+      if (p0 + px >= P) continue;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float g = dls[c * 256 + px];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(g, ws[c * Cin + c4 * 4 + e], o[e]);
+      }
+      if (relu_mask) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = xs[px * ld + c4 * 4 + e] > 0.f ? o[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dx + (p0 + px) * Cin + c4 * 4) = o;
+    }
+    // dW/db partials: wave `wave` reduces its 64 pixels for every (c,k) pair
+#pragma unroll
+    for (int pass = 0; pass < MAXPASS; ++pass) {
+      const int pair = pass * 64 + lane;
+      if (pair < npairs) {
+        const int c = pair / (Cin + 1), k = pair - c * (Cin + 1);
+        float a = acc[pass];
+        const float* g = dls + c * 256 + wave * 64;
+        if (k < Cin) {
+          const float* xv = xs + (wave * 64) * ld + k;
+          for (int pp = 0; pp < 64; ++pp) a = fmaf(g[pp], xv[pp * ld], a);
+        } else {
+          for (int pp = 0; pp < 64; ++pp) a += g[pp];
+        }
+        acc[pass] = a;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < MAXPASS; ++pass) {
+    const int pair = pass * 64 + lane;
+    if (pair < npairs) red[wave * npairs + pair] = acc[pass];
+  }
+  __syncthreads();
+  for (int pair = tid; pair < npairs; pair += 256)
+    partial[(long)blockIdx.x * npairs + pair] = (red[pair] + red[npairs + pair]) + (red[2 * npairs + pair] + red[3 * npairs + pair]);
+}
+
+// one block per (c,k) pair: sums the per-block partials in fp64
+__global__ __launch_bounds__(256) void final_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                                 int Cin, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double red[256];
+  const int pair = blockIdx.x, npairs = C * (Cin + 1);
+  double s = 0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partial[(long)b * npairs + pair];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int c = pair / (Cin + 1), k = pair - c * (Cin + 1);
+    if (k < Cin) dw[c * Cin + k] = (float)red[0];
+    else db[c] = (float)red[0];
+  }
+}
+
+constexpr int kFinalBwdMaxBlocks = 1024;
+
+template <int C>
+int launch_final_bwd(const float* x, const float* w, const float* dl, float* dx, float* dw, float* db, float* partial,
+                     long P, long HW, int Cin, int relu_mask, hipStream_t s) {
+  const long ntiles = (P + 255) / 256;
+  const int grid = ntiles < kFinalBwdMaxBlocks ? (int)ntiles : kFinalBwdMaxBlocks;
+  const int npairs = C * (Cin + 1);
+  const size_t smem = (size_t)(256 * (Cin + 1) + C * 256 + C * Cin + 4 * npairs) * sizeof(float);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_bwd_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  final_bwd_kernel<C><<<grid, 256, smem, s>>>(x, w, dl, dx, partial, P, HW, Cin, ntiles, relu_mask);
+  final_bwd_finalize_kernel<<<npairs, 256, 0, s>>>(partial, grid, C, Cin, dw, db);
+  return RS_LAUNCH_RESULT();
+}
+
+}  // namespace
+
+extern "C" int rs_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W, int C, int k,
+                                int stride, int pad, int Ho, int Wo, int accumulate, rs_stream_t stream) {
+  if (!dy || !argmax || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k <= 0 || k > 15 || stride <= 0 ||
+      pad < 0 || Ho <= 0 || Wo <= 0)
+    return RS_EINVAL;
+  const long total = (long)N * H * W * (C / 4);
+  maxpool_bwd_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(dy, argmax, dx, H, W, C / 4, k, stride, pad, Ho,
+                                                                           Wo, total, accumulate);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_upsample2x_bwd(const float* dup, float* d1, float* d2, const float* mask1, const float* mask2, int N,
+                                 int H, int W, int C1, int C2, int accumulate1, rs_stream_t stream) {
+  if (!dup || !d1 || N <= 0 || H <= 0 || W <= 0 || C1 <= 0 || (C1 & 3) || C2 < 0 || (C2 & 3)) return RS_EINVAL;
+  if (C2 > 0 && !d2) return RS_EINVAL;
+  const long total = (long)N * H * W * ((C1 + C2) / 4);
+  upsample2x_bwd_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(dup, d1, d2, mask1, mask2, H, W, C1, C2,
+                                                                              total, accumulate1);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" long rs_final_conv1x1_bwd_workspace_bytes(int Cin, int C) {
+  if (Cin <= 0 || Cin > 64 || C <= 0 || C > 8) return RS_EINVAL;
+  return (long)kFinalBwdMaxBlocks * C * (Cin + 1) * (long)sizeof(float);
+}
+
+extern "C" int rs_final_conv1x1_bwd(const float* x, const float* w, const float* dlogits, float* dx, float* dw, float* db,
+                                    int N, int H, int W, int Cin, int C, int relu_mask, void* workspace,
+                                    rs_stream_t stream) {
+  if (!x || !w || !dlogits || !dx || !dw || !db || !workspace || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) ||
+      Cin > 64 || C <= 0 || C > 8)
+    return RS_EINVAL;
+  const long HW = (long)H * W, P = (long)N * HW;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = reinterpret_cast<float*>(workspace);
+  switch (C) {
+    case 1: return launch_final_bwd<1>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 2: return launch_final_bwd<2>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 3: return launch_final_bwd<3>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 4: return launch_final_bwd<4>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 5: return launch_final_bwd<5>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 6: return launch_final_bwd<6>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 7: return launch_final_bwd<7>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    default: return launch_final_bwd<8>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+  }
+}

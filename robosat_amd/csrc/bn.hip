@@ -1,0 +1,256 @@
+// Train-mode BatchNorm2d for NHWC activations viewed as an [M = N*H*W][C] matrix: per-channel column reductions and
+// elementwise normalise / backward kernels.  HBM-bound: every kernel streams its operands once with 16-byte accesses
+// (4 consecutive channels per thread, consecutive threads on consecutive channel quads => full 128-B segments).
+//
+// Reference semantics (torch.nn.BatchNorm2d as used by torchvision's ResNet-50 under robosat/unet.py:122-130, train
+// mode in tools/train.py:169): normalise with the batch mean and BIASED variance, eps 1e-5; update running_mean /
+// running_var with momentum 0.1 and the UNBIASED variance; num_batches_tracked += 1.
+//
+// Reductions: stage 1 writes per-row-split partial sums in fp64 (one thread accumulates its rows in fp64, the
+// block combines its row lanes through LDS), stage 2 combines the splits -- deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxSplits = 512;
+
+struct Geometry {
+  int Q;     // channel quads per row
+  int qb;    // quads per block
+  int rpb;   // row lanes per block
+  int gx;    // blocks along channels
+  int R;     // row splits
+  long rows_per_split;
+};
+
+Geometry geometry(long M, int C) {
+  Geometry g;
+  g.Q = C / 4;
+  g.qb = g.Q < 256 ? g.Q : 256;
+  g.rpb = 256 / g.qb;
+  g.gx = rs_cdiv(g.Q, g.qb);
+  // aim at ~2048 blocks, at least 64 rows per row lane
+  long want = 2048 / g.gx;
+  if (want < 1) want = 1;
+  long maxsplit = M / ((long)g.rpb * 64);
+  if (maxsplit < 1) maxsplit = 1;
+  long R = want < maxsplit ? want : maxsplit;
+  if (R > kMaxSplits) R = kMaxSplits;
+  g.rows_per_split = (M + R - 1) / R;
+  g.R = rs_cdiv(M, g.rows_per_split);
+  return g;
+}
+
+// MODE 0: s0 = sum y,  s1 = sum y^2                       (forward statistics)
+// MODE 1: s0 = sum g,  s1 = sum g * (y - mean) * invstd     (backward; g = dz * (z > 0) when zmask != null)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ y, const float* __restrict__ dz,
+                                                         const float* __restrict__ zmask, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, double* __restrict__ part,
+                                                         long M, int C, int qb, int rpb, long rows_per_split) {
+  __shared__ double red[256 * 8];
+  const int tid = threadIdx.x;
+  const int Q = C >> 2;
+  const int ql = tid % qb, rl = tid / qb;
+  const int q = blockIdx.x * qb + ql;
+  const long r0 = (long)blockIdx.y * rows_per_split;
+  long r1 = r0 + rows_per_split;
+  if (r1 > M) r1 = M;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  const bool active = (q < Q) && (rl < rpb);
+  if (active) {
+    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+      is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+    }
+    for (long r = r0 + rl; r < r1; r += rpb) {
+      const long o = r * C + q * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0[e] += (double)v[e];
+          s1[e] += (double)v[e] * (double)v[e];
+        }
+      } else {
+        f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
+        if (zmask) {
+          const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0[e] += (double)g[e];
+          s1[e] += (double)g[e] * (double)((v[e] - mu[e]) * is[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[tid * 8 + e] = s0[e];
+    red[tid * 8 + 4 + e] = s1[e];
+  }
+  __syncthreads();
+  if (active && rl == 0) {
+    for (int g = 1; g < rpb; ++g) {
+      const double* o = red + (g * qb + ql) * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] += o[e];
+        s1[e] += o[4 + e];
+      }
+    }
+    double* p0 = part + ((long)blockIdx.y * 2) * C + q * 4;
+    double* p1 = p0 + C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p0[e] = s0[e];
+      p1[e] = s1[e];
+    }
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int R, long M, int C, float eps, float momentum,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int r = 0; r < R; ++r) {
+    s += part[((long)r * 2) * C + c];
+    ss += part[((long)r * 2 + 1) * C + c];
+  }
+  const double mu = s / (double)M;
+  double var = ss / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mu * sc;
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// coef[0][c] = k1 = gamma*invstd, coef[1][c] = k2 = k1*sum(g)/M, coef[2][c] = k3 = k1*invstd*sum(g*xhat)/M
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int R, long M, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int r = 0; r < R; ++r) {
+    s0 += part[((long)r * 2) * C + c];
+    s1 += part[((long)r * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)s0;
+  dgamma[c] = (float)s1;
+  const double k1 = (double)gamma[c] * (double)invstd[c];
+  coef[c] = (float)k1;
+  coef[C + c] = (float)(k1 * s0 / (double)M);
+  coef[2 * C + c] = (float)(k1 * (double)invstd[c] * s1 / (double)M);
+}
+
+// out = relu?( y * scale[c] + shift[c] (+ residual) )
+__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                const float* __restrict__ res, float* __restrict__ out, long total4, int Q, int relu) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int q = (int)(i % Q);
+  f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+  f32x4 r = {0, 0, 0, 0};
+  if (res) r = *reinterpret_cast<const f32x4*>(res + i * 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = v[e] * sc[e] + sh[e] + r[e];
+    v[e] = relu ? fmaxf(t, 0.f) : t;
+  }
+  *reinterpret_cast<f32x4*>(out + i * 4) = v;
+}
+
+// dy = k1*g - k2 - k3*(y - mean),  g = dz*(z>0) (or dz);  optionally dmasked = g (gradient of the residual branch)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ zmask, const float* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ coef, float* __restrict__ dy,
+                                    float* __restrict__ dmasked, long total4, int Q) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int q = (int)(i % Q);
+  const int C = Q * 4;
+  f32x4 g = *reinterpret_cast<const f32x4*>(dz + i * 4);
+  if (zmask) {
+    const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+  }
+  const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+  const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + q * 4);
+  const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + C + q * 4);
+  const f32x4 k3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + q * 4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = k1[e] * g[e] - k2[e] - k3[e] * (v[e] - mu[e]);
+  *reinterpret_cast<f32x4*>(dy + i * 4) = o;
+  if (dmasked) *reinterpret_cast<f32x4*>(dmasked + i * 4) = g;
+}
+
+}  // namespace
+
+extern "C" long rs_bn_workspace_bytes(long M, int C) {
+  if (M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
+  const Geometry g = geometry(M, C);
+  return (long)g.R * 2 * C * (long)sizeof(double);
+}
+
+extern "C" int rs_bn_train_stats(const float* y, long M, int C, float eps, float momentum, const float* gamma,
+                                 const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked, void* workspace,
+                                 rs_stream_t stream) {
+  if (!y || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace || M <= 0 || C <= 0 || (C & 3))
+    return RS_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return RS_EINVAL;
+  const Geometry g = geometry(M, C);
+  hipStream_t s = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(workspace);
+  bn_partial_kernel<0><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
+                                                       g.rows_per_split);
+  bn_stats_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd, scale,
+                                                           shift, running_mean, running_var, num_batches_tracked);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out,
+                           long M, int C, int relu, rs_stream_t stream) {
+  if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
+  const long total4 = M * (C / 4);
+  bn_apply_kernel<<<rs_cdiv(total4, 256), 256, 0, (hipStream_t)stream>>>(y, scale, shift, residual, out, total4, C / 4, relu);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_bn_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
+                         const float* gamma, float* dy, float* dmasked, float* dgamma, float* dbeta, long M, int C,
+                         void* workspace, rs_stream_t stream) {
+  if (!dz || !y || !mean || !invstd || !gamma || !dy || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || (C & 3))
+    return RS_EINVAL;
+  const Geometry g = geometry(M, C);
+  hipStream_t s = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(workspace);
+  float* coef = reinterpret_cast<float*>(part + (long)g.R * 2 * C);  // 3*C floats behind the partials
+  bn_partial_kernel<1><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb, g.rows_per_split);
+  bn_bwd_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, gamma, invstd, dgamma, dbeta, coef);
+  const long total4 = M * (C / 4);
+  bn_bwd_apply_kernel<<<rs_cdiv(total4, 256), 256, 0, s>>>(dz, zmask, y, mean, coef, dy, dmasked, total4, C / 4);
+  return RS_LAUNCH_RESULT();
+}

@@ -18,8 +18,12 @@
 //   MFMA   = lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].  Each lane reads 4 consecutive k per
 //            operand with one b128 (k = 8j + 4*(l>>5) + t) and issues 4 MFMAs; A and B use the same k
 //            permutation, so every k of the chunk is consumed exactly once.
-//   store  = D[i][j]: j = l&31 (cout), i = (reg&3) + 8*(reg>>2) + 4*(l>>5) (pixel): each store instruction writes
-//            two full 128-B segments.  Epilogue: per-cout scale/shift (eval BatchNorm), residual add, ReLU.
+//            The WEIGHT fragment is the A operand, so D[i][j] has i = cout, j = pixel and a lane's registers
+//            4g..4g+3 hold 4 consecutive couts of one pixel.
+//   store  = the accumulators are staged through the (now idle) LDS as [pixel][cout] with ds_write_b128, then
+//            read back row-wise so every global access of the epilogue (output store, residual / ReLU-mask read)
+//            is a 16-byte access on consecutive couts: whole 128-B lines per wave instruction.  Epilogue:
+//            per-cout scale/shift (eval BatchNorm), residual add, ReLU, ReLU-mask (backward).
 //
 // The 7x7/2 stem (Cin = 3, padded to NHWC4) uses the same kernel with STEM = 1: a chunk is one filter ROW,
 // 8 taps x 4 channels = 32 contiguous floats, per-tap bounds checks, weights packed [Cout][7][8][4].
@@ -34,6 +38,7 @@ struct ConvArgs {
   const float* scale;
   const float* shift;
   const float* res;
+  const float* mask;
   float* out;
   int Hs, Ws, C1, C2, Hv, Wv, ups;
   int kw, stride, pad, Ho, Wo, Cout;
@@ -151,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
     for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&L[(BM + lrow + 32 * i) * LDK + c4 * 4]) = rb[i];
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[TN][TM];  // [cout sub-tile][pixel sub-tile]; D rows = couts, D cols = pixels
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int a = 0; a < TN; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], acc[tm][tn], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[tn][t], a[tm][t], acc[tn][tm], 0, 0, 0);
     }
   };
 
@@ -194,26 +199,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------------
+  // ---- epilogue: registers -> LDS [pixel][cout] -> 16-byte row-wise global accesses ----------------------------
+  // (the loop's trailing barrier guarantees nobody still reads the pipeline buffers)
+  constexpr int LDO = BN + 4;  // row stride: 8 consecutive pixel rows land on 8 distinct 4-bank groups
+  static_assert(BM * LDO <= 2 * BUF, "staging tile must fit in the pipeline buffers");
+  {
+    const int prow = wm * WM + (lane & 31);
+    const int ccol = wn * WN + 4 * (lane >> 5);
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + wn * WN + tn * 32 + (lane & 31);
-    const float sc = p.scale ? p.scale[col] : 1.f;
-    const float sh = p.shift ? p.shift[col] : 0.f;
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = m0 + wm * WM + tm * 32 + row;
-        if (m < p.M) {
-          const long o = (long)m * p.Cout + col;
-          float v = acc[tm][tn][r] * sc + sh;
-          if (p.res) v += p.res[o];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.out[o] = v;
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = acc[tn][tm][4 * g + 0];
+          v[1] = acc[tn][tm][4 * g + 1];
+          v[2] = acc[tn][tm][4 * g + 2];
+          v[3] = acc[tn][tm][4 * g + 3];
+          *reinterpret_cast<f32x4*>(&lds[(prow + 32 * tm) * LDO + ccol + 32 * tn + 8 * g]) = v;
         }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = BN / 4;                // float4 chunks per row
+    constexpr int RPI = 256 / CPR;             // rows per iteration
+    const int cc = tid % CPR, rr = tid / CPR;  // CPR is a power of two <= 32
+    const int col = n0 + cc * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+    for (int row = rr; row < BM; row += RPI) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      const long o = (long)m * p.Cout + col;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+      if (p.res) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
       }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.mask) {
+        const f32x4 z = *reinterpret_cast<const f32x4*>(p.mask + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(p.out + o) = v;
     }
   }
 }
@@ -270,8 +308,8 @@ extern "C" int rs_conv2d_tile(const rs_conv_desc* d) { return valid(d) ? pick_ti
 extern "C" const char* rs_conv2d_tile_name(int tile) { return (tile >= 0 && tile < NTILES) ? kTileNames[tile] : ""; }
 
 extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const float* src2, const float* weight,
-                             const float* scale, const float* shift, const float* residual, float* out,
-                             rs_stream_t stream) {
+                             const float* scale, const float* shift, const float* residual, const float* relu_mask,
+                             float* out, rs_stream_t stream) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
   ConvArgs a;
@@ -281,6 +319,7 @@ extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const flo
   a.scale = scale;
   a.shift = shift;
   a.res = residual;
+  a.mask = relu_mask;
   a.out = out;
   a.Hs = d->Hs;
   a.Ws = d->Ws;

@@ -144,7 +144,7 @@ int launch_final(const float* x, const float* w, const float* bias, float* out, 
 
 }  // namespace
 
-extern "C" int rs_abi_version(void) { return 1; }
+extern "C" int rs_abi_version(void) { return 2; }
 
 extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;

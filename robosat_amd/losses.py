@@ -1,0 +1,80 @@
+"""Losses of the reference (``robosat/losses.py``) on the MI355X: same class names, constructor arguments and
+``forward(inputs[N,C,H,W] float32, targets[N,H,W] int64) -> 0-dim tensor`` contract (tools/train.py:97-106,185), with
+the arithmetic in ``librobosat_hip.so`` (``rs_nll_loss_*``, ``rs_lovasz_fwd``).  No CPU path."""
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _check(inputs, targets):
+    if not inputs.is_cuda:
+        raise RuntimeError("robosat_amd losses run on the MI355X only (got a {} tensor); there is no CPU fallback".format(inputs.device))
+    assert inputs.dim() == 4 and targets.dim() == 3 and inputs.shape[0] == targets.shape[0] and inputs.shape[2:] == targets.shape[1:]
+    assert targets.dtype == torch.int64
+    return inputs.contiguous(), targets.contiguous()
+
+
+class _NLLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, weight, mode, gamma):
+        x = inputs.detach().float()
+        loss, stats = ops.nll_loss_fwd(x, targets, weight, mode, gamma)
+        ctx.save_for_backward(x, targets, stats)
+        ctx.weight, ctx.mode, ctx.gamma = weight, mode, gamma
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, targets, stats = ctx.saved_tensors
+        g = grad_out.detach().float().contiguous()
+        return ops.nll_loss_bwd(x, targets, ctx.weight, stats, g, ctx.mode, ctx.gamma), None, None, None, None
+
+
+class _LovaszFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets):
+        loss, grad_unit = ops.lovasz_fwd(inputs.detach().float(), targets, want_grad=True)
+        ctx.save_for_backward(grad_unit)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad_unit,) = ctx.saved_tensors
+        return ops.scale_by_scalar(grad_unit, grad_out.detach().float().contiguous()), None
+
+
+class _WeightedLoss(nn.Module):
+    def __init__(self, weight=None):
+        super().__init__()
+        # a buffer (not a parameter) so that ``criterion.to(device)`` moves it, as nn.NLLLoss(weight) does
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32).clone())
+
+
+class CrossEntropyLoss2d(_WeightedLoss):
+    """Cross-entropy: weighted NLL of log_softmax over the class axis (reference losses.py:8-25)."""
+
+    def forward(self, inputs, targets):
+        inputs, targets = _check(inputs, targets)
+        return _NLLFn.apply(inputs, targets, self.weight, ops.NLL_CROSS_ENTROPY, 0.0)
+
+
+class FocalLoss2d(_WeightedLoss):
+    """Focal loss, gamma = 2 by default (reference losses.py:28-50)."""
+
+    def __init__(self, gamma=2, weight=None):
+        super().__init__(weight)
+        self.gamma = gamma
+
+    def forward(self, inputs, targets):
+        inputs, targets = _check(inputs, targets)
+        return _NLLFn.apply(inputs, targets, self.weight, ops.NLL_FOCAL, float(self.gamma))
+
+
+class LovaszLoss2d(nn.Module):
+    """The reference's Lovasz hinge variant over the flattened C*H*W vector per image (losses.py:86-119)."""
+
+    def forward(self, inputs, targets):
+        inputs, targets = _check(inputs, targets)
+        return _LovaszFn.apply(inputs, targets)

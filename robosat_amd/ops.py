@@ -54,10 +54,11 @@ def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=
 
 
 def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False,
-           stem=0, out_hw=None, out=None):
+           stem=0, out_hw=None, out=None, relu_mask=None):
     """``rs_conv2d_fwd``: out = relu?(conv(gather(src1|src2)) * scale + shift + residual).
 
-    ``stem``: 0, or the true filter width (7) when ``weight`` is the packed ``[Cout,kh,8,4]`` stem filter."""
+    ``stem``: 0, or the true filter width (7) when ``weight`` is the packed ``[Cout,kh,8,4]`` stem filter.
+    ``relu_mask``: tensor shaped like ``out``; the result is zeroed where it is <= 0 (fused ReLU backward)."""
 
     d = conv_desc(src1, weight, src2, ups, stride, pad, relu, stem, out_hw)
     if out is None:
@@ -68,12 +69,14 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
         assert weight.shape[3] == d.C1 + d.C2, "weight Cin {} != {}+{}".format(weight.shape[3], d.C1, d.C2)
     if residual is not None:
         assert residual.shape == out.shape
+    if relu_mask is not None:
+        assert relu_mask.shape == out.shape
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     rc = _lib.lib().rs_conv2d_fwd(
         ctypes.byref(d), _dev(src1, "src1"), _dev(src2, "src2"), _dev(weight, "weight"), _dev(scale, "scale"),
-        _dev(shift, "shift"), _dev(residual, "residual"), _dev(out, "out"), _stream(),
+        _dev(shift, "shift"), _dev(residual, "residual"), _dev(relu_mask, "relu_mask"), _dev(out, "out"), _stream(),
     )
     check(rc, "rs_conv2d_fwd")
     if PROFILE is not None:
@@ -135,3 +138,219 @@ def final_conv1x1(x, w, bias, softmax=False):
                                      int(softmax), _stream())
     check(rc, "rs_final_conv1x1")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training path
+# ------------------------------------------------------------------------------------------------------------------
+
+_WORKSPACE = {}
+
+
+def _workspace(nbytes, device):
+    """A per-device scratch buffer, grown on demand.  All kernels run on one stream, so successive users serialise."""
+
+    if nbytes < 0:
+        raise ValueError("workspace query failed (RS_EINVAL)")
+    ws = _WORKSPACE.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        _WORKSPACE[device] = ws
+    return ctypes.c_void_p(ws.data_ptr())
+
+
+def pack_dgrad_weight(w_krsc):
+    """[Cout,kh,kw,Cin] -> [Cin,kh,kw,Cout], taps flipped (weights of the data-gradient convolution)."""
+
+    cout, kh, kw, cin = w_krsc.shape
+    out = torch.empty((cin, kh, kw, cout), device=w_krsc.device, dtype=torch.float32)
+    check(_lib.lib().rs_pack_dgrad_weight(_dev(w_krsc, "w"), _dev(out, "out"), cout, kh, kw, cin, _stream()),
+          "rs_pack_dgrad_weight")
+    return out
+
+
+def unpack_stem_weight(packed, kw, cin, out=None):
+    cout, kh = packed.shape[:2]
+    if out is None:
+        out = torch.empty((cout, kh, kw, cin), device=packed.device, dtype=torch.float32)
+    assert tuple(out.shape) == (cout, kh, kw, cin)
+    check(_lib.lib().rs_unpack_stem_weight(_dev(packed, "packed"), _dev(out, "out"), cout, kh, kw, cin, _stream()),
+          "rs_unpack_stem_weight")
+    return out
+
+
+def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, out=None):
+    """``rs_conv2d_wgrad``: KRSC filter gradient [Cout,kh,kw,Cin] (packed [Cout,kh,8,4] for the stem)."""
+
+    n, ho, wo, cout = dy.shape
+    _, hs, ws, c1 = src1.shape
+    c2 = 0 if src2 is None else src2.shape[3]
+    d = ConvDesc(n, hs, ws, c1, c2, ups, kh, kw, stride, pad, ho, wo, cout, 0, int(bool(stem)))
+    lib = _lib.lib()
+    shape = (cout, kh, 8, 4) if stem else (cout, kh, kw, c1 + c2)
+    dw = out if out is not None else torch.empty(shape, device=dy.device, dtype=torch.float32)
+    assert tuple(dw.shape) == shape
+    wsb = lib.rs_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.rs_conv2d_wgrad(ctypes.byref(d), _dev(dy, "dy"), _dev(src1, "src1"), _dev(src2, "src2"), _dev(dw, "dw"),
+                             _workspace(wsb, dy.device), _stream())
+    check(rc, "rs_conv2d_wgrad")
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append(("conv_wgrad_f32", conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
+    return dw
+
+
+def _bn_ws(m, c, device):
+    return _workspace(_lib.lib().rs_bn_workspace_bytes(m, c) + 3 * c * 4, device)
+
+
+def bn_train_stats(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """Batch statistics of y [N,H,W,C]; returns (mean, invstd, scale, shift) and updates the running buffers."""
+
+    c = y.shape[-1]
+    m = y.numel() // c
+    mean, invstd, scale, shift = (torch.empty(c, device=y.device, dtype=torch.float32) for _ in range(4))
+    rc = _lib.lib().rs_bn_train_stats(
+        _dev(y, "y"), m, c, ctypes.c_float(eps), ctypes.c_float(momentum), _dev(gamma, "gamma"), _dev(beta, "beta"),
+        _dev(mean, "mean"), _dev(invstd, "invstd"), _dev(scale, "scale"), _dev(shift, "shift"),
+        _dev(running_mean, "running_mean"), _dev(running_var, "running_var"),
+        _dev(num_batches_tracked, "num_batches_tracked", torch.int64), _bn_ws(m, c, y.device), _stream())
+    check(rc, "rs_bn_train_stats")
+    return mean, invstd, scale, shift
+
+
+def bn_apply(y, scale, shift, residual=None, relu=False):
+    c = y.shape[-1]
+    out = torch.empty_like(y)
+    rc = _lib.lib().rs_bn_apply(_dev(y, "y"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(residual, "residual"),
+                                _dev(out, "out"), y.numel() // c, c, int(relu), _stream())
+    check(rc, "rs_bn_apply")
+    return out
+
+
+def bn_bwd(dz, zmask, y, mean, invstd, gamma, want_masked=False, dgamma=None, dbeta=None):
+    """Returns (dy, dgamma, dbeta[, dmasked])."""
+
+    c = y.shape[-1]
+    m = y.numel() // c
+    dy = torch.empty_like(y)
+    dmasked = torch.empty_like(y) if want_masked else None
+    if dgamma is None:
+        dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
+    if dbeta is None:
+        dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
+    rc = _lib.lib().rs_bn_bwd(_dev(dz, "dz"), _dev(zmask, "zmask"), _dev(y, "y"), _dev(mean, "mean"), _dev(invstd, "invstd"),
+                              _dev(gamma, "gamma"), _dev(dy, "dy"), _dev(dmasked, "dmasked"), _dev(dgamma, "dgamma"),
+                              _dev(dbeta, "dbeta"), m, c, _bn_ws(m, c, y.device), _stream())
+    check(rc, "rs_bn_bwd")
+    return (dy, dgamma, dbeta, dmasked) if want_masked else (dy, dgamma, dbeta)
+
+
+def maxpool2d_bwd(dy, argmax, in_shape, k, stride, pad, out=None):
+    """Gradient wrt the pooling input [N,H,W,C]; ``out`` given => accumulate into it."""
+
+    n, h, w, c = in_shape
+    ho, wo = dy.shape[1:3]
+    acc = out is not None
+    if out is None:
+        out = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    rc = _lib.lib().rs_maxpool2d_bwd(_dev(dy, "dy"), _dev(argmax, "argmax", torch.uint8), _dev(out, "dx"), n, h, w, c, k,
+                                     stride, pad, ho, wo, int(acc), _stream())
+    check(rc, "rs_maxpool2d_bwd")
+    return out
+
+
+def upsample2x_bwd(dup, c1, c2=0, mask1=None, mask2=None, out1=None):
+    """dup [N,2H,2W,C1+C2] -> (d1 [N,H,W,C1], d2 [N,H,W,C2] or None); ``out1`` given => accumulate into it."""
+
+    n, h2, w2, ct = dup.shape
+    assert ct == c1 + c2 and h2 % 2 == 0 and w2 % 2 == 0
+    h, w = h2 // 2, w2 // 2
+    acc = out1 is not None
+    d1 = out1 if acc else torch.empty((n, h, w, c1), device=dup.device, dtype=torch.float32)
+    d2 = torch.empty((n, h, w, c2), device=dup.device, dtype=torch.float32) if c2 else None
+    rc = _lib.lib().rs_upsample2x_bwd(_dev(dup, "dup"), _dev(d1, "d1"), _dev(d2, "d2"), _dev(mask1, "mask1"),
+                                      _dev(mask2, "mask2"), n, h, w, c1, c2, int(acc), _stream())
+    check(rc, "rs_upsample2x_bwd")
+    return d1, d2
+
+
+def final_conv1x1_bwd(x, w, dlogits, relu_mask=True, dw=None, db=None):
+    """x [N,H,W,Cin] NHWC, w [C,Cin], dlogits NCHW -> (dx NHWC, dw [C,Cin], db [C])."""
+
+    n, h, wd, cin = x.shape
+    c = w.shape[0]
+    lib = _lib.lib()
+    dx = torch.empty_like(x)
+    if dw is None:
+        dw = torch.empty((c, cin), device=x.device, dtype=torch.float32)
+    if db is None:
+        db = torch.empty(c, device=x.device, dtype=torch.float32)
+    ws = _workspace(lib.rs_final_conv1x1_bwd_workspace_bytes(cin, c), x.device)
+    rc = lib.rs_final_conv1x1_bwd(_dev(x, "x"), _dev(w, "w"), _dev(dlogits, "dlogits"), _dev(dx, "dx"), _dev(dw, "dw"),
+                                  _dev(db, "db"), n, h, wd, cin, c, int(relu_mask), ws, _stream())
+    check(rc, "rs_final_conv1x1_bwd")
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# losses / metrics (NCHW logits, int64 targets)
+# ------------------------------------------------------------------------------------------------------------------
+
+NLL_CROSS_ENTROPY, NLL_FOCAL = 0, 1
+
+
+def nll_loss_fwd(logits, targets, weight, mode, gamma=2.0):
+    n, c, h, w = logits.shape
+    lib = _lib.lib()
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    stats = torch.empty(2, device=logits.device, dtype=torch.float32)
+    rc = lib.rs_nll_loss_fwd(_dev(logits, "logits"), _dev(targets, "targets", torch.int64), _dev(weight, "weight"),
+                             _dev(loss, "loss"), _dev(stats, "stats"), n, c, h, w, mode, ctypes.c_float(gamma),
+                             _workspace(lib.rs_nll_loss_workspace_bytes(), logits.device), _stream())
+    check(rc, "rs_nll_loss_fwd")
+    return loss, stats
+
+
+def nll_loss_bwd(logits, targets, weight, stats, grad_out, mode, gamma=2.0):
+    n, c, h, w = logits.shape
+    dlogits = torch.empty_like(logits)
+    rc = _lib.lib().rs_nll_loss_bwd(_dev(logits, "logits"), _dev(targets, "targets", torch.int64), _dev(weight, "weight"),
+                                    _dev(stats, "stats"), _dev(grad_out, "grad_out"), _dev(dlogits, "dlogits"), n, c, h, w,
+                                    mode, ctypes.c_float(gamma), _stream())
+    check(rc, "rs_nll_loss_bwd")
+    return dlogits
+
+
+def lovasz_fwd(logits, targets, want_grad=True):
+    """Returns (loss, d loss / d logits for grad_out = 1 or None)."""
+
+    n, c, h, w = logits.shape
+    lib = _lib.lib()
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    rc = lib.rs_lovasz_fwd(_dev(logits, "logits"), _dev(targets, "targets", torch.int64), _dev(loss, "loss"),
+                           _dev(grad, "grad"), n, c, h, w,
+                           _workspace(lib.rs_lovasz_workspace_bytes(n, c, h, w), logits.device), _stream())
+    check(rc, "rs_lovasz_fwd")
+    return loss, grad
+
+
+def scale_by_scalar(src, scalar):
+    out = torch.empty_like(src)
+    check(_lib.lib().rs_scale_by_scalar(_dev(src, "src"), _dev(scalar, "scalar"), _dev(out, "out"), src.numel(), _stream()),
+          "rs_scale_by_scalar")
+    return out
+
+
+def confusion_counts(scores, targets, counts):
+    """counts (uint64-as-int64 [4] device tensor) += (tn, fn, fp, tp) of the whole batch (reference naming)."""
+
+    n, c, h, w = scores.shape
+    rc = _lib.lib().rs_confusion_counts(_dev(scores, "scores"), _dev(targets, "targets", torch.int64),
+                                        _dev(counts, "counts", torch.int64), n, c, h, w, _stream())
+    check(rc, "rs_confusion_counts")
+    return counts

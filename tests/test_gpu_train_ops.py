@@ -1,0 +1,221 @@
+"""Parity of the training-path kernels on the MI355X against PyTorch autograd on the host CPU (fp32), op by op."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import robosat_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def krsc(w):
+    return w.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def close(got, want, tol=3e-4, what=""):
+    scale = max(1e-6, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, "{} max abs err {} (scale {})".format(what, err, scale)
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+WGRAD = [
+    # name, N, Cin, H, W, Cout, k, stride, pad   -> wgrad tile
+    ("128x128", 2, 128, 20, 20, 128, 3, 1, 1),
+    ("128x64", 2, 64, 24, 24, 256, 1, 1, 0),
+    ("64x128", 2, 128, 16, 16, 64, 3, 1, 1),
+    ("64x64_s2", 2, 64, 22, 18, 64, 3, 2, 1),
+    ("32x128", 1, 128, 32, 32, 32, 3, 1, 1),
+    ("32x32", 2, 32, 40, 40, 32, 3, 1, 1),
+    ("1x1_s2", 2, 256, 16, 16, 512, 1, 2, 0),
+    ("split_big", 2, 32, 128, 128, 32, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD, ids=[c[0] for c in WGRAD])
+def test_wgrad_and_dgrad(case):
+    from robosat_amd import ops
+
+    _, n, cin, h, w, cout, k, stride, pad = case
+    x = rnd(n, cin, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(cout, cin, k, k, seed=2) * (2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=pad)
+    gy = rnd(*y.shape, seed=3)
+    y.backward(gy)
+    dw = ops.conv2d_wgrad(nhwc(gy), nhwc(x.detach()), k, k, stride=stride, pad=pad)
+    close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="wgrad")
+    wd = ops.pack_dgrad_weight(krsc(wt.detach()))
+    dx = ops.conv2d(nhwc(gy), wd, ups=2 if stride == 2 else 0, pad=k - 1 - pad, out_hw=(h, w))
+    close(nchw(dx), x.grad, what="dgrad")
+
+
+@pytest.mark.parametrize("c1,c2,cout", [(256, 64, 128), (128, 0, 32), (512, 256, 64)])
+def test_decoder_block_backward(c1, c2, cout):
+    """wgrad through the fused upsample+concat gather, dgrad + 2x2 sum + split + ReLU masks."""
+    from robosat_amd import ops
+
+    n, h, w = 2, 8, 12
+    a = rnd(n, c1, h, w, seed=4).requires_grad_(True)
+    b = F.relu(rnd(n, c2, h, w, seed=5)).requires_grad_(True) if c2 else None
+    wt = (rnd(cout, c1 + c2, 3, 3, seed=6) * 0.03).requires_grad_(True)
+    cat = torch.cat([a, b], 1) if c2 else a
+    y = F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1)
+    gy = rnd(*y.shape, seed=7)
+    y.backward(gy)
+    dw = ops.conv2d_wgrad(nhwc(gy), nhwc(a.detach()), 3, 3, src2=nhwc(b.detach()) if c2 else None, ups=1, pad=1)
+    close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="wgrad")
+    dup = ops.conv2d(nhwc(gy), ops.pack_dgrad_weight(krsc(wt.detach())), pad=1)
+    mask2 = nhwc(b.detach()) if c2 else None
+    d1, d2 = ops.upsample2x_bwd(dup, c1, c2, mask2=mask2)
+    close(nchw(d1), a.grad, what="d skip")
+    if c2:
+        close(nchw(d2), b.grad * (b.detach() > 0), what="d prev (masked)")
+    acc = torch.ones_like(d1)
+    d1b, _ = ops.upsample2x_bwd(dup, c1, c2, mask2=mask2, out1=acc)
+    close(nchw(d1b), a.grad + 1.0, what="accumulate")
+
+
+def test_stem_wgrad():
+    from robosat_amd import ops
+
+    for cin in (3, 4):
+        x = rnd(2, cin, 64, 96, seed=8)
+        wt = (rnd(64, cin, 7, 7, seed=9) * 0.1).requires_grad_(True)
+        y = F.conv2d(x, wt, stride=2, padding=3)
+        gy = rnd(*y.shape, seed=10)
+        y.backward(gy)
+        x4 = ops.nchw_to_nhwc4(x.to(DEV))
+        dwp = ops.conv2d_wgrad(nhwc(gy), x4, 7, 7, stride=2, pad=3, stem=7)
+        dw = ops.unpack_stem_weight(dwp, 7, cin)
+        close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="stem wgrad")
+
+
+@pytest.mark.parametrize("c,hw,res,relu", [(64, 24, False, True), (256, 10, True, True), (320, 6, False, False), (2048, 2, True, True)])
+def test_batchnorm_train(c, hw, res, relu):
+    from robosat_amd import ops
+
+    n = 3
+    y = (rnd(n, c, hw, hw, seed=11) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(c) + 0.5).requires_grad_(True)
+    beta = (rnd(c, seed=12) * 0.1).requires_grad_(True)
+    rm, rv = rnd(c, seed=13) * 0.1, torch.rand(c) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    resid = rnd(n, c, hw, hw, seed=14).requires_grad_(True) if res else None
+    out = F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        out = out + resid
+    z = F.relu(out) if relu else out
+    gz = rnd(*z.shape, seed=15)
+    z.backward(gz)
+
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    drm, drv = rm0.to(DEV), rv0.to(DEV)
+    yd = nhwc(y.detach())
+    mean, invstd, scale, shift = ops.bn_train_stats(yd, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, drm, drv, nbt)
+    zd = ops.bn_apply(yd, scale, shift, residual=nhwc(resid.detach()) if res else None, relu=relu)
+    close(nchw(zd), z.detach(), what="bn fwd")
+    close(drm.cpu(), rm, 1e-5, "running_mean")
+    close(drv.cpu(), rv, 1e-5, "running_var")
+    assert int(nbt.item()) == 1
+    dy, dg, db, gm = ops.bn_bwd(nhwc(gz), zd if relu else None, yd, mean, invstd, gamma.detach().to(DEV), want_masked=True)
+    close(nchw(dy), y.grad, 1e-3, "bn dy")
+    close(dg.cpu(), gamma.grad, 1e-3, "dgamma")
+    close(db.cpu(), beta.grad, 1e-3, "dbeta")
+    if res:
+        close(nchw(gm), resid.grad, what="residual grad")
+
+
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (2, 2, 0)])
+def test_maxpool_backward(k, s, p):
+    from robosat_amd import ops
+
+    x = F.relu(rnd(2, 64, 18, 22, seed=16)).requires_grad_(True)  # many exact-zero ties, as after a ReLU
+    y = F.max_pool2d(x, k, s, p)
+    gy = rnd(*y.shape, seed=17)
+    y.backward(gy)
+    _, amax = ops.maxpool2d(nhwc(x.detach()), k, s, p, want_argmax=True)
+    dx = ops.maxpool2d_bwd(nhwc(gy), amax, (2, 18, 22, 64), k, s, p)
+    close(nchw(dx), x.grad, 1e-6)
+    dx2 = ops.maxpool2d_bwd(nhwc(gy), amax, (2, 18, 22, 64), k, s, p, out=torch.ones_like(dx))
+    close(nchw(dx2), x.grad + 1.0, 1e-6)
+
+
+@pytest.mark.parametrize("ncls", [2, 4])
+def test_final_conv_backward(ncls):
+    from robosat_amd import ops
+
+    x = F.relu(rnd(2, 32, 24, 40, seed=18)).requires_grad_(True)
+    w = (rnd(ncls, 32, 1, 1, seed=19) * 0.3).requires_grad_(True)
+    b = rnd(ncls, seed=20).requires_grad_(True)
+    pre = rnd(2, 32, 24, 40, seed=18).requires_grad_(True)  # the same values before the ReLU
+    y = F.conv2d(F.relu(pre), w, b)
+    gy = rnd(*y.shape, seed=21)
+    y.backward(gy)
+    dx, dw, db = ops.final_conv1x1_bwd(nhwc(x.detach()), w.detach().view(ncls, 32).to(DEV), gy.to(DEV), relu_mask=True)
+    close(nchw(dx), pre.grad, what="dx through relu")
+    close(dw.cpu(), w.grad.view(ncls, 32), what="dw")
+    close(db.cpu(), b.grad, what="db")
+
+
+@pytest.mark.parametrize("tag", ["c2", "c4"])
+@pytest.mark.parametrize("name", ["CrossEntropy", "Focal", "Lovasz"])
+def test_losses_match_reference_golden(golden_dir, tag, name):
+    from robosat_amd import losses
+
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    logits = torch.from_numpy(g[tag + "_logits"]).to(DEV).requires_grad_(True)
+    targets = torch.from_numpy(g[tag + "_targets"]).to(DEV)
+    weight = torch.from_numpy(g[tag + "_weight"])
+    crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=weight), "Focal": lambda: losses.FocalLoss2d(weight=weight),
+            "Lovasz": lambda: losses.LovaszLoss2d()}[name]().to(DEV)
+    loss = crit(logits, targets)
+    (loss * 1.5).backward()  # a non-unit upstream gradient
+    want = float(g["{}_{}_loss".format(tag, name)])
+    assert abs(loss.item() - want) <= 2e-5 * max(1.0, abs(want)), (loss.item(), want)
+    close(logits.grad.cpu() / 1.5, torch.from_numpy(g["{}_{}_grad".format(tag, name)]), 2e-4, name + " grad")
+
+
+@pytest.mark.parametrize("n,c,h,w", [(3, 2, 128, 128), (2, 4, 64, 96), (1, 3, 48, 80)])
+def test_lovasz_vs_oracle(n, c, h, w):
+    """Multi-block radix sort / scan sizes (P up to 65k per image) against the CPU oracle."""
+    from robosat_amd import losses
+    from oracle import seeded
+
+    logits = rnd(n, c, h, w, seed=22) * 3
+    targets = seeded.synthetic_targets(n, c, h if h % 8 == 0 else h, w, 3)
+    ref_in = logits.clone().requires_grad_(True)
+    want = R.lovasz2d(ref_in, targets)
+    want.backward()
+    got_in = logits.to(DEV).requires_grad_(True)
+    got = losses.LovaszLoss2d()(got_in, targets.to(DEV))
+    got.backward()
+    assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (got.item(), want.item())
+    close(got_in.grad.cpu(), ref_in.grad, 1e-5, "lovasz grad")
+
+
+def test_metrics_match_reference_golden(golden_dir):
+    from robosat_amd.metrics import Metrics
+
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    m = Metrics(range(2))
+    scores, actual = torch.from_numpy(g["scores"]).to(DEV), torch.from_numpy(g["actual"]).to(DEV)
+    m.add(actual[0], scores[0])  # reference-style single sample
+    m.add_batch(actual[1:], scores[1:])
+    assert [m.tn, m.fn, m.fp, m.tp] == g["counts"].tolist()
+    assert np.allclose([m.get_miou(), m.get_fg_iou(), m.get_mcc()], g["scores3"], rtol=0, atol=1e-12)

@@ -1,0 +1,64 @@
+"""One full training step on the MI355X (train-mode forward with batch statistics, loss, hand-scheduled backward)
+against the golden vectors produced by the unmodified reference (tests/golden/make_golden.py: 2x3x128x128, 2 classes).
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import robosat_ref as R, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("loss_name", ["CrossEntropy", "Lovasz"])
+def test_train_step_matches_reference_golden(golden_dir, loss_name):
+    from robosat_amd import losses
+    from robosat_amd.unet import UNet
+
+    g = np.load(os.path.join(golden_dir, "train_step_{}.npz".format(loss_name)))
+    net = UNet(2, pretrained=False)
+    net.load_state_dict(seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 2))
+    net = net.to(DEV).train()
+    x = seeded.synthetic_images(2, 3, 128, 128, 2).to(DEV)
+    t = seeded.synthetic_targets(2, 2, 128, 128, 2).to(DEV)
+    crit = (losses.CrossEntropyLoss2d(weight=torch.tensor([1.6248, 5.762827])) if loss_name == "CrossEntropy" else losses.LovaszLoss2d()).to(DEV)
+
+    logits = net(x)
+    loss = crit(logits, t)
+    loss.backward()
+
+    err_logits = float(np.abs(logits.detach().cpu().numpy() - g["logits"]).max())
+    print(loss_name, "loss", loss.item(), float(g["loss"]), "max|dlogits|", err_logits)
+    assert err_logits <= 2e-3 * max(1.0, float(np.abs(g["logits"]).max()))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3 * max(1.0, abs(float(g["loss"])))
+
+    params = dict(net.named_parameters())
+    assert params["resnet.fc.weight"].grad is None  # unused in forward, as in the reference
+    worst = 0.0
+    for name, want_norm in zip(g["grad_names"], g["grad_norms"]):
+        grad = params[str(name)].grad
+        assert grad is not None, name
+        got_norm = float(grad.double().norm())
+        rel = abs(got_norm - want_norm) / max(want_norm, 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 2e-2, (str(name), got_norm, float(want_norm))
+    print("worst grad-norm relative error", worst)
+    for key in g.files:
+        if key.startswith("grad/"):
+            want = torch.from_numpy(g[key])
+            got = params[key[5:]].grad.cpu()
+            err = float((got - want).abs().max())
+            assert err <= 2e-2 * max(1e-8, float(want.abs().max())), (key, err, float(want.abs().max()))
+    sd = net.state_dict()
+    for key in g.files:
+        if key.startswith("bn/"):
+            want = torch.from_numpy(g[key])
+            got = sd[key[3:]].cpu()
+            if want.dtype == torch.int64:
+                assert int(got) == int(want), key
+            else:
+                assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), key

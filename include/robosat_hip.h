@@ -163,6 +163,14 @@ int rs_nll_loss_bwd(const float* logits, const long long* targets, const float* 
                     const float* grad_out, float* dlogits, int N, int C, int H, int W, int mode, float gamma,
                     rs_stream_t stream);
 
+/* mIoULoss2d (losses.py:53-83): max(1 - mean_{c,n} softIoU, weighted NLL), gradient through the larger branch.
+ * stats needs 3 + 2*N*C floats (loss, sum w, chosen branch, per-(n,c) gradient coefficients). */
+long rs_miou_loss_workspace_bytes(int N, int C);
+int rs_miou_loss_fwd(const float* logits, const long long* targets, const float* weight, float* loss, float* stats, int N,
+                     int C, int H, int W, void* workspace, rs_stream_t stream);
+int rs_miou_loss_bwd(const float* logits, const long long* targets, const float* weight, const float* stats,
+                     const float* grad_out, float* dlogits, int N, int C, int H, int W, rs_stream_t stream);
+
 /* LovaszLoss2d (losses.py:86-119): batched radix sort + scans.  loss[0] = mean over images; grad_unit (optional,
  * NCHW like logits) receives d loss / d logits for grad_out = 1 (multiply with rs_scale_by_scalar). */
 long rs_lovasz_workspace_bytes(int N, int C, int H, int W);

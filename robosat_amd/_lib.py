@@ -58,6 +58,9 @@ SIGNATURES = {
     "rs_nll_loss_workspace_bytes": (c_long, []),
     "rs_nll_loss_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
     "rs_nll_loss_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "rs_miou_loss_workspace_bytes": (c_long, [c_int, c_int]),
+    "rs_miou_loss_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "rs_miou_loss_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "rs_lovasz_workspace_bytes": (c_long, [c_int, c_int, c_int, c_int]),
     "rs_lovasz_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "rs_scale_by_scalar": (c_int, [P, P, P, c_long, P]),

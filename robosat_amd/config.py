@@ -1,0 +1,39 @@
+"""TOML configuration files (model / dataset), same keys as the reference (``robosat/config.py``, ``config/*.toml``).
+
+Model:   [common] cuda, batch_size, image_size, checkpoint   [opt] epochs, lr, loss
+Dataset: [common] dataset, classes, colors                   [weights] values
+``cuda = true`` means "use the MI355X" (the HIP device shows up as torch's ``cuda``); ``cuda = false`` is rejected by
+the tools because this implementation has no CPU compute path.
+"""
+
+import tomli
+
+
+def load_config(path):
+    """Parses the TOML file at ``path`` into a dictionary."""
+
+    with open(path, "rb") as fp:
+        return tomli.load(fp)
+
+
+def _fmt(v):
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, (int, float)):
+        return repr(v)
+    if isinstance(v, str):
+        return "'{}'".format(v) if "'" not in v else '"{}"'.format(v.replace("\\", "\\\\").replace('"', '\\"'))
+    if isinstance(v, (list, tuple)):
+        return "[" + ", ".join(_fmt(x) for x in v) + "]"
+    raise TypeError("unsupported TOML value: {!r}".format(v))
+
+
+def save_config(attrs, path):
+    """Writes a two-level configuration dictionary (``{table: {key: scalar | list}}``) as TOML."""
+
+    with open(path, "w") as fp:
+        for table, entries in attrs.items():
+            fp.write("[{}]\n".format(table))
+            for key, value in entries.items():
+                fp.write("  {} = {}\n".format(key, _fmt(value)))
+            fp.write("\n")

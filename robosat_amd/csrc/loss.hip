@@ -201,6 +201,154 @@ int run_conf(const float* x, const long long* t, unsigned long long* counts, lon
   return RS_LAUNCH_RESULT();
 }
 
+
+// ---- mIoULoss2d (robosat/losses.py:53-83) ------------------------------------------------------------------------
+// soft IoU per (class c, image n): inter = sum_p s_c m_c, union = sum_p (s_c + m_c - s_c m_c); miou = 1 - mean(inter/union);
+// the reference returns Python max(miou, weighted NLL): whichever is larger, gradient through that branch only.
+// Per-(n,c) sums: A = sum_{p: t=c} s_c, B = sum_p s_c, cnt = #{p: t=c}  =>  inter = A, union = B + cnt - A.
+template <int C>
+__global__ __launch_bounds__(256) void miou_partial_kernel(const float* __restrict__ x, const long long* __restrict__ tgt,
+                                                           const float* __restrict__ weight, double* __restrict__ partial,
+                                                           long HW, int nblk) {
+  // partial[(n*nblk + b)][3*C + 2]
+  __shared__ double red[4][3 * C + 2];
+  const long n = blockIdx.y;
+  double acc[3 * C + 2];
+#pragma unroll
+  for (int i = 0; i < 3 * C + 2; ++i) acc[i] = 0;
+  for (long hw = (long)blockIdx.x * 256 + threadIdx.x; hw < HW; hw += (long)nblk * 256) {
+    float v[C];
+    load_logits<C>(x, n, hw, HW, v);
+    const int t = (int)tgt[n * HW + hw];
+    float mx = v[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, v[c]);
+    float e[C], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      e[c] = expf(v[c] - mx);
+      sum += e[c];
+    }
+    float xt = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float sc = e[c] / sum;
+      acc[c] += (c == t) ? (double)sc : 0.0;
+      acc[C + c] += (double)sc;
+      acc[2 * C + c] += (c == t) ? 1.0 : 0.0;
+      xt = (c == t) ? v[c] : xt;
+    }
+    const float w = weight ? weight[t] : 1.f;
+    acc[3 * C] += (double)(w * ((logf(sum) + mx) - xt));
+    acc[3 * C + 1] += (double)w;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 3 * C + 2; ++i) {
+    const double s = rs_wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * C + 2) {
+    const int i = threadIdx.x;
+    partial[(n * nblk + blockIdx.x) * (3 * C + 2) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+// stats: [0] loss, [1] sum w, [2] branch (0 = miou, 1 = nll), [3 + n*C + c] = g for m=1, [3 + N*C + n*C + c] = g for m=0
+__global__ void miou_finalize_kernel(const double* __restrict__ partial, int N, int C, int nblk, float* __restrict__ loss,
+                                     float* __restrict__ stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int S = 3 * C + 2;
+  double sl = 0, sw = 0, rsum = 0;
+  for (int n = 0; n < N; ++n) {
+    for (int c = 0; c < C; ++c) {
+      double A = 0, B = 0, cnt = 0;
+      for (int b = 0; b < nblk; ++b) {
+        const double* p = partial + ((long)n * nblk + b) * S;
+        A += p[c];
+        B += p[C + c];
+        cnt += p[2 * C + c];
+      }
+      const double U = B + cnt - A;
+      rsum += A / U;
+      const double k = 1.0 / ((double)C * (double)N);
+      stats[3 + n * C + c] = (float)(-k / U);
+      stats[3 + N * C + n * C + c] = (float)(k * A / (U * U));
+    }
+    for (int b = 0; b < nblk; ++b) {
+      const double* p = partial + ((long)n * nblk + b) * S;
+      sl += p[3 * C];
+      sw += p[3 * C + 1];
+    }
+  }
+  const float miou = (float)(1.0 - rsum / ((double)C * (double)N));
+  const float nll = (float)(sl / sw);
+  const bool use_nll = nll > miou;  // Python max(miou, nll): returns nll only if nll > miou
+  loss[0] = use_nll ? nll : miou;
+  stats[0] = loss[0];
+  stats[1] = (float)sw;
+  stats[2] = use_nll ? 1.f : 0.f;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void miou_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ tgt,
+                                                       const float* __restrict__ weight, const float* __restrict__ stats,
+                                                       const float* __restrict__ gout, float* __restrict__ dx, int N, long HW) {
+  const long hw = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = blockIdx.y;
+  if (hw >= HW) return;
+  float v[C], g[C];
+  load_logits<C>(x, n, hw, HW, v);
+  const int t = (int)tgt[n * HW + hw];
+  const float go = gout ? gout[0] : 1.f;
+  if (stats[2] > 0.5f) {
+    const float w = weight ? weight[t] : 1.f;
+    pixel_loss<C>(v, t, 0, 0.f, &g);
+    const float k = go * w / stats[1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dx[(n * C + c) * HW + hw] = k * g[c];
+    return;
+  }
+  float mx = v[0];
+#pragma unroll
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, v[c]);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    v[c] = expf(v[c] - mx);
+    sum += v[c];
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    v[c] = v[c] / sum;
+    g[c] = (c == t) ? stats[3 + n * C + c] : stats[3 + N * C + n * C + c];
+    dot += g[c] * v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) dx[(n * C + c) * HW + hw] = go * v[c] * (g[c] - dot);
+}
+
+constexpr int kMiouBlocks = 64;  // per image
+
+template <int C>
+int run_miou_fwd(const float* x, const long long* t, const float* w, float* loss, float* stats, double* part, int N, long HW,
+                 hipStream_t s) {
+  const long nb = (HW + 255) / 256;
+  const int nblk = nb < kMiouBlocks ? (int)nb : kMiouBlocks;
+  miou_partial_kernel<C><<<dim3(nblk, N), 256, 0, s>>>(x, t, w, part, HW, nblk);
+  miou_finalize_kernel<<<1, 64, 0, s>>>(part, N, C, nblk, loss, stats);
+  return RS_LAUNCH_RESULT();
+}
+
+template <int C>
+int run_miou_bwd(const float* x, const long long* t, const float* w, const float* stats, const float* gout, float* dx, int N,
+                 long HW, hipStream_t s) {
+  miou_bwd_kernel<C><<<dim3(rs_cdiv(HW, 256), N), 256, 0, s>>>(x, t, w, stats, gout, dx, N, HW);
+  return RS_LAUNCH_RESULT();
+}
+
 #define RS_DISPATCH_C(C, CALL)              \
   switch (C) {                              \
     case 1: { constexpr int K = 1; return CALL; } \
@@ -244,4 +392,27 @@ extern "C" int rs_confusion_counts(const float* scores, const long long* targets
   const long HW = (long)H * W, P = (long)N * HW;
   hipStream_t s = (hipStream_t)stream;
   RS_DISPATCH_C(C, run_conf<K>(scores, targets, counts, P, HW, s));
+}
+
+extern "C" long rs_miou_loss_workspace_bytes(int N, int C) {
+  if (N <= 0 || C <= 0 || C > kMaxC) return RS_EINVAL;
+  return (long)N * kMiouBlocks * (3 * C + 2) * (long)sizeof(double);
+}
+
+extern "C" int rs_miou_loss_fwd(const float* logits, const long long* targets, const float* weight, float* loss, float* stats,
+                                int N, int C, int H, int W, void* workspace, rs_stream_t stream) {
+  if (!logits || !targets || !loss || !stats || !workspace || N <= 0 || C <= 0 || C > kMaxC || H <= 0 || W <= 0)
+    return RS_EINVAL;
+  const long HW = (long)H * W;
+  hipStream_t s = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(workspace);
+  RS_DISPATCH_C(C, run_miou_fwd<K>(logits, targets, weight, loss, stats, part, N, HW, s));
+}
+
+extern "C" int rs_miou_loss_bwd(const float* logits, const long long* targets, const float* weight, const float* stats,
+                                const float* grad_out, float* dlogits, int N, int C, int H, int W, rs_stream_t stream) {
+  if (!logits || !targets || !stats || !dlogits || N <= 0 || C <= 0 || C > kMaxC || H <= 0 || W <= 0) return RS_EINVAL;
+  const long HW = (long)H * W;
+  hipStream_t s = (hipStream_t)stream;
+  RS_DISPATCH_C(C, run_miou_bwd<K>(logits, targets, weight, stats, grad_out, dlogits, N, HW, s));
 }

@@ -32,6 +32,21 @@ class _NLLFn(torch.autograd.Function):
         return ops.nll_loss_bwd(x, targets, ctx.weight, stats, g, ctx.mode, ctx.gamma), None, None, None, None
 
 
+class _MIoUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, weight):
+        x = inputs.detach().float()
+        loss, stats = ops.miou_loss_fwd(x, targets, weight)
+        ctx.save_for_backward(x, targets, stats)
+        ctx.weight = weight
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, targets, stats = ctx.saved_tensors
+        return ops.miou_loss_bwd(x, targets, ctx.weight, stats, grad_out.detach().float().contiguous()), None, None
+
+
 class _LovaszFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, targets):
@@ -70,6 +85,15 @@ class FocalLoss2d(_WeightedLoss):
     def forward(self, inputs, targets):
         inputs, targets = _check(inputs, targets)
         return _NLLFn.apply(inputs, targets, self.weight, ops.NLL_FOCAL, float(self.gamma))
+
+
+class mIoULoss2d(_WeightedLoss):
+    """Soft mean-IoU loss; like the reference it returns ``max(miou, weighted NLL)`` and back-propagates through
+    whichever of the two is larger (reference losses.py:53-83)."""
+
+    def forward(self, inputs, targets):
+        inputs, targets = _check(inputs, targets)
+        return _MIoUFn.apply(inputs, targets, self.weight)
 
 
 class LovaszLoss2d(nn.Module):

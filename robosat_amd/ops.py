@@ -325,6 +325,28 @@ def nll_loss_bwd(logits, targets, weight, stats, grad_out, mode, gamma=2.0):
     return dlogits
 
 
+def miou_loss_fwd(logits, targets, weight):
+    n, c, h, w = logits.shape
+    lib = _lib.lib()
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    stats = torch.empty(3 + 2 * n * c, device=logits.device, dtype=torch.float32)
+    rc = lib.rs_miou_loss_fwd(_dev(logits, "logits"), _dev(targets, "targets", torch.int64), _dev(weight, "weight"),
+                              _dev(loss, "loss"), _dev(stats, "stats"), n, c, h, w,
+                              _workspace(lib.rs_miou_loss_workspace_bytes(n, c), logits.device), _stream())
+    check(rc, "rs_miou_loss_fwd")
+    return loss, stats
+
+
+def miou_loss_bwd(logits, targets, weight, stats, grad_out):
+    n, c, h, w = logits.shape
+    dlogits = torch.empty_like(logits)
+    rc = _lib.lib().rs_miou_loss_bwd(_dev(logits, "logits"), _dev(targets, "targets", torch.int64), _dev(weight, "weight"),
+                                     _dev(stats, "stats"), _dev(grad_out, "grad_out"), _dev(dlogits, "dlogits"), n, c, h, w,
+                                     _stream())
+    check(rc, "rs_miou_loss_bwd")
+    return dlogits
+
+
 def lovasz_fwd(logits, targets, want_grad=True):
     """Returns (loss, d loss / d logits for grad_out = 1 or None)."""
 

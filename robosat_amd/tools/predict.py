@@ -1,0 +1,99 @@
+"""``rs predict``: same flags and output files as the reference (``robosat/tools/predict.py``) -- one mode-P PNG per
+tile holding the 8-bit quantised foreground probability with the continuous pink palette -- computed by the
+MI355X-native model with the softmax fused into the last kernel.  With several processes (torchrun) the batches are
+dealt round-robin to the ranks; there is no collective."""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader
+from tqdm import tqdm
+
+from robosat_amd.colors import continuous_palette_for_color
+from robosat_amd.config import load_config
+from robosat_amd.datasets import BufferedSlippyMapDirectory
+from robosat_amd.transforms import Compose, ConvertImageMode, ImageToTensor, Normalize
+from robosat_amd.unet import UNet
+
+
+def add_parser(subparser):
+    parser = subparser.add_parser(
+        "predict",
+        help="predicts probability masks for slippy map tiles",
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+    )
+    parser.add_argument("--batch_size", type=int, default=1, help="images per batch")
+    parser.add_argument("--checkpoint", type=str, required=True, help="model checkpoint to load")
+    parser.add_argument("--overlap", type=int, default=32, help="tile pixel overlap to predict on")
+    parser.add_argument("--tile_size", type=int, required=True, help="tile size for slippy map tiles")
+    parser.add_argument("--workers", type=int, default=0, help="number of workers pre-processing images")
+    parser.add_argument("tiles", type=str, help="directory to read slippy map image tiles from")
+    parser.add_argument("probs", type=str, help="directory to save slippy map probability masks to")
+    parser.add_argument("--model", type=str, required=True, help="path to model configuration file")
+    parser.add_argument("--dataset", type=str, required=True, help="path to dataset configuration file")
+    parser.set_defaults(func=main)
+
+
+def strip_module_prefix(state_dict):
+    """Checkpoints carry the ``module.`` prefix of the reference's DataParallel wrapper (tools/train.py:69,158)."""
+
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
+def quantize(foreground):
+    """Probabilities in [0,1] -> uint8 bins exactly as the reference (predict.py:102-103): 1-based ``np.digitize``
+    over 256 anchors; p == 1.0 lands in bin 256 and wraps to 0."""
+
+    return np.digitize(foreground, np.linspace(0, 1, 256)).astype(np.uint8)
+
+
+def main(args):
+    model = load_config(args.model)
+    dataset = load_config(args.dataset)
+
+    if not model["common"]["cuda"]:
+        sys.exit("Error: this build computes on the MI355X only; set [common] cuda = true")
+    if not torch.cuda.is_available():
+        sys.exit("Error: CUDA requested but not available")
+
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    num_classes = len(dataset["common"]["classes"])
+
+    chkpt = torch.load(args.checkpoint, map_location=device)
+    net = UNet(num_classes, pretrained=False).to(device)
+    net.load_state_dict(strip_module_prefix(chkpt["state_dict"]))
+    net.eval()
+
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    transform = Compose([ConvertImageMode(mode="RGB"), ImageToTensor(), Normalize(mean=mean, std=std)])
+
+    directory = BufferedSlippyMapDirectory(args.tiles, transform=transform, size=args.tile_size, overlap=args.overlap)
+    assert len(directory) > 0, "at least one tile in dataset"
+
+    loader = DataLoader(directory, batch_size=args.batch_size, num_workers=args.workers, pin_memory=True)
+    palette = continuous_palette_for_color("pink", 256)
+
+    for i, (images, tiles) in enumerate(tqdm(loader, desc="Eval", unit="batch", ascii=True, disable=rank != 0)):
+        if i % world != rank:
+            continue
+        probs = net.predict_probs(images.to(device, non_blocking=True)).cpu().numpy()
+
+        for tile, prob in zip(tiles, probs):
+            x, y, z = list(map(int, tile))
+            prob = directory.unbuffer(prob)
+
+            assert prob.shape[0] == 2, "single channel requires binary model"
+            assert np.allclose(np.sum(prob, axis=0), 1.0), "single channel requires probabilities to sum up to one"
+
+            out = Image.fromarray(quantize(prob[1:, :, :]).squeeze(), mode="P")
+            out.putpalette(palette)
+
+            os.makedirs(os.path.join(args.probs, str(z), str(x)), exist_ok=True)
+            out.save(os.path.join(args.probs, str(z), str(x), str(y) + ".png"), optimize=True)

@@ -1,0 +1,284 @@
+"""``rs train``: same flags, TOML keys, log lines, history plots and checkpoint files as the reference
+(``robosat/tools/train.py``), driving the MI355X-native model, losses and metrics.
+
+Differences by design:
+  * data parallelism is one process per GPU with an RCCL gradient all-reduce (launch with ``torchrun`` or let
+    WORLD_SIZE/RANK/LOCAL_RANK be set); a single process uses one GPU.  The checkpoint keeps the ``module.`` key prefix
+    the reference's ``DataParallel`` wrapper produces, so files are interchangeable; only rank 0 writes.
+  * the per-step ``loss.item()`` and the 4 host syncs per sample of ``Metrics.add`` are gone: loss and confusion
+    counts accumulate on the device and are read once per epoch.
+"""
+
+import argparse
+import collections
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+from PIL import Image
+from torch.optim import Adam
+from torch.utils.data import DataLoader
+from tqdm import tqdm
+
+from robosat_amd import parallel
+from robosat_amd.config import load_config
+from robosat_amd.datasets import SlippyMapTilesConcatenation
+from robosat_amd.log import Log
+from robosat_amd.losses import CrossEntropyLoss2d, FocalLoss2d, LovaszLoss2d, mIoULoss2d
+from robosat_amd.metrics import Metrics
+from robosat_amd.transforms import (
+    CenterCrop, ConvertImageMode, ImageToTensor, JointCompose, JointRandomHorizontalFlip, JointRandomRotation,
+    JointTransform, MaskToTensor, Normalize, Resize,
+)
+from robosat_amd.unet import UNet
+
+
+class Replica(torch.nn.Module):
+    """Holds the network under the attribute ``module`` so state-dict keys read ``module.<name>`` exactly like the
+    reference's ``DataParallel(net)`` (tools/train.py:69); the actual data parallelism is process-level (parallel.py)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, x):
+        return self.module(x)
+
+
+def add_parser(subparser):
+    parser = subparser.add_parser(
+        "train", help="trains model on dataset", formatter_class=argparse.ArgumentDefaultsHelpFormatter
+    )
+    parser.add_argument("--model", type=str, required=True, help="path to model configuration file")
+    parser.add_argument("--dataset", type=str, required=True, help="path to dataset configuration file")
+    parser.add_argument("--checkpoint", type=str, required=False, help="path to a model checkpoint (to retrain)")
+    parser.add_argument("--resume", type=bool, default=False, help="resume training or fine-tuning (if checkpoint)")
+    parser.add_argument("--workers", type=int, default=0, help="number of workers pre-processing images")
+    parser.set_defaults(func=main)
+
+
+def _dist_env():
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    return world, rank, local
+
+
+def main(args):
+    model = load_config(args.model)
+    dataset = load_config(args.dataset)
+
+    if not model["common"]["cuda"]:
+        sys.exit("Error: this build computes on the MI355X only; set [common] cuda = true")
+    if not torch.cuda.is_available():
+        sys.exit("Error: CUDA requested but not available")
+
+    world, rank, local = _dist_env()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    master = rank == 0
+
+    os.makedirs(model["common"]["checkpoint"], exist_ok=True)
+
+    num_classes = len(dataset["common"]["classes"])
+    net = Replica(UNet(num_classes)).to(device)
+    if world > 1:
+        net.module.grad_reducer = parallel.GradReducer()
+
+    try:
+        weight = torch.Tensor(dataset["weights"]["values"])
+    except KeyError:
+        weight = None
+        if model["opt"]["loss"] in ("CrossEntropy", "mIoU", "Focal"):
+            sys.exit("Error: The loss function used, need dataset weights values")
+
+    optimizer = Adam(net.parameters(), lr=model["opt"]["lr"])
+
+    resume = 0
+    if args.checkpoint:
+        chkpt = torch.load(args.checkpoint, map_location=device)
+        net.load_state_dict(chkpt["state_dict"])
+        if args.resume:
+            optimizer.load_state_dict(chkpt["optimizer"])
+            resume = chkpt["epoch"]
+
+    loss_name = model["opt"]["loss"]
+    if loss_name == "CrossEntropy":
+        criterion = CrossEntropyLoss2d(weight=weight).to(device)
+    elif loss_name == "mIoU":
+        criterion = mIoULoss2d(weight=weight).to(device)
+    elif loss_name == "Focal":
+        criterion = FocalLoss2d(weight=weight).to(device)
+    elif loss_name == "Lovasz":
+        criterion = LovaszLoss2d().to(device)
+    else:
+        sys.exit("Error: Unknown [opt][loss] value !")
+
+    train_loader, val_loader = get_dataset_loaders(model, dataset, args.workers, rank, world)
+
+    num_epochs = model["opt"]["epochs"]
+    if resume >= num_epochs:
+        sys.exit("Error: Epoch {} set in {} already reached by the checkpoint provided".format(num_epochs, args.model))
+
+    history = collections.defaultdict(list)
+    log = Log(os.path.join(model["common"]["checkpoint"], "log"), out=sys.stdout if master else None) if master else None
+
+    def say(msg):
+        if log is not None:
+            log.log(msg)
+
+    say("--- Hyper Parameters on Dataset: {} ---".format(dataset["common"]["dataset"]))
+    say("Batch Size:\t {}".format(model["common"]["batch_size"]))
+    say("Image Size:\t {}".format(model["common"]["image_size"]))
+    say("Learning Rate:\t {}".format(model["opt"]["lr"]))
+    say("Loss function:\t {}".format(loss_name))
+    if weight is not None:
+        say("Weights :\t {}".format(dataset["weights"]["values"]))
+    say("---")
+
+    fmt = "{} loss: {:.4f}, mIoU: {:.3f}, {} IoU: {:.3f}, MCC: {:.3f}"
+    fg = dataset["common"]["classes"][1]
+
+    for epoch in range(resume, num_epochs):
+        say("Epoch: {}/{}".format(epoch + 1, num_epochs))
+        train_loader.batch_sampler.set_epoch(epoch)
+
+        train_hist = train(train_loader, num_classes, device, net, optimizer, criterion, master)
+        say(fmt.format("Train   ", train_hist["loss"], train_hist["miou"], fg, train_hist["fg_iou"], train_hist["mcc"]))
+        for k, v in train_hist.items():
+            history["train " + k].append(v)
+
+        val_hist = validate(val_loader, num_classes, device, net, criterion, master)
+        say(fmt.format("Validate", val_hist["loss"], val_hist["miou"], fg, val_hist["fg_iou"], val_hist["mcc"]))
+        for k, v in val_hist.items():
+            history["val " + k].append(v)
+
+        if master:
+            from robosat_amd.utils import plot
+
+            visual = "history-{:05d}-of-{:05d}.png".format(epoch + 1, num_epochs)
+            plot(os.path.join(model["common"]["checkpoint"], visual), history)
+
+            checkpoint = "checkpoint-{:05d}-of-{:05d}.pth".format(epoch + 1, num_epochs)
+            states = {"epoch": epoch + 1, "state_dict": net.state_dict(), "optimizer": optimizer.state_dict()}
+            torch.save(states, os.path.join(model["common"]["checkpoint"], checkpoint))
+        if world > 1:
+            dist.barrier()
+
+
+def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, desc="Train"):
+    training = optimizer is not None
+    num_samples = 0
+    running_loss = torch.zeros((), device=device, dtype=torch.float64)
+    metrics = Metrics(range(num_classes))
+
+    net.train() if training else net.eval()
+
+    for images, masks, tiles in tqdm(loader, desc=desc, unit="batch", ascii=True, disable=not master):
+        images = images.to(device, non_blocking=True)
+        masks = masks.to(device, non_blocking=True)
+
+        assert images.size()[2:] == masks.size()[1:], "resolutions for images and masks are in sync"
+        num_samples += int(images.size(0))
+
+        if training:
+            optimizer.zero_grad()
+        outputs = net(images)
+
+        assert outputs.size()[2:] == masks.size()[1:], "resolutions for predictions and masks are in sync"
+        assert outputs.size()[1] == num_classes, "classes for predictions and dataset are in sync"
+
+        loss = criterion(outputs, masks)
+        if training:
+            loss.backward()
+            optimizer.step()
+
+        running_loss += loss.detach()  # stays on the device: no per-step host sync
+        metrics.add_batch(masks, outputs.detach())
+
+    # one sync per epoch; same normalisation quirk as the reference: sum of batch-mean losses / number of samples
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    total_loss, total_samples = parallel.average_scalars([float(running_loss.item()), float(num_samples)], device)
+    if metrics._counts is not None:
+        parallel.sum_counts(metrics._counts)
+    del world
+    return {
+        "loss": total_loss / total_samples if total_samples else float("nan"),
+        "miou": metrics.get_miou(),
+        "fg_iou": metrics.get_fg_iou(),
+        "mcc": metrics.get_mcc(),
+    }
+
+
+def train(loader, num_classes, device, net, optimizer, criterion, master=True):
+    return _epoch(loader, num_classes, device, net, criterion, master, optimizer=optimizer, desc="Train")
+
+
+@torch.no_grad()
+def validate(loader, num_classes, device, net, criterion, master=True):
+    return _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, desc="Validate")
+
+
+class ShardedBatchSampler:
+    """Global batches of ``batch_size * world`` samples (``drop_last=True`` like the reference loaders), of which this
+    rank yields its ``batch_size`` share; the shuffled order is the same permutation on every rank."""
+
+    def __init__(self, num_items, batch_size, rank, world, shuffle, seed=0):
+        self.n, self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch = num_items, batch_size, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _batches(self):
+        order = None
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        return parallel.shard_indices(self.n, self.bs, self.rank, self.world, order)
+
+    def __iter__(self):
+        return iter(self._batches())
+
+    def __len__(self):
+        return self.n // (self.bs * self.world)
+
+
+def get_dataset_loaders(model, dataset, workers, rank=0, world=1):
+    target_size = (model["common"]["image_size"],) * 2
+    batch_size = model["common"]["batch_size"]
+    path = dataset["common"]["dataset"]
+
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+    transform = JointCompose(
+        [
+            JointTransform(ConvertImageMode("RGB"), ConvertImageMode("P")),
+            JointTransform(Resize(target_size, Image.BILINEAR), Resize(target_size, Image.NEAREST)),
+            JointTransform(CenterCrop(target_size), CenterCrop(target_size)),
+            JointRandomHorizontalFlip(0.5),
+            JointRandomRotation(0.5, 90),
+            JointRandomRotation(0.5, 90),
+            JointRandomRotation(0.5, 90),
+            JointTransform(ImageToTensor(), MaskToTensor()),
+            JointTransform(Normalize(mean=mean, std=std), None),
+        ]
+    )
+
+    train_dataset = SlippyMapTilesConcatenation(
+        [os.path.join(path, "training", "images")], os.path.join(path, "training", "labels"), transform
+    )
+    val_dataset = SlippyMapTilesConcatenation(
+        [os.path.join(path, "validation", "images")], os.path.join(path, "validation", "labels"), transform
+    )
+
+    assert len(train_dataset) > 0, "at least one tile in training dataset"
+    assert len(val_dataset) > 0, "at least one tile in validation dataset"
+
+    seed = int(os.environ.get("ROBOSAT_SEED", "0"))
+    train_loader = DataLoader(train_dataset, num_workers=workers, pin_memory=True,
+                              batch_sampler=ShardedBatchSampler(len(train_dataset), batch_size, rank, world, True, seed))
+    val_loader = DataLoader(val_dataset, num_workers=workers, pin_memory=True,
+                            batch_sampler=ShardedBatchSampler(len(val_dataset), batch_size, rank, world, False))
+    return train_loader, val_loader

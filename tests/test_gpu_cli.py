@@ -1,0 +1,127 @@
+"""End to end on the MI355X: ``rs train`` then ``rs predict`` on a synthetic slippy-map dataset (BASELINE configs[0]
+shape: 256x256 2-class tiles, 1 epoch), checking the reference's artifacts (log lines, history plot, checkpoint layout,
+probability PNGs) and parity with the CPU oracle fed the very same batches / checkpoint."""
+
+import argparse
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import robosat_ref as R, seeded
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_rs_train_then_predict(tmp_path):
+    from robosat_amd.tools import predict as predict_tool
+    from robosat_amd.tools import train as train_tool
+
+    tmp = str(tmp_path)
+    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=8, n_val=4, size=256)
+    ckdir = os.path.join(tmp, "pth")
+    model_toml, ds_toml = synth.write_configs(tmp, ds_root, ckdir, loss="Lovasz", batch_size=2, image_size=256, epochs=1)
+
+    random.seed(0)
+    torch.manual_seed(0)
+    train_tool.main(argparse.Namespace(model=model_toml, dataset=ds_toml, checkpoint=None, resume=False, workers=0))
+
+    # --- artifacts, exactly as the reference names them (tools/train.py:114-160) ---
+    log = open(os.path.join(ckdir, "log")).read().splitlines()
+    assert log[0].startswith("--- Hyper Parameters on Dataset: ") and "Epoch: 1/1" in log
+    pat = r"^(Train   |Validate) loss: \d+\.\d{4}, mIoU: (\d\.\d{3}|nan), parking IoU: (\d\.\d{3}|nan), MCC: (-?\d\.\d{3}|nan)$"
+    assert sum(bool(re.match(pat, l)) for l in log) == 2, log
+    assert os.path.exists(os.path.join(ckdir, "history-00001-of-00001.png"))
+    ck_path = os.path.join(ckdir, "checkpoint-00001-of-00001.pth")
+    ck = torch.load(ck_path, map_location="cpu")
+    assert set(ck) == {"epoch", "state_dict", "optimizer"} and ck["epoch"] == 1
+    ref = R.UNetRef(2)
+    assert list(ck["state_dict"]) == ["module." + k for k in ref.state_dict()]
+    assert len(ck["optimizer"]["state"]) == 168 and len(ck["optimizer"]["param_groups"][0]["params"]) == 170
+    # the checkpoint loads into the reference architecture as-is
+    ref.load_state_dict({k[len("module."):]: v for k, v in ck["state_dict"].items()})
+    assert int(ck["state_dict"]["module.resnet.bn1.num_batches_tracked"]) == 4  # 8 tiles / batch 2
+
+    # --- rs predict on the validation tiles; compare with the oracle run on the same checkpoint ---
+    tiles_dir, probs_dir = os.path.join(ds_root, "validation", "images"), os.path.join(tmp, "probs")
+    predict_tool.main(argparse.Namespace(batch_size=2, checkpoint=ck_path, overlap=32, tile_size=256, workers=0,
+                                         tiles=tiles_dir, probs=probs_dir, model=model_toml, dataset=ds_toml))
+    from robosat_amd.datasets import BufferedSlippyMapDirectory
+    from robosat_amd.transforms import Compose, ConvertImageMode, ImageToTensor, Normalize
+
+    tf = Compose([ConvertImageMode("RGB"), ImageToTensor(), Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    directory = BufferedSlippyMapDirectory(tiles_dir, transform=tf, size=256, overlap=32)
+    assert len(directory) == 4
+    ref.eval()
+    worst = 0
+    for i in range(len(directory)):
+        image, tile = directory[i]
+        x, y, z = (int(v) for v in tile)
+        png = Image.open(os.path.join(probs_dir, str(z), str(x), "{}.png".format(y)))
+        assert png.mode == "P" and png.size == (256, 256)
+        got = np.array(png).astype(np.int32)
+        probs = directory.unbuffer(R.predict_probs(ref, image.unsqueeze(0))[0].numpy())
+        want = R.quantize_probs(probs[1]).astype(np.int32)
+        diff = np.abs(got - want)
+        diff = np.minimum(diff, 256 - diff)  # bin 0 <-> 255 wrap (p == 1.0 quirk)
+        worst = max(worst, int(diff.max()))
+        assert (diff > 0).mean() < 0.02  # only pixels sitting on a bin edge may move, and by one bin
+    assert worst <= 1
+
+
+def test_training_trajectory_matches_cpu_oracle(tmp_path):
+    """Same initial weights, same batches, same Adam: per-step losses and epoch metrics of the GPU path track the CPU
+    oracle (fp32 tolerance grows with the step count, Adam normalises even tiny gradient differences)."""
+    from robosat_amd import losses
+    from robosat_amd.metrics import Metrics
+    from robosat_amd.tools.train import get_dataset_loaders
+    from robosat_amd.unet import UNet
+
+    tmp = str(tmp_path)
+    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=8, n_val=4, size=128, seed=3)
+    model = {"common": {"image_size": 128, "batch_size": 2}}
+    dataset = {"common": {"dataset": ds_root}}
+    random.seed(1)
+    loader, _ = get_dataset_loaders(model, dataset, 0)
+    batches = [(im.clone(), mk.clone()) for im, mk, _ in loader]
+    assert len(batches) == 4
+
+    sd = seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 4)
+    ref = R.UNetRef(2)
+    ref.load_state_dict(sd)
+    ref.train()
+    net = UNet(2, pretrained=False)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    crit = losses.LovaszLoss2d().to(DEV)
+    m, counts = Metrics(range(2)), np.zeros(4, dtype=np.int64)
+    for step, (images, masks) in enumerate(batches):
+        opt_ref.zero_grad()
+        out_ref = ref(images)
+        loss_ref = R.lovasz2d(out_ref, masks)
+        loss_ref.backward()
+        opt_ref.step()
+        for a, s in zip(masks, out_ref.detach()):
+            counts += np.array(R.confusion_counts(a, s))
+
+        opt.zero_grad()
+        out = net(images.to(DEV))
+        loss = crit(out, masks.to(DEV))
+        loss.backward()
+        opt.step()
+        m.add_batch(masks.to(DEV), out.detach())
+        rel = abs(loss.item() - loss_ref.item()) / max(1.0, abs(loss_ref.item()))
+        print("step", step, "loss", loss.item(), "oracle", loss_ref.item())
+        assert rel <= 5e-3 * (step + 1)
+    want = R.metric_scores(*counts)
+    got = (m.get_miou(), m.get_fg_iou(), m.get_mcc())
+    print("metrics", got, want)
+    assert abs(got[0] - want[0]) <= 0.01 and abs(got[1] - want[1]) <= 0.01

@@ -33,3 +33,29 @@ __device__ __forceinline__ double rs_wave_sum(double v) {
 }
 
 static inline int rs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Division of a 31-bit unsigned by a runtime-constant divisor with one mul-hi (Granlund-Montgomery round-up
+// method): q = (umulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31 and 1 <= d < 2^31.
+struct rs_fastdiv {
+  unsigned int mul;
+  unsigned int shift;
+  unsigned int div;
+};
+
+static inline rs_fastdiv rs_make_fastdiv(unsigned int d) {
+  rs_fastdiv f;
+  unsigned int s = 0;
+  while ((1ull << s) < d) ++s;  // s = ceil(log2 d)
+  f.shift = s;
+  f.mul = (unsigned int)((((1ull << s) - d) << 32) / d + 1);
+  f.div = d;
+  return f;
+}
+
+__host__ __device__ __forceinline__ unsigned int rs_div(unsigned int n, const rs_fastdiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (__umulhi(n, f.mul) + n) >> f.shift;
+#else
+  return (unsigned int)((((unsigned long long)n * f.mul) >> 32) + n) >> f.shift;
+#endif
+}

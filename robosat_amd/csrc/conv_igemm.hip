@@ -7,7 +7,12 @@
 // (one filter tap x 32 consecutive input channels: 128 contiguous bytes per output pixel in NHWC).
 //
 //   block  = 256 threads = 4 waves, tile BM x BN, K-chunk 32, LDS double buffered, one barrier per chunk;
-//            the next chunk is fetched into registers while the MFMAs of the current one run.
+//            the next chunk is fetched into registers while the MFMAs of the current one run.  The loop body is
+//            ONE basic block: loads are buffer_load_dwordx4 through SRSRC descriptors whose hardware bounds
+//            check returns zeros for padding / tail rows (offset = -1), so there is no branch around any load and
+//            the compiler interleaves the address arithmetic + load issue of chunk k+1 with the MFMAs of chunk
+//            k (PMC on the first version showed both waves of a SIMD doing their ~1250-cycle load phase at the
+//            same time: MFMA busy 74 %).  The prefetch of the non-existent chunk nk is harmless (zeros / in-range).
 //   gather = per output pixel: (n, oy*stride-pad, ox*stride-pad) is decoded once; per chunk only the tap offset
 //            is added.  `ups = 1` reads the source at (y>>1, x>>1) (nearest x2, DecoderBlock, unet.py:73);
 //            `ups = 2` additionally zeroes odd coordinates (zero-insertion: adjoint of a stride-2 conv);
@@ -40,10 +45,22 @@ struct ConvArgs {
   const float* res;
   const float* mask;
   float* out;
-  int Hs, Ws, C1, C2, Hv, Wv, ups;
+  int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles;
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0): loads at byte offsets >= bytes return 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_make_rsrc(const float* base, long bytes) {
+  const unsigned int n = bytes > 0xFFFFFFFEL ? 0xFFFFFFFEu : (unsigned int)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)n, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 rs_buffer_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
 
 constexpr int LDK = 36;  // padded LDS row (floats)
 
@@ -70,9 +87,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
   const int lrow = tid >> 3;  // 0..31: row within a 32-row slab
   const int c4 = tid & 7;     // which float4 of the 32-float chunk row
 
-  // ---- decode this thread's output pixels once -------------------------------------------------------------
-  int rn[AR], ry[AR], rx[AR];
+  // ---- decode this thread's output pixels once; offsets are relative to the tile's first image so that 32-bit
+  //      byte offsets are enough (validated on the host) -------------------------------------------------------
   const int HoWo = p.Ho * p.Wo;
+  const int nfirst = m0 / HoWo;
+  int rbase[AR], ry[AR], rx[AR];  // (n - nfirst) * Hs  (or -1 for rows past M), top-left input coordinates
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = m0 + lrow + 32 * i;
@@ -81,70 +100,67 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
       const int rem = m - n * HoWo;
       const int oy = rem / p.Wo;
       const int ox = rem - oy * p.Wo;
-      rn[i] = n;
+      rbase[i] = (n - nfirst) * p.Hs;
       ry[i] = oy * p.stride - p.pad;
       rx[i] = ox * p.stride - p.pad;
     } else {
-      rn[i] = -1;
-      ry[i] = 0;
+      rbase[i] = 0;
+      ry[i] = -64;  // taps add at most kh-1 <= 14: never inside [0, Hv)
       rx[i] = 0;
     }
   }
+  const long img1 = (long)p.Hs * p.Ws * (STEM ? 4 : p.C1);
+  const long img2 = (long)p.Hs * p.Ws * p.C2;
+  const __amdgpu_buffer_rsrc_t rsrc1 = rs_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * 4);
+  const __amdgpu_buffer_rsrc_t rsrc2 = rs_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * 4);
+  const __amdgpu_buffer_rsrc_t rsrcw = rs_make_rsrc(p.wgt, (long)p.Cout * p.Kw * 4);
+  int woff[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) woff[i] = ((n0 + lrow + 32 * i) * p.Kw + c4 * 4) * 4;
+  const int ush = p.ups ? 1 : 0;       // nearest / zero-insert x2: source coordinate = virtual >> 1
+  const int upar = p.ups == 2 ? 1 : 0;  // zero-insert: odd virtual coordinates are zeros
 
   f32x4 ra[AR], rb[BR];
   int lr = 0, ls = 0, lc = 0, lk = 0;  // next chunk to fetch: tap row / tap col / channel chunk / linear index
 
-  auto load_chunk = [&]() __attribute__((always_inline)) {
-    const float* src;
-    int Cs, cs;
-    if (STEM) {
-      src = p.src1;
-      Cs = 4;
-      cs = 0;
-    } else {
-      const int c0 = lc * 32;
-      if (c0 < p.C1) {
-        src = p.src1;
-        Cs = p.C1;
-        cs = c0 + c4 * 4;
-      } else {
-        src = p.src2;
-        Cs = p.C2;
-        cs = c0 - p.C1 + c4 * 4;
-      }
-    }
+  // issues a third of the loads of the NEXT chunk (parts 0..2; the last MFMA quarter stays load-free so that the
+  // latency of the final loads is covered before the LDS store needs them); branch-free
+  auto load_part = [&](int part) __attribute__((always_inline)) {
+    const int c0 = lc * 32;
+    const bool first = STEM || (c0 < p.C1);
+    const __amdgpu_buffer_rsrc_t rs = first ? rsrc1 : rsrc2;
+    const int Cs = STEM ? 4 : (first ? p.C1 : p.C2);
+    const int cs = STEM ? 0 : ((first ? c0 : c0 - p.C1) + c4 * 4);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
+      if ((i % 3) != part) continue;
       const int iy = ry[i] + lr;
       const int ix = rx[i] + (STEM ? c4 : ls);
-      bool ok = (rn[i] >= 0) && ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
-      int sy = iy, sx = ix;
-      if (p.ups) {
-        if (p.ups == 2) ok = ok && (((iy | ix) & 1) == 0);
-        sy = iy >> 1;
-        sx = ix >> 1;
-      }
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const long off = (((long)rn[i] * p.Hs + sy) * p.Ws + sx) * Cs + cs;
-        v = *reinterpret_cast<const f32x4*>(src + off);
-      }
-      ra[i] = v;
+      bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
+      ok = ok && ((((iy | ix) & upar)) == 0);
+      const int pix = (rbase[i] + (iy >> ush)) * p.Ws + (ix >> ush);
+      const int off = ok ? (pix * Cs + cs) * 4 : -1;
+      ra[i] = rs_buffer_load4(rs, off);
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const int row = n0 + lrow + 32 * i;
-      rb[i] = *reinterpret_cast<const f32x4*>(p.wgt + (long)row * p.Kw + lk * 32 + c4 * 4);
+      if (((i + 1) % 3) != part) continue;
+      rb[i] = rs_buffer_load4(rsrcw, woff[i] + lk * 128);
     }
+  };
+
+  auto advance = [&]() __attribute__((always_inline)) {
     ++lk;
     if (STEM) {
       ++lr;
-    } else if (++lc == p.cpt) {
-      lc = 0;
-      if (++ls == p.kw) {
-        ls = 0;
-        ++lr;
-      }
+    } else {
+      ++lc;
+      const int w1 = (lc == p.cpt) ? 1 : 0;
+      lc = w1 ? 0 : lc;
+      ls += w1;
+      const int w2 = (ls == p.kw) ? 1 : 0;
+      ls = w2 ? 0 : ls;
+      lr += w2;
     }
   };
 
@@ -168,34 +184,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
   const int brow = BM + wn * WN + (lane & 31);
   const int kq = (lane >> 5) * 4;
 
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float* L = lds + buf * BUF;
+  // one quarter of a chunk = 8 of the 32 k: fragments via one ds_read_b128 per 32-row sub-tile, TM*TN*4 MFMAs
+  auto read_frag = [&](const float* L, int j, f32x4 (&a)[TM], f32x4 (&b)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 a[TM], b[TN];
+    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(&L[(arow + 32 * tm) * LDK + 8 * j + kq]);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(&L[(arow + 32 * tm) * LDK + 8 * j + kq]);
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(&L[(brow + 32 * tn) * LDK + 8 * j + kq]);
+  };
+  auto mma_frag = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(&L[(brow + 32 * tn) * LDK + 8 * j + kq]);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[tn][t], a[tm][t], acc[tn][tm], 0, 0, 0);
-    }
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[tn][t], a[tm][t], acc[tn][tm], 0, 0, 0);
   };
 
-  // ---- main loop: fetch(k+1) -> regs | MFMA(k) from LDS | regs -> LDS(other buffer) | barrier --------------
-  load_chunk();
+  // ---- main loop.  Per quarter j: { prefetch the LDS fragments of quarter j+1 | address math + buffer loads of a
+  //      third of chunk k+1 | 16 MFMAs of quarter j }; then regs -> LDS(other buffer) | barrier.  No branch inside;
+  //      sched_barrier keeps each quarter's loads in that quarter (the scheduler otherwise sinks every load to the
+  //      end of the chunk, right before its use) and the last quarter load-free (latency cover for the LDS store).
+#pragma unroll
+  for (int part = 0; part < 3; ++part) load_part(part);
+  advance();
   store_chunk(0);
   __syncthreads();
   for (int kc = 0; kc < p.nk; ++kc) {
-    const bool more = (kc + 1) < p.nk;
-    if (more) load_chunk();
-    compute(kc & 1);
-    if (more) store_chunk((kc + 1) & 1);
+    const float* L = lds + (kc & 1) * BUF;
+    f32x4 fa[2][TM], fb[2][TN];
+    read_frag(L, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) {
+        read_frag(L, j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+        load_part(j);
+      }
+      mma_frag(fa[j & 1], fb[j & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance();
+    store_chunk((kc + 1) & 1);
     __syncthreads();
   }
 
@@ -321,6 +350,7 @@ extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const flo
   a.res = residual;
   a.mask = relu_mask;
   a.out = out;
+  a.N = d->N;
   a.Hs = d->Hs;
   a.Ws = d->Ws;
   a.C1 = d->C1;
@@ -337,6 +367,14 @@ extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const flo
   const long M = (long)d->N * d->Ho * d->Wo;
   if (M >= (1L << 31)) return RS_EINVAL;
   a.M = (int)M;
+  {
+    // the kernel addresses its inputs with 32-bit byte offsets relative to the first image of a tile: a tile of
+    // <= 128 output pixels touches at most 128 / (Ho*Wo) + 2 images
+    const long cmax = d->stem ? 4 : (d->C1 > d->C2 ? d->C1 : d->C2);
+    const long img_bytes = (long)d->Hs * d->Ws * cmax * 4;
+    const long span = (128 / ((long)d->Ho * d->Wo) + 2) * img_bytes;
+    if (span >= (1L << 31)) return RS_EINVAL;
+  }
   a.cpt = d->stem ? 1 : (d->C1 + d->C2) / 32;
   a.nk = d->stem ? d->kh : d->kh * d->kw * a.cpt;
   a.Kw = a.nk * 32;

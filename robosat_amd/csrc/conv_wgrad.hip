@@ -11,6 +11,9 @@
 //
 //   block  = tile BMo couts x BNo cins of one tap, over a contiguous range of pixels (split-P), walked in chunks of
 //            32 pixels; LDS double buffered, next chunk prefetched into registers during the MFMAs.
+//   loads  = buffer_load_dwordx4 through SRSRC descriptors (hardware bounds check => zeros for padding / tail
+//            pixels, offset = -1): branch-free, so the address math + loads of chunk k+1 interleave with the MFMAs
+//            of chunk k; pixel -> (n, oy, ox) uses mul-hi division by constants prepared on the host.
 //   LDS    = both tiles are stored as loaded, [32 pixels][channels]: the MFMA operands (A[i=co][k=pixel],
 //            B[k=pixel][j=ci], lane l <-> channel l&31, pixel parity l>>5) are read with ds_read_b32 on consecutive
 //            channels => conflict free; at 64 cycles per fp32 MFMA one b32 per operand per MFMA is ample.
@@ -25,10 +28,22 @@ struct WgradArgs {
   const float* src1;
   const float* src2;
   float* out;  // [splits][Cout][K]  (K = taps * Cin, or kh*32 for the stem)
-  int Hs, Ws, C1, C2, Hv, Wv, ups;
+  int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kw, stride, pad, Ho, Wo, Cout;
   int M, K, tiles_co, tiles_ci, tiles_k, chunks_per_split;
+  rs_fastdiv div_howo, div_wo;
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_make_rsrc(const float* base, long bytes) {
+  const unsigned int n = bytes > 0xFFFFFFFEL ? 0xFFFFFFFEu : (unsigned int)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)n, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 wg_buffer_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
 
 template <int BMo, int BNo, int WGM, int WGN, int STEM>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs p) {
@@ -73,45 +88,47 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   if (chunk1 > total_chunks) chunk1 = total_chunks;
   const int HoWo = p.Ho * p.Wo;
 
-  f32x4 ra[AR], rb[BR];
+  // 32-bit byte offsets relative to this split's first pixel (dy) / first image (input); validated on the host
+  const int m_first = chunk0 << 5;
+  const int n_first = (int)rs_div((unsigned)m_first, p.div_howo);
+  const long img = (long)p.Hs * p.Ws * Cs;
+  const __amdgpu_buffer_rsrc_t rsrc_dy = wg_make_rsrc(p.dy + (long)m_first * p.Cout, ((long)p.M - m_first) * p.Cout * 4);
+  const __amdgpu_buffer_rsrc_t rsrc_x = wg_make_rsrc(src + n_first * img, (long)(p.N - n_first) * img * 4);
+  const int ush = p.ups ? 1 : 0;
+  const int upar = p.ups == 2 ? 1 : 0;
 
-  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
-    const int mbase = chunk << 5;
+  f32x4 ra[AR], rb[BR];
+  int lchunk = chunk0;  // next chunk to fetch
+
+  // a third of the next chunk's loads (parts 0..2), branch-free
+  auto load_part = [&](int part) __attribute__((always_inline)) {
+    const int mbase = lchunk << 5;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
+      if ((i % 3) != part) continue;
       const int f = tid + NT * i;
-      const int row = f / AQ, c4 = f - row * AQ;
+      const int row = f / AQ, c4 = f - row * AQ;  // AQ is a power of two
       const int m = mbase + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) v = *reinterpret_cast<const f32x4*>(p.dy + (long)m * p.Cout + co0 + c4 * 4);
-      ra[i] = v;
+      const int off = (m < p.M) ? ((m - m_first) * p.Cout + co0 + c4 * 4) * 4 : -1;
+      ra[i] = wg_buffer_load4(rsrc_dy, off);
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
+      if (((i + 1) % 3) != part) continue;
       const int f = tid + NT * i;
       const int row = f / BQ, c4 = f - row * BQ;
       const int m = mbase + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) {
-        const int n = m / HoWo;
-        const int rem = m - n * HoWo;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride - p.pad + ky;
-        const int ix = ox * p.stride - p.pad + (STEM ? c4 : kx);
-        bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
-        int sy = iy, sx = ix;
-        if (p.ups) {
-          if (p.ups == 2) ok = ok && (((iy | ix) & 1) == 0);
-          sy = iy >> 1;
-          sx = ix >> 1;
-        }
-        if (ok) {
-          const long off = (((long)n * p.Hs + sy) * p.Ws + sx) * Cs + (STEM ? 0 : cs + c4 * 4);
-          v = *reinterpret_cast<const f32x4*>(src + off);
-        }
-      }
-      rb[i] = v;
+      const int n = (int)rs_div((unsigned)m, p.div_howo);
+      const int rem = m - n * HoWo;
+      const int oy = (int)rs_div((unsigned)rem, p.div_wo);
+      const int ox = rem - oy * p.Wo;
+      const int iy = oy * p.stride - p.pad + ky;
+      const int ix = ox * p.stride - p.pad + (STEM ? c4 : kx);
+      bool ok = (m < p.M) && ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
+      ok = ok && (((iy | ix) & upar) == 0);
+      const int pix = ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+      const int off = ok ? (pix * Cs + (STEM ? 0 : cs + c4 * 4)) * 4 : -1;
+      rb[i] = wg_buffer_load4(rsrc_x, off);
     }
   };
 
@@ -135,11 +152,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   const int bcol = wn * WN + (lane & 31);
   const int kh2 = lane >> 5;
 
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float* LA = lds + buf * BUF;
+  // a quarter of a chunk: 8 of the 32 pixels = 4 MFMA steps
+  auto compute_part = [&](const float* LA, int q) __attribute__((always_inline)) {
     const float* LB = LA + 32 * BMo;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 4 * q; t < 4 * q + 4; ++t) {
       const int prow = 2 * t + kh2;
       float a[TM], b[TN];
 #pragma unroll
@@ -155,14 +172,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   };
 
   if (chunk0 < chunk1) {
-    load_chunk(chunk0);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) load_part(part);
+    ++lchunk;
     store_chunk(0);
     __syncthreads();
     for (int c = chunk0; c < chunk1; ++c) {
-      const bool more = (c + 1) < chunk1;
-      if (more) load_chunk(c + 1);
-      compute((c - chunk0) & 1);
-      if (more) store_chunk((c - chunk0 + 1) & 1);
+      const float* LA = lds + ((c - chunk0) & 1) * BUF;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) load_part(q);  // the prefetch past the last chunk reads zeros (m >= M) or pixels of the next split
+        compute_part(LA, q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ++lchunk;
+      store_chunk((c - chunk0 + 1) & 1);
       __syncthreads();
     }
   }
@@ -284,7 +308,19 @@ Plan plan(const rs_conv_desc* d) {
   const long smax = (chunks + 7) / 8;        // ... of at least 8 chunks (256 pixels) each
   if (s > smax) s = smax;
   if (s < 1) s = 1;
-  pl.chunks_per_split = (int)((chunks + s - 1) / s);
+  // 32-bit byte offsets inside a split: dy spans pixels_per_split * Cout floats, the input spans the images the split
+  // touches (+1 for the prefetch past its end); shrink the splits until both fit
+  const long cmax = d->stem ? 4 : (d->C1 > d->C2 ? d->C1 : d->C2);
+  const long img_bytes = (long)d->Hs * d->Ws * cmax * 4;
+  const long howo = (long)d->Ho * d->Wo;
+  for (;;) {
+    pl.chunks_per_split = (int)((chunks + s - 1) / s);
+    const long px = ((long)pl.chunks_per_split + 1) * 32;
+    const long span_dy = px * d->Cout * 4;
+    const long span_x = (px / howo + 2) * img_bytes;
+    if ((span_dy < (1L << 31) && span_x < (1L << 31)) || pl.chunks_per_split == 1) break;
+    s *= 2;
+  }
   pl.splits = (int)((chunks + pl.chunks_per_split - 1) / pl.chunks_per_split);
   return pl;
 }
@@ -307,11 +343,14 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
   a.src1 = src1;
   a.src2 = src2;
   a.out = reinterpret_cast<float*>(workspace);
+  a.N = d->N;
   a.Hs = d->Hs;
   a.Ws = d->Ws;
   a.C1 = d->C1;
   a.C2 = d->C2;
   a.ups = d->ups;
+  a.div_howo = rs_make_fastdiv((unsigned)(d->Ho * d->Wo));
+  a.div_wo = rs_make_fastdiv((unsigned)d->Wo);
   a.Hv = d->ups == 0 ? d->Hs : (d->ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
   a.Wv = d->ups == 0 ? d->Ws : (d->ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
   a.kw = d->kw;

@@ -14,9 +14,14 @@
 //   loads  = buffer_load_dwordx4 through SRSRC descriptors (hardware bounds check => zeros for padding / tail
 //            pixels, offset = -1): branch-free, so the address math + loads of chunk k+1 interleave with the MFMAs
 //            of chunk k; pixel -> (n, oy, ox) uses mul-hi division by constants prepared on the host.
-//   LDS    = both tiles are stored as loaded, [32 pixels][channels]: the MFMA operands (A[i=co][k=pixel],
-//            B[k=pixel][j=ci], lane l <-> channel l&31, pixel parity l>>5) are read with ds_read_b32 on consecutive
-//            channels => conflict free; at 64 cycles per fp32 MFMA one b32 per operand per MFMA is ample.
+//   LDS    = channel-major [channel'][32 pixels (+4 pad)]: a thread fetches a 4-pixel x 4-channel block (four
+//            16-byte loads, each wave instruction = whole 512-B rows), transposes it in registers for free and
+//            writes four ds_write_b128 (4 consecutive pixels of one channel).  LDS row R = e*Q + c4 holds channel
+//            4*c4 + e (Q = channels/4), so consecutive lanes write consecutive rows (stride 36 floats: conflict
+//            free) and the MFMA operands are read exactly like the forward kernel: one ds_read_b128 = 4 pixels of
+//            the reduction per lane, A[i = co'][k = pixel], B[k = pixel][j = ci'].  The channel permutation is undone
+//            by the epilogue's addressing.  (The first version kept [pixel][channel] tiles and fed the MFMAs with
+//            ds_read_b32: 4x the LDS instructions, 89 TF on dec3 against 134 TF for the forward kernel.)
 //   split-P: partial tiles go to a workspace [split][Cout][K] and are summed by a second (streaming) kernel:
 //            deterministic, no atomics.
 #include "common.h"
@@ -50,10 +55,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int AQ = BMo / 4, BQ = BNo / 4;  // float4 per tile row
-  constexpr int AR = 8 * BMo / NT, BR = 8 * BNo / NT;  // float4 loads per thread per chunk
-  constexpr int BUF = 32 * (BMo + BNo);
-  static_assert(TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "bad tile");
+  constexpr int AQ = BMo / 4, BQ = BNo / 4;  // channel quads per tile
+  constexpr int TA = 2 * BMo, TB = 2 * BNo;  // threads staging the A / B tile (one 4-pixel x 4-channel block each)
+  constexpr int LDT = 36;                    // padded LDS row (floats): 32 pixels + 4
+  constexpr int BUF = (BMo + BNo) * LDT;
+  static_assert(TM >= 1 && TN >= 1 && TA <= NT && TB <= NT && (TA % 64) == 0 && (TB % 64) == 0, "bad tile");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
@@ -97,47 +103,64 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   const int ush = p.ups ? 1 : 0;
   const int upar = p.ups == 2 ? 1 : 0;
 
-  f32x4 ra[AR], rb[BR];
+  const bool doA = tid < TA, doB = tid < TB;  // wave-uniform
+  const int a_c4 = tid % AQ, a_pg = tid / AQ;  // channel quad / group of 4 pixels staged by this thread
+  const int b_c4 = tid % BQ, b_pg = tid / BQ;
+
+  f32x4 ra[4], rb[4];   // [pixel within the group] -> 4 channels
   int lchunk = chunk0;  // next chunk to fetch
 
-  // a third of the next chunk's loads (parts 0..2), branch-free
+  auto load_a = [&](int e) __attribute__((always_inline)) {
+    const int m = (lchunk << 5) + a_pg * 4 + e;
+    const int off = (doA && m < p.M) ? ((m - m_first) * p.Cout + co0 + a_c4 * 4) * 4 : -1;
+    ra[e] = wg_buffer_load4(rsrc_dy, off);
+  };
+  auto load_b = [&](int e) __attribute__((always_inline)) {
+    const int m = (lchunk << 5) + b_pg * 4 + e;
+    const int n = (int)rs_div((unsigned)m, p.div_howo);
+    const int rem = m - n * HoWo;
+    const int oy = (int)rs_div((unsigned)rem, p.div_wo);
+    const int ox = rem - oy * p.Wo;
+    const int iy = oy * p.stride - p.pad + ky;
+    const int ix = ox * p.stride - p.pad + (STEM ? b_c4 : kx);
+    bool ok = doB && (m < p.M) && ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
+    ok = ok && (((iy | ix) & upar) == 0);
+    const int pix = ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+    const int off = ok ? (pix * Cs + (STEM ? 0 : cs + b_c4 * 4)) * 4 : -1;
+    rb[e] = wg_buffer_load4(rsrc_x, off);
+  };
+  // a third of the next chunk's loads, branch-free (3 + 3 + 2)
   auto load_part = [&](int part) __attribute__((always_inline)) {
-    const int mbase = lchunk << 5;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      if ((i % 3) != part) continue;
-      const int f = tid + NT * i;
-      const int row = f / AQ, c4 = f - row * AQ;  // AQ is a power of two
-      const int m = mbase + row;
-      const int off = (m < p.M) ? ((m - m_first) * p.Cout + co0 + c4 * 4) * 4 : -1;
-      ra[i] = wg_buffer_load4(rsrc_dy, off);
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      if (((i + 1) % 3) != part) continue;
-      const int f = tid + NT * i;
-      const int row = f / BQ, c4 = f - row * BQ;
-      const int m = mbase + row;
-      const int n = (int)rs_div((unsigned)m, p.div_howo);
-      const int rem = m - n * HoWo;
-      const int oy = (int)rs_div((unsigned)rem, p.div_wo);
-      const int ox = rem - oy * p.Wo;
-      const int iy = oy * p.stride - p.pad + ky;
-      const int ix = ox * p.stride - p.pad + (STEM ? c4 : kx);
-      bool ok = (m < p.M) && ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
-      ok = ok && (((iy | ix) & upar) == 0);
-      const int pix = ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
-      const int off = ok ? (pix * Cs + (STEM ? 0 : cs + c4 * 4)) * 4 : -1;
-      rb[i] = wg_buffer_load4(rsrc_x, off);
-    }
+    if (part == 0) { load_a(0); load_a(3); load_b(2); }
+    if (part == 1) { load_a(1); load_b(0); load_b(3); }
+    if (part == 2) { load_a(2); load_b(1); }
   };
 
+  // registers -> LDS with the free 4x4 transpose: row (e*Q + c4) <- pixels 4*pg..4*pg+3 of channel 4*c4+e
   auto store_chunk = [&](int buf) __attribute__((always_inline)) {
     float* L = lds + buf * BUF;
+    if (doA) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&L[(tid + NT * i) * 4]) = ra[i];
+      for (int e = 0; e < 4; ++e) {
+        f32x4 v;
+        v[0] = ra[0][e];
+        v[1] = ra[1][e];
+        v[2] = ra[2][e];
+        v[3] = ra[3][e];
+        *reinterpret_cast<f32x4*>(&L[(e * AQ + a_c4) * LDT + a_pg * 4]) = v;
+      }
+    }
+    if (doB) {
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&L[32 * BMo + (tid + NT * i) * 4]) = rb[i];
+      for (int e = 0; e < 4; ++e) {
+        f32x4 v;
+        v[0] = rb[0][e];
+        v[1] = rb[1][e];
+        v[2] = rb[2][e];
+        v[3] = rb[3][e];
+        *reinterpret_cast<f32x4*>(&L[(BMo + e * BQ + b_c4) * LDT + b_pg * 4]) = v;
+      }
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -148,27 +171,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int acol = wm * WM + (lane & 31);
-  const int bcol = wn * WN + (lane & 31);
-  const int kh2 = lane >> 5;
+  const int arow = wm * WM + (lane & 31);
+  const int brow = BMo + wn * WN + (lane & 31);
+  const int kq = (lane >> 5) * 4;
 
-  // a quarter of a chunk: 8 of the 32 pixels = 4 MFMA steps
-  auto compute_part = [&](const float* LA, int q) __attribute__((always_inline)) {
-    const float* LB = LA + 32 * BMo;
+  // one quarter of a chunk = 8 of the 32 pixels; lane reads pixels 8j + 4*(lane>>5) + t with one b128 per sub-tile
+  auto read_frag = [&](const float* L, int j, f32x4 (&a)[TM], f32x4 (&b)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 4 * q; t < 4 * q + 4; ++t) {
-      const int prow = 2 * t + kh2;
-      float a[TM], b[TN];
+    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(&L[(arow + 32 * tm) * LDT + 8 * j + kq]);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = LA[prow * BMo + acol + 32 * tm];
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(&L[(brow + 32 * tn) * LDT + 8 * j + kq]);
+  };
+  auto mma_frag = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = LB[prow * BNo + bcol + 32 * tn];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-    }
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], acc[tm][tn], 0, 0, 0);
   };
 
   if (chunk0 < chunk1) {
@@ -178,11 +199,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
     store_chunk(0);
     __syncthreads();
     for (int c = chunk0; c < chunk1; ++c) {
-      const float* LA = lds + ((c - chunk0) & 1) * BUF;
+      const float* L = lds + ((c - chunk0) & 1) * BUF;
+      f32x4 fa[2][TM], fb[2][TN];
+      read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < 3) load_part(q);  // the prefetch past the last chunk reads zeros (m >= M) or pixels of the next split
-        compute_part(LA, q);
+      for (int j = 0; j < 4; ++j) {
+        if (j < 3) {
+          read_frag(L, j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+          load_part(j);  // the prefetch past the last chunk reads zeros (m >= M) or pixels of the next split
+        }
+        mma_frag(fa[j & 1], fb[j & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
       ++lchunk;
@@ -191,19 +217,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
     }
   }
 
-  // D[i = co][j = ci]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5); 128-B segments per store instruction
+  // D[i][j]: i = (r&3) + 8*(r>>2) + 4*(lane>>5) is an LDS row of the dy tile, j = lane&31 one of the input tile;
+  // LDS row R <-> channel 4*(R % Q) + R / Q
   float* out = p.out + (long)split * p.Cout * p.K;
   const int kbase = STEM ? tap * 32 : tap * (p.C1 + p.C2) + ci0;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+    for (int tn = 0; tn < TN; ++tn) {
+      const int Rb = wn * WN + tn * 32 + (lane & 31);
+      const int kk = kbase + 4 * (Rb % BQ) + Rb / BQ;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int kk = kbase + wn * WN + tn * 32 + (lane & 31);
+        const int Ra = wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + 4 * (Ra % AQ) + Ra / AQ;
         out[(long)co * p.K + kk] = acc[tm][tn][r];
       }
+    }
 }
 
 __global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int splits) {

@@ -26,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: dense bf16 (v_mfma_f32_32x32x16_bf16); never the 2:1-sparsity figure
+
+
+def kernel_peak(name):
+    return BF16_MFMA_PEAK_TFLOPS if "bf16" in name else FP32_MFMA_PEAK_TFLOPS
 
 
 def parse():
@@ -40,17 +45,19 @@ def parse():
     ap.add_argument("--phase", choices=["predict", "train"], default="predict",
                     help="predict = BASELINE configs[1] (default); train = fwd + loss + bwd + grad all-reduce + Adam")
     ap.add_argument("--loss", choices=["CrossEntropy", "Lovasz", "Focal"], default="Lovasz", help="train phase criterion")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="compute dtype: fp32 (exact-fp32 MFMA, the parity path; BASELINE configs[1]) or bf16 (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
     ap.add_argument("--layers-json", type=str, default="", help="also dump the per-layer roofline table here")
     return ap.parse_args()
 
 
-def build_model(classes, device, train=False):
+def build_model(classes, device, train=False, dtype="fp32"):
     from robosat_amd.unet import UNet
 
     torch.manual_seed(0)
-    net = UNet(classes, pretrained=False)  # random init of the reference architecture (no network for checkpoints)
+    net = UNet(classes, pretrained=False, compute_dtype=dtype)  # random init of the reference architecture
     g = torch.Generator().manual_seed(1)
     for name, buf in net.named_buffers():  # non-trivial BatchNorm statistics (fresh init would make BN an identity)
         if name.endswith("running_mean"):
@@ -85,16 +92,32 @@ def roofline(step):
     flops, ms, launches = per_kernel[dom]
     total_ms = sum(v[1] for v in per_kernel.values())
     total_fl = sum(v[0] for v in per_kernel.values())
+    # time-weighted peak of the launches (fp32 and bf16 kernels coexist in the bf16 path: the stem stays fp32)
+    ideal_ms = sum(v[0] / kernel_peak(n) / 1e9 for n, v in per_kernel.items())
     achieved = flops / ms / 1e9
+    peak = kernel_peak(dom)
     out = {
-        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": launches,
+        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom), "launches": launches,
         "avg_launch_ms": round(ms / launches, 4), "gflop_per_launch": round(flops / launches / 1e9, 3),
-        "all_convs": {"tflops": round(total_fl / total_ms / 1e9, 2), "frac": round(total_fl / total_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "all_convs": {"tflops": round(total_fl / total_ms / 1e9, 2), "frac": round(ideal_ms / total_ms, 4),
                       "ms": round(total_ms, 3), "gflop": round(total_fl / 1e9, 2)},
         "per_kernel": {n: {"tflops": round(v[0] / v[1] / 1e9, 2), "ms": round(v[1], 3), "launches": v[2]} for n, v in per_kernel.items()},
     }
     return out, layers
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+    passes, corrected as MI355X_MICROARCH.md prescribes) -- profiles/pmc_traffic.json, written by scripts/pmc_summary.py
+    from a run of this same command.  None when no counter run has been committed for this kernel."""
+
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fp:
+            return json.load(fp).get(kernel)
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
@@ -165,7 +188,7 @@ def main():
     device = torch.device("cuda", local)
 
     train = args.phase == "train"
-    net = build_model(args.classes, device, train)
+    net = build_model(args.classes, device, train, args.dtype)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM
 
@@ -219,10 +242,10 @@ def main():
             "metric": "512x512 tiles/sec train+predict, 1/2/4/8 MI355X; mIoU vs CPU ref",
             "value": round(world * args.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("rs predict ResNet50-UNet, bs={} 3x{}x{} fp32 per GPU, {} classes (BASELINE configs[1])" if not train else
-                                    "rs train ResNet50-UNet, bs={} 3x{}x{} fp32 per GPU, {} classes, " + args.loss + " loss + Adam (BASELINE configs[2] at fp32)").format(
-                args.batch, args.size, args.size, args.classes), "phase": args.phase, "tiles_per_gpu_per_step": args.batch,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": ("rs predict ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes (BASELINE configs[1])" if not train else
+                                    "rs train ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes, " + args.loss + " loss + Adam (BASELINE configs[2])").format(
+                args.batch, args.size, args.size, args.dtype, args.classes), "phase": args.phase, "tiles_per_gpu_per_step": args.batch,
                 "tile": args.size, "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
                                                    "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)},
             "roofline": roof,

@@ -28,6 +28,12 @@ extern "C" {
 
 typedef void* rs_stream_t;
 
+/* Activation storage types of the *_dt / *_bf16 entry points (the bf16 training path, BASELINE configs[2]).
+ * bf16 tensors are passed as raw 16-bit words (torch.bfloat16 storage); arithmetic and accumulation stay fp32. */
+typedef uint16_t rs_bf16;
+#define RS_F32 0
+#define RS_BF16 1
+
 /* Version of this ABI (bumped on any signature change). */
 int rs_abi_version(void);
 
@@ -181,6 +187,53 @@ int rs_scale_by_scalar(const float* src, const float* scalar, float* dst, long n
 /* Metrics.add over a whole batch (metrics.py:27-41): counts[0..3] += (tn, fn, fp, tp) in the reference's naming. */
 int rs_confusion_counts(const float* scores, const long long* targets, unsigned long long* counts, int N, int C, int H,
                         int W, rs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * bf16 path (BASELINE configs[2]: rs train bf16): the same operators with activations stored as bf16 NHWC, fp32
+ * master weights cast per step, fp32 accumulation (v_mfma_f32_32x32x16_bf16), fp32 statistics / gradients of
+ * parameters / logits / losses.  The 7x7 stem + bn1 stay on the fp32 kernels (0.7 % of the FLOPs); the precision
+ * boundary is the stem max-pool (fp32 in, bf16 out; bf16 dy, fp32 dx in the backward).
+ *
+ * `_dt` variants: same contract as the fp32 entry point of the same name, activations typed by `dtype`
+ * (RS_F32 | RS_BF16); per-channel vectors, parameter gradients, logits and workspaces are always fp32.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* rs_conv2d_fwd with bf16 sources / weights (KRSC bf16) / residual / relu_mask / output; scale, shift fp32.
+ * stem = 1 is not supported here.  Same fused gather (ups, concat) and epilogue. */
+int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, const rs_bf16* src2, const rs_bf16* weight,
+                       const float* scale, const float* shift, const rs_bf16* residual, const rs_bf16* relu_mask,
+                       rs_bf16* out, rs_stream_t stream);
+int rs_conv2d_tile_bf16(const rs_conv_desc* d);
+const char* rs_conv2d_tile_name_bf16(int tile);
+
+/* rs_conv2d_wgrad with bf16 dy / sources; dw is fp32 KRSC (the optimizer's master gradient). */
+long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d);
+int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, const rs_bf16* src1, const rs_bf16* src2, float* dw,
+                         void* workspace, rs_stream_t stream);
+
+/* fp32 master weights -> bf16 compute copies: plain cast (KRSC stays KRSC), and the data-gradient packing of
+ * rs_pack_dgrad_weight with a bf16 result. */
+int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stream);
+int rs_pack_dgrad_weight_bf16(const float* w_krsc, rs_bf16* out, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
+
+int rs_maxpool2d_fwd_dt(const void* x, int x_dtype, void* y, int y_dtype, uint8_t* argmax, int N, int H, int W, int C, int k,
+                        int stride, int pad, int Ho, int Wo, rs_stream_t stream);
+int rs_maxpool2d_bwd_dt(const void* dy, int dy_dtype, const uint8_t* argmax, void* dx, int dx_dtype, int N, int H, int W,
+                        int C, int k, int stride, int pad, int Ho, int Wo, int accumulate, rs_stream_t stream);
+int rs_final_conv1x1_dt(const void* x, int x_dtype, const float* w, const float* bias, float* out, int N, int H, int W,
+                        int Cin, int C, int softmax, rs_stream_t stream);
+int rs_final_conv1x1_bwd_dt(const void* x, const float* w, const float* dlogits, void* dx, float* dw, float* db, int dtype,
+                            int N, int H, int W, int Cin, int C, int relu_mask, void* workspace, rs_stream_t stream);
+int rs_bn_train_stats_dt(const void* y, int dtype, long M, int C, float eps, float momentum, const float* gamma,
+                         const float* beta, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, void* workspace, rs_stream_t stream);
+int rs_bn_apply_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out, int dtype, long M,
+                   int C, int relu, rs_stream_t stream);
+int rs_bn_bwd_dt(const void* dz, const void* zmask, const void* y, const float* mean, const float* invstd, const float* gamma,
+                 void* dy, void* dmasked, float* dgamma, float* dbeta, int dtype, long M, int C, void* workspace,
+                 rs_stream_t stream);
+int rs_upsample2x_bwd_dt(const void* dup, void* d1, void* d2, const void* mask1, const void* mask2, int dtype, int N, int H,
+                         int W, int C1, int C2, int accumulate1, rs_stream_t stream);
 
 #ifdef __cplusplus
 }

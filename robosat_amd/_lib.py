@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 2
+ABI_VERSION = 3
+RS_F32, RS_BF16 = 0, 1
 
 
 class ConvDesc(ctypes.Structure):
@@ -65,6 +66,22 @@ SIGNATURES = {
     "rs_lovasz_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "rs_scale_by_scalar": (c_int, [P, P, P, c_long, P]),
     "rs_confusion_counts": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    # bf16 path (activations typed by a dtype code / bf16 entry points)
+    "rs_conv2d_fwd_bf16": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
+    "rs_conv2d_tile_bf16": (c_int, [POINTER(ConvDesc)]),
+    "rs_conv2d_tile_name_bf16": (c_char_p, [c_int]),
+    "rs_conv2d_wgrad_bf16_workspace_bytes": (c_long, [POINTER(ConvDesc)]),
+    "rs_conv2d_wgrad_bf16": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    "rs_cast_f32_to_bf16": (c_int, [P, P, c_long, P]),
+    "rs_pack_dgrad_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_maxpool2d_fwd_dt": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_maxpool2d_bwd_dt": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_final_conv1x1_dt": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_final_conv1x1_bwd_dt": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "rs_bn_train_stats_dt": (c_int, [P, c_int, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "rs_bn_apply_dt": (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, P]),
+    "rs_bn_bwd_dt": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_long, c_int, P, P]),
+    "rs_upsample2x_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 }
 
 _lib = None

@@ -83,11 +83,12 @@ def _bn_train(bn, y, residual=None, relu=True):
 def _forward(net, x, tape):
     r = net.resnet
     t = tape.t
+    dt = net.compute_dtype  # fp32, or bf16 activations from the stem pool on (stem conv + bn1 stay fp32)
     x4 = ops.nchw_to_nhwc4(x)
     t["x4"] = x4
     y0 = ops.conv2d(x4, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, stem=7)
     z0, st0 = _bn_train(r.bn1, y0)
-    p0, am0 = ops.maxpool2d(z0, 3, 2, 1, want_argmax=True)
+    p0, am0 = ops.maxpool2d(z0, 3, 2, 1, want_argmax=True, out_dtype=dt)
     t.update(y0=y0, st0=st0, z0=z0, am0=am0)
 
     h = p0
@@ -95,13 +96,13 @@ def _forward(net, x, tape):
     for layer in net._blocks():
         for blk in layer:
             rec = {"blk": blk, "h": h}
-            y1 = ops.conv2d(h, blk.conv1.krsc())
+            y1 = ops.conv2d(h, blk.conv1.krsc(dt))
             z1, rec["st1"] = _bn_train(blk.bn1, y1)
-            y2 = ops.conv2d(z1, blk.conv2.krsc(), stride=blk.stride, pad=1)
+            y2 = ops.conv2d(z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1)
             z2, rec["st2"] = _bn_train(blk.bn2, y2)
-            y3 = ops.conv2d(z2, blk.conv3.krsc())
+            y3 = ops.conv2d(z2, blk.conv3.krsc(dt))
             if blk.downsample is not None:
-                yd = ops.conv2d(h, blk.downsample[0].krsc(), stride=blk.stride)
+                yd = ops.conv2d(h, blk.downsample[0].krsc(dt), stride=blk.stride)
                 idt, rec["std"] = _bn_train(blk.downsample[1], yd, relu=False)
                 rec["yd"] = yd
             else:
@@ -114,7 +115,7 @@ def _forward(net, x, tape):
     enc1, enc2, enc3, enc4 = enc
 
     def up(block, skip, prev=None):
-        return ops.conv2d(skip, block.block.block.krsc(), src2=prev, ups=1, pad=1, relu=True)
+        return ops.conv2d(skip, block.block.block.krsc(dt), src2=prev, ups=1, pad=1, relu=True)
 
     pooled, amc = ops.maxpool2d(enc4, 2, 2, 0, want_argmax=True)
     center = up(net.center, pooled)
@@ -123,16 +124,16 @@ def _forward(net, x, tape):
     dec2 = up(net.dec2, enc2, dec1)
     dec3 = up(net.dec3, enc1, dec2)
     dec4 = up(net.dec4, dec3)
-    dec5 = ops.conv2d(dec4, net.dec5.block.krsc(), pad=1, relu=True)
+    dec5 = ops.conv2d(dec4, net.dec5.block.krsc(dt), pad=1, relu=True)
     t.update(enc=enc, pooled=pooled, amc=amc, center=center, dec0=dec0, dec1=dec1, dec2=dec2, dec3=dec3, dec4=dec4, dec5=dec5)
     wf = net.final.weight.detach().reshape(net.num_classes, -1)
     return ops.final_conv1x1(dec5, wf, net.final.bias.detach())
 
 
 def _dgrad(dy, conv, out_hw, residual=None, relu_mask=None):
-    """Data gradient of ``conv`` (a parameter holder with .k/.stride/.padding) evaluated at dy."""
+    """Data gradient of ``conv`` (a parameter holder with .k/.stride/.padding) evaluated at dy (fp32 or bf16)."""
 
-    wd = ops.pack_dgrad_weight(conv.krsc())
+    wd = ops.pack_dgrad_weight(conv.krsc(), dy.dtype)
     return ops.conv2d(dy, wd, ups=2 if conv.stride == 2 else 0, pad=conv.k - 1 - conv.padding, out_hw=out_hw,
                       residual=residual, relu_mask=relu_mask)
 
@@ -153,14 +154,14 @@ def _backward(net, tape, dlogits, arena):
 
     c5 = net.dec5.block
     ops.conv2d_wgrad(d5, t["dec4"], 3, 3, pad=1, out=arena.conv(c5))
-    d4 = ops.conv2d(d5, ops.pack_dgrad_weight(c5.krsc()), pad=1, relu_mask=t["dec4"])
+    d4 = ops.conv2d(d5, ops.pack_dgrad_weight(c5.krsc(), d5.dtype), pad=1, relu_mask=t["dec4"])
     del d5
 
     def up_bwd(block, dz, skip, prev, mask_skip, mask_prev, skip_grad_out=None):
         """dz = gradient at the block's conv output (ReLU already applied).  Returns (d skip, d prev)."""
         conv = block.block.block
         ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=arena.conv(conv))
-        dup = ops.conv2d(dz, ops.pack_dgrad_weight(conv.krsc()), pad=1)
+        dup = ops.conv2d(dz, ops.pack_dgrad_weight(conv.krsc(), dz.dtype), pad=1)
         c1 = skip.shape[3]
         c2 = 0 if prev is None else prev.shape[3]
         return ops.upsample2x_bwd(dup, c1, c2, mask1=mask_skip, mask2=mask_prev, out1=skip_grad_out)
@@ -222,7 +223,7 @@ def _backward(net, tape, dlogits, arena):
             arena.flush()  # one bucket per finished ResNet layer
 
     # ---- stem -------------------------------------------------------------------------------------------------
-    dz0 = ops.maxpool2d_bwd(g, t["am0"], tuple(t["z0"].shape), 3, 2, 1)
+    dz0 = ops.maxpool2d_bwd(g, t["am0"], tuple(t["z0"].shape), 3, 2, 1, out_dtype=torch.float32)  # back to the fp32 stem
     dy0, _, _ = ops.bn_bwd(dz0, t["z0"], t["y0"], t["st0"][0], t["st0"][1], r.bn1.weight.detach(), **bn_grads(r.bn1))
     dwp = ops.conv2d_wgrad(dy0, t["x4"], 7, 7, stride=2, pad=3, stem=7)
     ops.unpack_stem_weight(dwp, 7, net.in_channels, out=arena.conv(r.conv1))

@@ -8,7 +8,8 @@ namespace {
 
 // d/dx of F.max_pool2d (unet.py:125,132) in gather form: every input element sums the gradients of the windows that
 // selected it (the forward kernel recorded the winning tap per window, first maximum as torch).
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax, float* __restrict__ dx,
+template <typename TY, typename TX>
+__global__ void maxpool_bwd_kernel(const TY* __restrict__ dy, const uint8_t* __restrict__ amax, TX* __restrict__ dx,
                                    int H, int W, int C4, int k, int stride, int pad, int Ho, int Wo, long total,
                                    int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +21,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
   const int iy = (int)(pix % H);
   const long n = pix / H;
   f32x4 g = {0.f, 0.f, 0.f, 0.f};
-  if (accumulate) g = *reinterpret_cast<const f32x4*>(dx + i * 4);
+  if (accumulate) g = rs_ld4(dx + i * 4);
   int ny = iy + pad - (k - 1), nx = ix + pad - (k - 1);
   const int oy0 = ny <= 0 ? 0 : (ny + stride - 1) / stride;
   const int ox0 = nx <= 0 ? 0 : (nx + stride - 1) / stride;
@@ -34,20 +35,21 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
       const uint32_t tap = (uint32_t)(r * k + s);
       const long o = ((n * Ho + oy) * Wo + ox) * (long)C4 + c;
       const uint32_t sel = *reinterpret_cast<const uint32_t*>(amax + o * 4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(dy + o * 4);
+      const f32x4 v = rs_ld4(dy + o * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (((sel >> (8 * e)) & 0xffu) == tap) g[e] += v[e];
     }
   }
-  *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+  rs_st4(dx + i * 4, g);
 }
 
 // d/dx of F.interpolate(scale_factor=2, mode="nearest") (unet.py:73) followed by the split of torch.cat
 // (unet.py:134-137): 2x2 sum of the gradient at the upsampled resolution, channels [0,C1) -> d1, [C1,C1+C2) -> d2.
 // mask1/mask2 (optional) are the ReLU outputs the gradients flow into: result zeroed where mask <= 0.
-__global__ void upsample2x_bwd_kernel(const float* __restrict__ dup, float* __restrict__ d1, float* __restrict__ d2,
-                                      const float* __restrict__ mask1, const float* __restrict__ mask2, int H, int W,
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dup, T* __restrict__ d1, T* __restrict__ d2,
+                                      const T* __restrict__ mask1, const T* __restrict__ mask2, int H, int W,
                                       int C1, int C2, long total, int accumulate1) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -58,34 +60,34 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dup, float* __re
   const long ny = pix / W;  // n*H + y
   const long W2 = 2L * W;
   const long base = ((2 * ny) * W2 + 2 * x) * Ct + q * 4;  // row 2*(n*H+y) of the [N*2H][2W] image == n*2H + 2y
-  f32x4 s = *reinterpret_cast<const f32x4*>(dup + base);
-  const f32x4 b = *reinterpret_cast<const f32x4*>(dup + base + Ct);
-  const f32x4 c = *reinterpret_cast<const f32x4*>(dup + base + W2 * Ct);
-  const f32x4 d = *reinterpret_cast<const f32x4*>(dup + base + W2 * Ct + Ct);
+  f32x4 s = rs_ld4(dup + base);
+  const f32x4 b = rs_ld4(dup + base + Ct);
+  const f32x4 c = rs_ld4(dup + base + W2 * Ct);
+  const f32x4 d = rs_ld4(dup + base + W2 * Ct + Ct);
 #pragma unroll
   for (int e = 0; e < 4; ++e) s[e] = (s[e] + b[e]) + (c[e] + d[e]);
   const int ch = q * 4;
   if (ch < C1) {
     const long o = pix * C1 + ch;
     if (mask1) {
-      const f32x4 z = *reinterpret_cast<const f32x4*>(mask1 + o);
+      const f32x4 z = rs_ld4(mask1 + o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = z[e] > 0.f ? s[e] : 0.f;
     }
     if (accumulate1) {
-      const f32x4 old = *reinterpret_cast<const f32x4*>(d1 + o);
+      const f32x4 old = rs_ld4(d1 + o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] += old[e];
     }
-    *reinterpret_cast<f32x4*>(d1 + o) = s;
+    rs_st4(d1 + o, s);
   } else {
     const long o = pix * C2 + (ch - C1);
     if (mask2) {
-      const f32x4 z = *reinterpret_cast<const f32x4*>(mask2 + o);
+      const f32x4 z = rs_ld4(mask2 + o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = z[e] > 0.f ? s[e] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(d2 + o) = s;
+    rs_st4(d2 + o, s);
   }
 }
 
@@ -94,9 +96,9 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dup, float* __re
 //   dW[c][k]  = sum_p dlogits[c][p] * x[p][k],   db[c] = sum_p dlogits[c][p]
 // Blocks stride over 256-pixel tiles; per-thread partial dW/db live in registers across tiles (wave w owns pixels
 // [64w, 64w+64) of each tile), then waves and blocks are combined in two deterministic stages.
-template <int C>
-__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ dl, float* __restrict__ dx,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void final_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ dl, T* __restrict__ dx,
                                                         float* __restrict__ partial, long P, long HW, int Cin, long ntiles,
                                                         int relu_mask) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     for (int f = tid; f < 256 * q; f += 256) {
       const int px = f / q, c4 = f - px * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p0 + px < P) v = *reinterpret_cast<const f32x4*>(x + (p0 + px) * Cin + c4 * 4);
+      if (p0 + px < P) v = rs_ld4(x + (p0 + px) * Cin + c4 * 4);
       float* d = xs + px * ld + c4 * 4;
       d[0] = v[0];
       d[1] = v[1];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = xs[px * ld + c4 * 4 + e] > 0.f ? o[e] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(dx + (p0 + px) * Cin + c4 * 4) = o;
+      rs_st4(dx + (p0 + px) * Cin + c4 * 4, o);
     }
     // dW/db partials: wave `wave` reduces its 64 pixels for every (c,k) pair
 #pragma unroll
@@ -203,44 +205,91 @@ __global__ __launch_bounds__(256) void final_bwd_finalize_kernel(const float* __
 
 constexpr int kFinalBwdMaxBlocks = 1024;
 
-template <int C>
-int launch_final_bwd(const float* x, const float* w, const float* dl, float* dx, float* dw, float* db, float* partial,
+template <int C, typename T>
+int launch_final_bwd(const T* x, const float* w, const float* dl, T* dx, float* dw, float* db, float* partial,
                      long P, long HW, int Cin, int relu_mask, hipStream_t s) {
   const long ntiles = (P + 255) / 256;
   const int grid = ntiles < kFinalBwdMaxBlocks ? (int)ntiles : kFinalBwdMaxBlocks;
   const int npairs = C * (Cin + 1);
   const size_t smem = (size_t)(256 * (Cin + 1) + C * 256 + C * Cin + 4 * npairs) * sizeof(float);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_bwd_kernel<C>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_bwd_kernel<C, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  final_bwd_kernel<C><<<grid, 256, smem, s>>>(x, w, dl, dx, partial, P, HW, Cin, ntiles, relu_mask);
+  final_bwd_kernel<C, T><<<grid, 256, smem, s>>>(x, w, dl, dx, partial, P, HW, Cin, ntiles, relu_mask);
   final_bwd_finalize_kernel<<<npairs, 256, 0, s>>>(partial, grid, C, Cin, dw, db);
+  return RS_LAUNCH_RESULT();
+}
+
+template <typename T>
+int dispatch_final_bwd(const T* x, const float* w, const float* dl, T* dx, float* dw, float* db, float* part, long P, long HW,
+                       int Cin, int C, int relu_mask, hipStream_t s) {
+  switch (C) {
+    case 1: return launch_final_bwd<1>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 2: return launch_final_bwd<2>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 3: return launch_final_bwd<3>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 4: return launch_final_bwd<4>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 5: return launch_final_bwd<5>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 6: return launch_final_bwd<6>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    case 7: return launch_final_bwd<7>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+    default: return launch_final_bwd<8>(x, w, dl, dx, dw, db, part, P, HW, Cin, relu_mask, s);
+  }
+}
+
+template <typename TY, typename TX>
+int launch_maxpool_bwd(const void* dy, const uint8_t* argmax, void* dx, int H, int W, int C, int k, int stride, int pad,
+                       int Ho, int Wo, long total, int accumulate, hipStream_t s) {
+  maxpool_bwd_kernel<TY, TX><<<rs_cdiv(total, 256), 256, 0, s>>>(reinterpret_cast<const TY*>(dy), argmax,
+                                                                 reinterpret_cast<TX*>(dx), H, W, C / 4, k, stride, pad, Ho,
+                                                                 Wo, total, accumulate);
+  return RS_LAUNCH_RESULT();
+}
+
+template <typename T>
+int launch_upsample_bwd(const void* dup, void* d1, void* d2, const void* mask1, const void* mask2, int H, int W, int C1,
+                        int C2, long total, int accumulate1, hipStream_t s) {
+  upsample2x_bwd_kernel<T><<<rs_cdiv(total, 256), 256, 0, s>>>(
+      reinterpret_cast<const T*>(dup), reinterpret_cast<T*>(d1), reinterpret_cast<T*>(d2), reinterpret_cast<const T*>(mask1),
+      reinterpret_cast<const T*>(mask2), H, W, C1, C2, total, accumulate1);
   return RS_LAUNCH_RESULT();
 }
 
 }  // namespace
 
-extern "C" int rs_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W, int C, int k,
-                                int stride, int pad, int Ho, int Wo, int accumulate, rs_stream_t stream) {
+extern "C" int rs_maxpool2d_bwd_dt(const void* dy, int dy_dtype, const uint8_t* argmax, void* dx, int dx_dtype, int N, int H,
+                                   int W, int C, int k, int stride, int pad, int Ho, int Wo, int accumulate,
+                                   rs_stream_t stream) {
   if (!dy || !argmax || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k <= 0 || k > 15 || stride <= 0 ||
       pad < 0 || Ho <= 0 || Wo <= 0)
     return RS_EINVAL;
   const long total = (long)N * H * W * (C / 4);
-  maxpool_bwd_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(dy, argmax, dx, H, W, C / 4, k, stride, pad, Ho,
-                                                                           Wo, total, accumulate);
-  return RS_LAUNCH_RESULT();
+  hipStream_t s = (hipStream_t)stream;
+  if (dy_dtype == RS_F32 && dx_dtype == RS_F32) return launch_maxpool_bwd<float, float>(dy, argmax, dx, H, W, C, k, stride, pad, Ho, Wo, total, accumulate, s);
+  if (dy_dtype == RS_BF16 && dx_dtype == RS_BF16) return launch_maxpool_bwd<bf16_t, bf16_t>(dy, argmax, dx, H, W, C, k, stride, pad, Ho, Wo, total, accumulate, s);
+  if (dy_dtype == RS_BF16 && dx_dtype == RS_F32) return launch_maxpool_bwd<bf16_t, float>(dy, argmax, dx, H, W, C, k, stride, pad, Ho, Wo, total, accumulate, s);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W, int C, int k,
+                                int stride, int pad, int Ho, int Wo, int accumulate, rs_stream_t stream) {
+  return rs_maxpool2d_bwd_dt(dy, RS_F32, argmax, dx, RS_F32, N, H, W, C, k, stride, pad, Ho, Wo, accumulate, stream);
+}
+
+extern "C" int rs_upsample2x_bwd_dt(const void* dup, void* d1, void* d2, const void* mask1, const void* mask2, int dtype,
+                                    int N, int H, int W, int C1, int C2, int accumulate1, rs_stream_t stream) {
+  if (!dup || !d1 || N <= 0 || H <= 0 || W <= 0 || C1 <= 0 || (C1 & 3) || C2 < 0 || (C2 & 3)) return RS_EINVAL;
+  if (C2 > 0 && !d2) return RS_EINVAL;
+  const long total = (long)N * H * W * ((C1 + C2) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32) return launch_upsample_bwd<float>(dup, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
+  if (dtype == RS_BF16) return launch_upsample_bwd<bf16_t>(dup, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
+  return RS_EINVAL;
 }
 
 extern "C" int rs_upsample2x_bwd(const float* dup, float* d1, float* d2, const float* mask1, const float* mask2, int N,
                                  int H, int W, int C1, int C2, int accumulate1, rs_stream_t stream) {
-  if (!dup || !d1 || N <= 0 || H <= 0 || W <= 0 || C1 <= 0 || (C1 & 3) || C2 < 0 || (C2 & 3)) return RS_EINVAL;
-  if (C2 > 0 && !d2) return RS_EINVAL;
-  const long total = (long)N * H * W * ((C1 + C2) / 4);
-  upsample2x_bwd_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(dup, d1, d2, mask1, mask2, H, W, C1, C2,
-                                                                              total, accumulate1);
-  return RS_LAUNCH_RESULT();
+  return rs_upsample2x_bwd_dt(dup, d1, d2, mask1, mask2, RS_F32, N, H, W, C1, C2, accumulate1, stream);
 }
 
 extern "C" long rs_final_conv1x1_bwd_workspace_bytes(int Cin, int C) {
@@ -248,23 +297,26 @@ extern "C" long rs_final_conv1x1_bwd_workspace_bytes(int Cin, int C) {
   return (long)kFinalBwdMaxBlocks * C * (Cin + 1) * (long)sizeof(float);
 }
 
-extern "C" int rs_final_conv1x1_bwd(const float* x, const float* w, const float* dlogits, float* dx, float* dw, float* db,
-                                    int N, int H, int W, int Cin, int C, int relu_mask, void* workspace,
-                                    rs_stream_t stream) {
+extern "C" int rs_final_conv1x1_bwd_dt(const void* x, const float* w, const float* dlogits, void* dx, float* dw, float* db,
+                                       int dtype, int N, int H, int W, int Cin, int C, int relu_mask, void* workspace,
+                                       rs_stream_t stream) {
   if (!x || !w || !dlogits || !dx || !dw || !db || !workspace || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) ||
       Cin > 64 || C <= 0 || C > 8)
     return RS_EINVAL;
   const long HW = (long)H * W, P = (long)N * HW;
   hipStream_t s = (hipStream_t)stream;
   float* part = reinterpret_cast<float*>(workspace);
-  switch (C) {
-    case 1: return launch_final_bwd<1>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    case 2: return launch_final_bwd<2>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    case 3: return launch_final_bwd<3>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    case 4: return launch_final_bwd<4>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    case 5: return launch_final_bwd<5>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    case 6: return launch_final_bwd<6>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    case 7: return launch_final_bwd<7>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-    default: return launch_final_bwd<8>(x, w, dlogits, dx, dw, db, part, P, HW, Cin, relu_mask, s);
-  }
+  if (dtype == RS_F32)
+    return dispatch_final_bwd(reinterpret_cast<const float*>(x), w, dlogits, reinterpret_cast<float*>(dx), dw, db, part, P, HW,
+                              Cin, C, relu_mask, s);
+  if (dtype == RS_BF16)
+    return dispatch_final_bwd(reinterpret_cast<const bf16_t*>(x), w, dlogits, reinterpret_cast<bf16_t*>(dx), dw, db, part, P,
+                              HW, Cin, C, relu_mask, s);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_final_conv1x1_bwd(const float* x, const float* w, const float* dlogits, float* dx, float* dw, float* db,
+                                    int N, int H, int W, int Cin, int C, int relu_mask, void* workspace,
+                                    rs_stream_t stream) {
+  return rs_final_conv1x1_bwd_dt(x, w, dlogits, dx, dw, db, RS_F32, N, H, W, Cin, C, relu_mask, workspace, stream);
 }

@@ -43,9 +43,9 @@ Geometry geometry(long M, int C) {
 
 // MODE 0: s0 = sum y,  s1 = sum y^2                       (forward statistics)
 // MODE 1: s0 = sum g,  s1 = sum g * (y - mean) * invstd     (backward; g = dz * (z > 0) when zmask != null)
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ y, const float* __restrict__ dz,
-                                                         const float* __restrict__ zmask, const float* __restrict__ mean,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y, const T* __restrict__ dz,
+                                                         const T* __restrict__ zmask, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, double* __restrict__ part,
                                                          long M, int C, int qb, int rpb, long rows_per_split) {
   __shared__ double red[256 * 8];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
     for (long r = r0 + rl; r < r1; r += rpb) {
       const long o = r * C + q * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+      const f32x4 v = rs_ld4(y + o);
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
           s1[e] += (double)v[e] * (double)v[e];
         }
       } else {
-        f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
+        f32x4 g = rs_ld4(dz + o);
         if (zmask) {
-          const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + o);
+          const f32x4 z = rs_ld4(zmask + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
         }
@@ -162,39 +162,41 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int R, l
 }
 
 // out = relu?( y * scale[c] + shift[c] (+ residual) )
-__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
-                                const float* __restrict__ res, float* __restrict__ out, long total4, int Q, int relu) {
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                const T* __restrict__ res, T* __restrict__ out, long total4, int Q, int relu) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int q = (int)(i % Q);
-  f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+  f32x4 v = rs_ld4(y + i * 4);
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
   f32x4 r = {0, 0, 0, 0};
-  if (res) r = *reinterpret_cast<const f32x4*>(res + i * 4);
+  if (res) r = rs_ld4(res + i * 4);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float t = v[e] * sc[e] + sh[e] + r[e];
     v[e] = relu ? fmaxf(t, 0.f) : t;
   }
-  *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  rs_st4(out + i * 4, v);
 }
 
 // dy = k1*g - k2 - k3*(y - mean),  g = dz*(z>0) (or dz);  optionally dmasked = g (gradient of the residual branch)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ zmask, const float* __restrict__ y,
-                                    const float* __restrict__ mean, const float* __restrict__ coef, float* __restrict__ dy,
-                                    float* __restrict__ dmasked, long total4, int Q) {
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ zmask, const T* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ coef, T* __restrict__ dy,
+                                    T* __restrict__ dmasked, long total4, int Q) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int q = (int)(i % Q);
   const int C = Q * 4;
-  f32x4 g = *reinterpret_cast<const f32x4*>(dz + i * 4);
+  f32x4 g = rs_ld4(dz + i * 4);
   if (zmask) {
-    const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + i * 4);
+    const f32x4 z = rs_ld4(zmask + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
   }
-  const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+  const f32x4 v = rs_ld4(y + i * 4);
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
   const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + q * 4);
   const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + C + q * 4);
@@ -202,55 +204,112 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
   f32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = k1[e] * g[e] - k2[e] - k3[e] * (v[e] - mu[e]);
-  *reinterpret_cast<f32x4*>(dy + i * 4) = o;
-  if (dmasked) *reinterpret_cast<f32x4*>(dmasked + i * 4) = g;
+  rs_st4(dy + i * 4, o);
+  if (dmasked) rs_st4(dmasked + i * 4, g);
+}
+
+template <typename T>
+int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const float* gamma, const float* beta, float* mean,
+                     float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
+                     long long* num_batches_tracked, void* workspace, hipStream_t s) {
+  const Geometry g = geometry(M, C);
+  double* part = reinterpret_cast<double*>(workspace);
+  bn_partial_kernel<0, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
+                                                          g.rows_per_split);
+  bn_stats_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd, scale,
+                                                           shift, running_mean, running_var, num_batches_tracked);
+  return RS_LAUNCH_RESULT();
+}
+
+template <typename T>
+int bn_bwd_t(const T* dz, const T* zmask, const T* y, const float* mean, const float* invstd, const float* gamma, T* dy,
+             T* dmasked, float* dgamma, float* dbeta, long M, int C, void* workspace, hipStream_t s) {
+  const Geometry g = geometry(M, C);
+  double* part = reinterpret_cast<double*>(workspace);
+  float* coef = reinterpret_cast<float*>(part + (long)g.R * 2 * C);  // 3*C floats behind the partials
+  bn_partial_kernel<1, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb,
+                                                          g.rows_per_split);
+  bn_bwd_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, gamma, invstd, dgamma, dbeta, coef);
+  const long total4 = M * (C / 4);
+  bn_bwd_apply_kernel<T><<<rs_cdiv(total4, 256), 256, 0, s>>>(dz, zmask, y, mean, coef, dy, dmasked, total4, C / 4);
+  return RS_LAUNCH_RESULT();
 }
 
 }  // namespace
 
-extern "C" long rs_bn_workspace_bytes(long M, int C) {
-  if (M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
-  const Geometry g = geometry(M, C);
-  return (long)g.R * 2 * C * (long)sizeof(double);
+extern "C" int rs_bn_train_stats_dt(const void* y, int dtype, long M, int C, float eps, float momentum, const float* gamma,
+                                    const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    void* workspace, rs_stream_t stream) {
+  if (!y || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace || M <= 0 || C <= 0 || (C & 3))
+    return RS_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return RS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32)
+    return bn_train_stats_t(reinterpret_cast<const float*>(y), M, C, eps, momentum, gamma, beta, mean, invstd, scale, shift,
+                            running_mean, running_var, num_batches_tracked, workspace, s);
+  if (dtype == RS_BF16)
+    return bn_train_stats_t(reinterpret_cast<const bf16_t*>(y), M, C, eps, momentum, gamma, beta, mean, invstd, scale, shift,
+                            running_mean, running_var, num_batches_tracked, workspace, s);
+  return RS_EINVAL;
 }
 
 extern "C" int rs_bn_train_stats(const float* y, long M, int C, float eps, float momentum, const float* gamma,
                                  const float* beta, float* mean, float* invstd, float* scale, float* shift,
                                  float* running_mean, float* running_var, long long* num_batches_tracked, void* workspace,
                                  rs_stream_t stream) {
-  if (!y || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace || M <= 0 || C <= 0 || (C & 3))
-    return RS_EINVAL;
-  if ((running_mean == nullptr) != (running_var == nullptr)) return RS_EINVAL;
-  const Geometry g = geometry(M, C);
+  return rs_bn_train_stats_dt(y, RS_F32, M, C, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean,
+                              running_var, num_batches_tracked, workspace, stream);
+}
+
+extern "C" int rs_bn_apply_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                              int dtype, long M, int C, int relu, rs_stream_t stream) {
+  if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
+  const long total4 = M * (C / 4);
   hipStream_t s = (hipStream_t)stream;
-  double* part = reinterpret_cast<double*>(workspace);
-  bn_partial_kernel<0><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
-                                                       g.rows_per_split);
-  bn_stats_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd, scale,
-                                                           shift, running_mean, running_var, num_batches_tracked);
+  if (dtype == RS_F32)
+    bn_apply_kernel<float><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const float*>(y), scale, shift,
+                                                                reinterpret_cast<const float*>(residual),
+                                                                reinterpret_cast<float*>(out), total4, C / 4, relu);
+  else if (dtype == RS_BF16)
+    bn_apply_kernel<bf16_t><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(y), scale, shift,
+                                                                 reinterpret_cast<const bf16_t*>(residual),
+                                                                 reinterpret_cast<bf16_t*>(out), total4, C / 4, relu);
+  else
+    return RS_EINVAL;
   return RS_LAUNCH_RESULT();
 }
 
 extern "C" int rs_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out,
                            long M, int C, int relu, rs_stream_t stream) {
-  if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
-  const long total4 = M * (C / 4);
-  bn_apply_kernel<<<rs_cdiv(total4, 256), 256, 0, (hipStream_t)stream>>>(y, scale, shift, residual, out, total4, C / 4, relu);
-  return RS_LAUNCH_RESULT();
+  return rs_bn_apply_dt(y, scale, shift, residual, out, RS_F32, M, C, relu, stream);
+}
+
+extern "C" int rs_bn_bwd_dt(const void* dz, const void* zmask, const void* y, const float* mean, const float* invstd,
+                            const float* gamma, void* dy, void* dmasked, float* dgamma, float* dbeta, int dtype, long M,
+                            int C, void* workspace, rs_stream_t stream) {
+  if (!dz || !y || !mean || !invstd || !gamma || !dy || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || (C & 3))
+    return RS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32)
+    return bn_bwd_t(reinterpret_cast<const float*>(dz), reinterpret_cast<const float*>(zmask),
+                    reinterpret_cast<const float*>(y), mean, invstd, gamma, reinterpret_cast<float*>(dy),
+                    reinterpret_cast<float*>(dmasked), dgamma, dbeta, M, C, workspace, s);
+  if (dtype == RS_BF16)
+    return bn_bwd_t(reinterpret_cast<const bf16_t*>(dz), reinterpret_cast<const bf16_t*>(zmask),
+                    reinterpret_cast<const bf16_t*>(y), mean, invstd, gamma, reinterpret_cast<bf16_t*>(dy),
+                    reinterpret_cast<bf16_t*>(dmasked), dgamma, dbeta, M, C, workspace, s);
+  return RS_EINVAL;
 }
 
 extern "C" int rs_bn_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
                          const float* gamma, float* dy, float* dmasked, float* dgamma, float* dbeta, long M, int C,
                          void* workspace, rs_stream_t stream) {
-  if (!dz || !y || !mean || !invstd || !gamma || !dy || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || (C & 3))
-    return RS_EINVAL;
+  return rs_bn_bwd_dt(dz, zmask, y, mean, invstd, gamma, dy, dmasked, dgamma, dbeta, RS_F32, M, C, workspace, stream);
+}
+
+extern "C" long rs_bn_workspace_bytes(long M, int C) {
+  if (M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
   const Geometry g = geometry(M, C);
-  hipStream_t s = (hipStream_t)stream;
-  double* part = reinterpret_cast<double*>(workspace);
-  float* coef = reinterpret_cast<float*>(part + (long)g.R * 2 * C);  // 3*C floats behind the partials
-  bn_partial_kernel<1><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb, g.rows_per_split);
-  bn_bwd_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, gamma, invstd, dgamma, dbeta, coef);
-  const long total4 = M * (C / 4);
-  bn_bwd_apply_kernel<<<rs_cdiv(total4, 256), 256, 0, s>>>(dz, zmask, y, mean, coef, dy, dmasked, total4, C / 4);
-  return RS_LAUNCH_RESULT();
+  return (long)g.R * 2 * C * (long)sizeof(double);
 }

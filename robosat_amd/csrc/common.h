@@ -7,6 +7,22 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Four consecutive activations as fp32, whatever the storage type: fp32 = one 16-byte access, bf16 = one 8-byte
+// access (+ v_cvt_pk_bf16_f32, round to nearest even, on the way out).  All arithmetic stays fp32.
+__device__ __forceinline__ f32x4 rs_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 rs_ld4(const bf16_t* p) {
+  return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
+}
+__device__ __forceinline__ void rs_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void rs_st4(bf16_t* p, f32x4 v) {
+  *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4);
+}
+__device__ __forceinline__ float rs_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float rs_ld1(const bf16_t* p) { return (float)*p; }
 
 #define RS_LAUNCH_RESULT() ((int)hipGetLastError())
 

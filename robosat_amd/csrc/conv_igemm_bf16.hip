@@ -1,0 +1,440 @@
+// Implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulation; dense chip
+// peak ~2.5 PFLOP/s): the bf16 training path of BASELINE configs[2] (`rs train ... bf16`).
+//
+// Same operator as conv_igemm.hip (every nn.Conv2d / F.interpolate / torch.cat of UNet.forward, reference
+// robosat/unet.py:122-141, and through `ups = 2` every data-gradient convolution of loss.backward(),
+// tools/train.py:186), same GEMM view (M = N*Ho*Wo pixels, N = Cout, K = taps x Cin), same fused gather and
+// epilogue.  What changes with 16x the MFMA rate is where the time goes, so the structure is re-balanced:
+//
+//   K-chunk = one filter tap x KC channels (KC = 64: 128-byte rows; KC = 32 for the 32-channel layers), i.e.
+//            KC/16 MFMA k-steps per barrier.
+//   gather  = the (tap, output pixel) -> source pixel map is computed ONCE per block into an LDS table
+//            (taps x BM ints, -1 = padding / zero-insert hole / tail row); per chunk a thread fetches its rows'
+//            entries with one ds_read and forms byte offsets with a multiply-add: the fp32 kernel's per-chunk
+//            coordinate arithmetic (~10 VALU per load) would no longer hide under 8x shorter MFMA phases.
+//            Loads are buffer_load_dwordx4 through SRSRC descriptors (offset -1 => hardware returns zeros).
+//   LDS     = UNPADDED rows of KC bf16, 16-byte pieces XOR-swizzled: piece c of row r is stored at position
+//            c ^ f(r), f(r) = (r>>1)&7 for 128-byte rows, (r>>2)&3 for 64-byte rows.  Staging writes are lane-linear
+//            (thread t -> byte 16*t of the pass: conflict-free ds_write_b128, and the image a wave writes is the one
+//            a `buffer_load ... lds` DMA would produce, so the staging primitive can be swapped without touching the
+//            readers); MFMA fragment reads (ds_read_b128: lane l reads row l&31, piece 2s + (l>>5)) hit 16 distinct
+//            16-byte slots in each of the instruction's four 16-lane groups.
+//   MFMA    = 32x32x16: lane l feeds A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31]: one b128
+//            per 32-row sub-tile per k-step.  The weight fragment is the A operand: D[i = cout][j = pixel].
+//   store   = accumulators -> LDS [pixel][cout] fp32 -> row-wise: 8 couts per thread, fp32 scale/shift, bf16 residual /
+//            ReLU / ReLU-mask, one 16-byte bf16x8 store.
+#include "common.h"
+
+namespace {
+
+struct ConvArgsB {
+  const bf16_t* src1;
+  const bf16_t* src2;
+  const bf16_t* wgt;
+  const float* scale;
+  const float* shift;
+  const bf16_t* res;
+  const bf16_t* mask;
+  bf16_t* out;
+  int N, Hs, Ws, C1, C2, Hv, Wv, ups;
+  int kh, kw, stride, pad, Ho, Wo, Cout;
+  int M, cpt, nk, Kw, relu, ntiles, ntaps;
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_make_rsrc(const void* base, long bytes) {
+  const unsigned int n = bytes > 0xFFFFFFFEL ? 0xFFFFFFFEu : (unsigned int)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
+}
+
+__device__ __forceinline__ bf16x8 rb_buffer_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+constexpr int kMaxTaps = 9;
+
+template <int BM, int BN, int WGM, int WGN, int KC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  static_assert(KC == 64 || KC == 32, "K-chunk is 64 or 32 channels");
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int ROWB = KC * 2;        // bytes per LDS row
+  constexpr int CPR = KC / 8;         // 16-byte pieces per row
+  constexpr int RPP = 256 / CPR;      // rows staged per pass of the block
+  constexpr int AR = (BM + RPP - 1) / RPP, BR = (BN + RPP - 1) / RPP;  // loads per thread per chunk
+  constexpr int KS = KC / 16;         // MFMA k-steps per chunk
+  constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline buffer
+  constexpr int LDO = BN + 4;         // epilogue staging row (floats)
+  constexpr int PIPE = 2 * BUF, STAGE = BM * LDO * 4;
+  constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
+  constexpr int TABN = (kMaxTaps + 1) * RPP * AR;  // (tap, row) -> source pixel
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
+  static_assert(BM % RPP == 0 || BM < RPP, "A tile rows vs staging pass");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAINB + TABN * 4];
+  int* tab = reinterpret_cast<int*>(smem + MAINB);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int bid = rs_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int prow = tid / CPR;  // row within a staging pass
+  const int ppos = tid % CPR;  // LDS piece position written by this thread
+  const int fsw = KC == 64 ? ((prow >> 1) & 7) : ((prow >> 2) & 3);
+  const int pc = ppos ^ fsw;   // global piece (8 channels) this thread fetches
+
+  const int HoWo = p.Ho * p.Wo;
+  const int nfirst = m0 / HoWo;
+  const int ush = p.ups ? 1 : 0;
+  const int upar = p.ups == 2 ? 1 : 0;
+
+  // ---- (tap, row) -> source pixel table, relative to the tile's first image; -1 = contributes zeros ------------
+  for (int e = tid; e < p.ntaps * BM; e += 256) {
+    const int tap = e / BM, row = e - tap * BM;
+    const int m = m0 + row;
+    int pix = -1;
+    if (m < p.M) {
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      const int r = tap / p.kw, s = tap - r * p.kw;
+      const int iy = oy * p.stride - p.pad + r;
+      const int ix = ox * p.stride - p.pad + s;
+      const bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv) && (((iy | ix) & upar) == 0);
+      if (ok) pix = ((n - nfirst) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+    }
+    tab[(tap * RPP + (row % RPP)) * AR + row / RPP] = pix;
+  }
+  for (int e = tid; e < RPP * AR; e += 256) tab[p.ntaps * RPP * AR + e] = -1;  // the prefetch past the last chunk
+
+  const long img1 = (long)p.Hs * p.Ws * p.C1;
+  const long img2 = (long)p.Hs * p.Ws * p.C2;
+  const __amdgpu_buffer_rsrc_t rsrc1 = rb_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * 2);
+  const __amdgpu_buffer_rsrc_t rsrc2 = rb_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * 2);
+  const __amdgpu_buffer_rsrc_t rsrcw = rb_make_rsrc(p.wgt, (long)p.Cout * p.Kw * 2);
+  int woff[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int row = prow + RPP * i;
+    woff[i] = (row < BN) ? ((n0 + row) * p.Kw + pc * 8) * 2 : -1;
+  }
+  __syncthreads();
+
+  bf16x8 ra[AR], rb[BR];
+  int lt = 0, lc = 0, lk = 0;  // next chunk to fetch: tap / channel chunk within the tap / linear index
+
+  // issues part `part` (of NP) of the loads of the NEXT chunk
+  auto load_part = [&](int part, int np) __attribute__((always_inline)) {
+    const int c0 = lc * KC;
+    const bool first = c0 < p.C1;
+    const __amdgpu_buffer_rsrc_t rs = first ? rsrc1 : rsrc2;
+    const int cs2 = (first ? p.C1 : p.C2) * 2;
+    const int cb = ((first ? c0 : c0 - p.C1) + pc * 8) * 2;
+    int pix[AR];
+    if constexpr (AR == 4) {
+      const i32x4 v = *reinterpret_cast<const i32x4*>(&tab[(lt * RPP + prow) * AR]);
+      pix[0] = v[0];
+      pix[1] = v[1];
+      pix[2] = v[2];
+      pix[3] = v[3];
+    } else if constexpr (AR == 2) {
+      const i32x2 v = *reinterpret_cast<const i32x2*>(&tab[(lt * RPP + prow) * AR]);
+      pix[0] = v[0];
+      pix[1] = v[1];
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) pix[i] = tab[(lt * RPP + prow) * AR + i];
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      if ((i % np) != part) continue;
+      const bool ok = pix[i] >= 0 && (BM >= RPP || prow < BM);
+      const int off = ok ? pix[i] * cs2 + cb : -1;
+      ra[i] = rb_buffer_load8(rs, off);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      if (((i + 1) % np) != part) continue;
+      rb[i] = rb_buffer_load8(rsrcw, woff[i] < 0 ? -1 : woff[i] + lk * ROWB);
+    }
+  };
+
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++lk;
+    ++lc;
+    const int w1 = (lc == p.cpt) ? 1 : 0;
+    lc = w1 ? 0 : lc;
+    lt += w1;
+  };
+
+  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* L = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      if (BM >= RPP || prow < BM) *reinterpret_cast<bf16x8*>(L + (prow + RPP * i) * ROWB + ppos * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      if (BN >= RPP * (i + 1) || prow + RPP * i < BN)
+        *reinterpret_cast<bf16x8*>(L + (BM + prow + RPP * i) * ROWB + ppos * 16) = rb[i];
+  };
+
+  f32x16 acc[TN][TM];  // [cout sub-tile][pixel sub-tile]; D rows = couts, D cols = pixels
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment addressing: row (lane&31) of a 32-row sub-tile, piece 2s + (lane>>5), swizzled
+  const int frow = lane & 31;
+  const int fl = KC == 64 ? ((frow >> 1) & 7) : ((frow >> 2) & 3);
+  int foff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) foff[s] = ((2 * s + (lane >> 5)) ^ fl) * 16;
+  const int abase = (wm * WM + frow) * ROWB;
+  const int bbase = (BM + wn * WN + frow) * ROWB;
+
+  auto read_frag = [&](const unsigned char* L, int s, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(L + abase + 32 * tm * ROWB + foff[s]);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const bf16x8*>(L + bbase + 32 * tn * ROWB + foff[s]);
+  };
+  auto mma_frag = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
+  };
+
+  // ---- main loop: per k-step { LDS fragments of step s+1 | a share of chunk k+1's global loads | MFMAs of step s };
+  //      then registers -> LDS (other buffer) | barrier.  The last k-step carries no global load (latency cover).
+  constexpr int NP = KS > 1 ? KS - 1 : 1;
+#pragma unroll
+  for (int part = 0; part < NP; ++part) load_part(part, NP);
+  advance();
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < p.nk; ++kc) {
+    const unsigned char* L = smem + (kc & 1) * BUF;
+    bf16x8 fa[2][TM], fb[2][TN];
+    read_frag(L, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+        read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        load_part(s, NP);
+      } else if (KS == 1) {
+        load_part(0, 1);
+      }
+      mma_frag(fa[s & 1], fb[s & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance();
+    store_chunk((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> LDS [pixel][cout] fp32 -> 8 couts per thread, 16-byte bf16 stores --------------------
+  float* lds = reinterpret_cast<float*>(smem);
+  {
+    const int pr = wm * WM + (lane & 31);
+    const int ccol = wn * WN + 4 * (lane >> 5);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = acc[tn][tm][4 * g + 0];
+          v[1] = acc[tn][tm][4 * g + 1];
+          v[2] = acc[tn][tm][4 * g + 2];
+          v[3] = acc[tn][tm][4 * g + 3];
+          *reinterpret_cast<f32x4*>(&lds[(pr + 32 * tm) * LDO + ccol + 32 * tn + 8 * g]) = v;
+        }
+  }
+  __syncthreads();
+  {
+    constexpr int TPR = BN / 8;                // threads per row (8 couts each)
+    constexpr int RPI = 256 / TPR;             // rows per iteration
+    const int cc = tid % TPR, rr = tid / TPR;
+    const int col = n0 + cc * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = p.scale ? p.scale[col + e] : 1.f;
+      sh[e] = p.shift ? p.shift[col + e] : 0.f;
+    }
+#pragma unroll 2
+    for (int row = rr; row < BM; row += RPI) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      const long o = (long)m * p.Cout + col;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * 8]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * 8 + 4]);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v0[e] * sc[e] + sh[e];
+        v[4 + e] = v1[e] * sc[4 + e] + sh[4 + e];
+      }
+      if (p.res) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.res + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.mask) {
+        const bf16x8 z = *reinterpret_cast<const bf16x8*>(p.mask + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)z[e] > 0.f ? v[e] : 0.f;
+      }
+      bf16x8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(p.out + o) = ov;
+    }
+  }
+}
+
+// fp32 KRSC [Cout][taps][Cin] -> bf16 data-gradient weights [Cin][taps][Cout], taps flipped (cf. conv_wgrad.hip)
+__global__ void pack_dgrad_weight_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int taps,
+                                              int Cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long)co * taps + tap) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  const int ftap = taps - 1 - tap;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) out[((long)ci * taps + ftap) * Cout + co] = (bf16_t)tile[tx][r];
+  }
+}
+
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, NTILES };
+const char* const kTileNames[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
+                                        "conv_igemm_bf16<64x64>"};
+const int kTileBM[NTILES] = {128, 128, 128, 64};
+const int kTileBN[NTILES] = {128, 64, 32, 64};
+
+bool valid(const rs_conv_desc* d) {
+  if (!d) return false;
+  if (d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
+  if (d->kh <= 0 || d->kw <= 0 || d->kh * d->kw > kMaxTaps || d->stride <= 0 || d->pad < 0) return false;
+  if (d->Cout <= 0 || (d->Cout % 32) != 0) return false;
+  if (d->ups < 0 || d->ups > 2 || d->stem) return false;
+  if (d->C1 <= 0 || (d->C1 % 32) != 0 || d->C2 < 0 || (d->C2 % 32) != 0) return false;
+  return true;
+}
+
+int pick_tile(const rs_conv_desc* d) {
+  const long M = (long)d->N * d->Ho * d->Wo;
+  const long want = 512;  // >= 2 blocks per CU
+  if (d->Cout % 128 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 128) >= want) return T128x128;
+  if (d->Cout % 64 == 0) {
+    if ((long)rs_cdiv(M, 128) * (d->Cout / 64) >= want) return T128x64;
+    return T64x64;
+  }
+  return T128x32;
+}
+
+template <int KC>
+void launch(int tile, int grid, hipStream_t s, const ConvArgsB& a) {
+  switch (tile) {
+    case T128x128: conv_igemm_bf16<128, 128, 2, 2, KC><<<grid, 256, 0, s>>>(a); break;
+    case T128x64: conv_igemm_bf16<128, 64, 2, 2, KC><<<grid, 256, 0, s>>>(a); break;
+    case T128x32: conv_igemm_bf16<128, 32, 4, 1, KC><<<grid, 256, 0, s>>>(a); break;
+    default: conv_igemm_bf16<64, 64, 2, 2, KC><<<grid, 256, 0, s>>>(a); break;
+  }
+}
+
+}  // namespace
+
+extern "C" int rs_conv2d_tile_bf16(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+
+extern "C" const char* rs_conv2d_tile_name_bf16(int tile) { return (tile >= 0 && tile < NTILES) ? kTileNames[tile] : ""; }
+
+extern "C" int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, const rs_bf16* src2, const rs_bf16* weight,
+                                  const float* scale, const float* shift, const rs_bf16* residual, const rs_bf16* relu_mask,
+                                  rs_bf16* out, rs_stream_t stream) {
+  if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
+  if (d->C2 > 0 && !src2) return RS_EINVAL;
+  ConvArgsB a;
+  a.src1 = reinterpret_cast<const bf16_t*>(src1);
+  a.src2 = reinterpret_cast<const bf16_t*>(src2);
+  a.wgt = reinterpret_cast<const bf16_t*>(weight);
+  a.scale = scale;
+  a.shift = shift;
+  a.res = reinterpret_cast<const bf16_t*>(residual);
+  a.mask = reinterpret_cast<const bf16_t*>(relu_mask);
+  a.out = reinterpret_cast<bf16_t*>(out);
+  a.N = d->N;
+  a.Hs = d->Hs;
+  a.Ws = d->Ws;
+  a.C1 = d->C1;
+  a.C2 = d->C2;
+  a.ups = d->ups;
+  a.Hv = d->ups == 0 ? d->Hs : (d->ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
+  a.Wv = d->ups == 0 ? d->Ws : (d->ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
+  a.kh = d->kh;
+  a.kw = d->kw;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.Ho = d->Ho;
+  a.Wo = d->Wo;
+  a.Cout = d->Cout;
+  const long M = (long)d->N * d->Ho * d->Wo;
+  if (M >= (1L << 31)) return RS_EINVAL;
+  a.M = (int)M;
+  {
+    // 32-bit byte offsets relative to the first image of a tile (<= 128 output pixels: 128/(Ho*Wo) + 2 images)
+    const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+    const long img_bytes = (long)d->Hs * d->Ws * cmax * 2;
+    const long span = (128 / ((long)d->Ho * d->Wo) + 2) * img_bytes;
+    if (span >= (1L << 31)) return RS_EINVAL;
+    if ((long)d->Cout * d->kh * d->kw * (d->C1 + d->C2) * 2 >= (1L << 31)) return RS_EINVAL;
+  }
+  const int kc = (d->C1 % 64 == 0 && d->C2 % 64 == 0) ? 64 : 32;
+  a.cpt = (d->C1 + d->C2) / kc;
+  a.ntaps = d->kh * d->kw;
+  a.nk = a.ntaps * a.cpt;
+  a.Kw = a.nk * kc;
+  a.relu = d->relu;
+
+  const int tile = pick_tile(d);
+  a.ntiles = d->Cout / kTileBN[tile];
+  const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles;
+  hipStream_t s = (hipStream_t)stream;
+  if (kc == 64) launch<64>(tile, grid, s, a);
+  else launch<32>(tile, grid, s, a);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_pack_dgrad_weight_bf16(const float* w_krsc, rs_bf16* out, int Cout, int kh, int kw, int Cin,
+                                         rs_stream_t stream) {
+  if (!w_krsc || !out || Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0) return RS_EINVAL;
+  dim3 grid(rs_cdiv(Cin, 32), rs_cdiv(Cout, 32), kh * kw);
+  pack_dgrad_weight_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, kh * kw,
+                                                                       Cin);
+  return RS_LAUNCH_RESULT();
+}

@@ -21,7 +21,8 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restr
 
 // F.max_pool2d on NHWC, 4 channels per thread.  Window scanned row-major with a strict '>' so the FIRST maximum
 // wins, as torch's max_pool2d_with_indices does; padding is -inf (never selected when any tap is valid).
-__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ amax, int H,
+template <typename TI, typename TO>
+__global__ void maxpool_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y, uint8_t* __restrict__ amax, int H,
                                     int W, int C4, int k, int stride, int pad, int Ho, int Wo, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -41,7 +42,7 @@ __global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restri
     for (int s = 0; s < k; ++s) {
       const int ix = ox * stride - pad + s;
       if ((unsigned)ix >= (unsigned)W) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
+      const f32x4 v = rs_ld4(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
       const int tap = r * k + s;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -53,7 +54,7 @@ __global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restri
       first = false;
     }
   }
-  *reinterpret_cast<f32x4*>(y + i * 4) = best;
+  rs_st4(y + i * 4, best);
   if (amax) {
     const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     *reinterpret_cast<uint32_t*>(amax + i * 4) = packed;
@@ -73,8 +74,8 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 // self.final (+ optional softmax): 256 pixels per block.  The block's [256][Cin] slab is read with fully coalesced
 // 16-byte loads into LDS (row stride Cin+1: conflict-free per-pixel reads), then one thread owns one pixel, keeps
 // the C class sums in registers and writes C coalesced NCHW planes.
-template <int C>
-__global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void final_conv1x1_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             long P, long HW, int Cin, int softmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restr
   for (int f = tid; f < 256 * q; f += 256) {
     const int px = f / q, c4 = f - px * q;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p0 + px < P) v = *reinterpret_cast<const f32x4*>(x + (p0 + px) * Cin + c4 * 4);
+    if (p0 + px < P) v = rs_ld4(x + (p0 + px) * Cin + c4 * 4);
     float* d = xs + px * ld + c4 * 4;
     d[0] = v[0];
     d[1] = v[1];
@@ -129,54 +130,22 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restr
   for (int c = 0; c < C; ++c) o[c * HW] = acc[c];
 }
 
-template <int C>
-int launch_final(const float* x, const float* w, const float* bias, float* out, long P, long HW, int Cin, int softmax,
+template <int C, typename T>
+int launch_final(const T* x, const float* w, const float* bias, float* out, long P, long HW, int Cin, int softmax,
                  hipStream_t s) {
   const size_t smem = (size_t)(256 * (Cin + 1) + C * Cin + C) * sizeof(float);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_conv1x1_kernel<C>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_conv1x1_kernel<C, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  final_conv1x1_kernel<C><<<rs_cdiv(P, 256), 256, smem, s>>>(x, w, bias, out, P, HW, Cin, softmax);
+  final_conv1x1_kernel<C, T><<<rs_cdiv(P, 256), 256, smem, s>>>(x, w, bias, out, P, HW, Cin, softmax);
   return RS_LAUNCH_RESULT();
 }
 
-}  // namespace
-
-extern "C" int rs_abi_version(void) { return 2; }
-
-extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
-  if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
-  const long HW = (long)H * W, total = (long)N * HW;
-  nchw_to_nhwc4_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, C, HW, total);
-  return RS_LAUNCH_RESULT();
-}
-
-extern "C" int rs_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride,
-                                int pad, int Ho, int Wo, rs_stream_t stream) {
-  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k <= 0 || k > 15 || stride <= 0 || pad < 0 ||
-      Ho <= 0 || Wo <= 0)
-    return RS_EINVAL;
-  const long total = (long)N * Ho * Wo * (C / 4);
-  maxpool_nhwc_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, argmax, H, W, C / 4, k, stride, pad, Ho,
-                                                                            Wo, total);
-  return RS_LAUNCH_RESULT();
-}
-
-extern "C" int rs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                          float* scale, float* shift, int C, rs_stream_t stream) {
-  if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) return RS_EINVAL;
-  bn_fold_kernel<<<rs_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, mean, var, eps, scale, shift, C);
-  return RS_LAUNCH_RESULT();
-}
-
-extern "C" int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
-                                int C, int softmax, rs_stream_t stream) {
-  if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cin > 128 || C <= 0 || C > 8)
-    return RS_EINVAL;
-  const long HW = (long)H * W, P = (long)N * HW;
-  hipStream_t s = (hipStream_t)stream;
+template <typename T>
+int dispatch_final(const T* x, const float* w, const float* bias, float* out, long P, long HW, int Cin, int C, int softmax,
+                   hipStream_t s) {
   switch (C) {
     case 1: return launch_final<1>(x, w, bias, out, P, HW, Cin, softmax, s);
     case 2: return launch_final<2>(x, w, bias, out, P, HW, Cin, softmax, s);
@@ -187,4 +156,87 @@ extern "C" int rs_final_conv1x1(const float* x, const float* w, const float* bia
     case 7: return launch_final<7>(x, w, bias, out, P, HW, Cin, softmax, s);
     default: return launch_final<8>(x, w, bias, out, P, HW, Cin, softmax, s);
   }
+}
+
+template <typename TI, typename TO>
+int launch_maxpool(const void* x, void* y, uint8_t* argmax, int H, int W, int C, int k, int stride, int pad, int Ho,
+                   int Wo, long total, hipStream_t s) {
+  maxpool_nhwc_kernel<TI, TO><<<rs_cdiv(total, 256), 256, 0, s>>>(reinterpret_cast<const TI*>(x), reinterpret_cast<TO*>(y),
+                                                                  argmax, H, W, C / 4, k, stride, pad, Ho, Wo, total);
+  return RS_LAUNCH_RESULT();
+}
+
+// fp32 -> bf16 (round to nearest even), 8 elements per thread; tail handled element-wise
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i), b = *reinterpret_cast<const f32x4*>(src + i + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (bf16_t)a[e];
+      o[4 + e] = (bf16_t)b[e];
+    }
+    *reinterpret_cast<bf16x8*>(dst + i) = o;
+  } else {
+    for (long j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+  }
+}
+
+}  // namespace
+
+extern "C" int rs_abi_version(void) { return 3; }
+
+extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
+  const long HW = (long)H * W, total = (long)N * HW;
+  nchw_to_nhwc4_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, C, HW, total);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_maxpool2d_fwd_dt(const void* x, int x_dtype, void* y, int y_dtype, uint8_t* argmax, int N, int H, int W,
+                                   int C, int k, int stride, int pad, int Ho, int Wo, rs_stream_t stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k <= 0 || k > 15 || stride <= 0 || pad < 0 ||
+      Ho <= 0 || Wo <= 0)
+    return RS_EINVAL;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == RS_F32 && y_dtype == RS_F32) return launch_maxpool<float, float>(x, y, argmax, H, W, C, k, stride, pad, Ho, Wo, total, s);
+  if (x_dtype == RS_F32 && y_dtype == RS_BF16) return launch_maxpool<float, bf16_t>(x, y, argmax, H, W, C, k, stride, pad, Ho, Wo, total, s);
+  if (x_dtype == RS_BF16 && y_dtype == RS_BF16) return launch_maxpool<bf16_t, bf16_t>(x, y, argmax, H, W, C, k, stride, pad, Ho, Wo, total, s);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride,
+                                int pad, int Ho, int Wo, rs_stream_t stream) {
+  return rs_maxpool2d_fwd_dt(x, RS_F32, y, RS_F32, argmax, N, H, W, C, k, stride, pad, Ho, Wo, stream);
+}
+
+extern "C" int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stream) {
+  if (!src || !dst || n <= 0) return RS_EINVAL;
+  cast_f32_bf16_kernel<<<rs_cdiv(rs_cdiv(n, 8), 256), 256, 0, (hipStream_t)stream>>>(src, reinterpret_cast<bf16_t*>(dst), n);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* shift, int C, rs_stream_t stream) {
+  if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) return RS_EINVAL;
+  bn_fold_kernel<<<rs_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, mean, var, eps, scale, shift, C);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_final_conv1x1_dt(const void* x, int x_dtype, const float* w, const float* bias, float* out, int N, int H,
+                                   int W, int Cin, int C, int softmax, rs_stream_t stream) {
+  if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cin > 128 || C <= 0 || C > 8)
+    return RS_EINVAL;
+  const long HW = (long)H * W, P = (long)N * HW;
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == RS_F32) return dispatch_final(reinterpret_cast<const float*>(x), w, bias, out, P, HW, Cin, C, softmax, s);
+  if (x_dtype == RS_BF16) return dispatch_final(reinterpret_cast<const bf16_t*>(x), w, bias, out, P, HW, Cin, C, softmax, s);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
+                                int C, int softmax, rs_stream_t stream) {
+  return rs_final_conv1x1_dt(x, RS_F32, w, bias, out, N, H, W, Cin, C, softmax, stream);
 }

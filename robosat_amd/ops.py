@@ -10,7 +10,19 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, check
+from ._lib import RS_BF16, RS_F32, ConvDesc, check
+
+BF16 = torch.bfloat16
+
+
+def _dt(t):
+    """dtype code of an activation tensor for the ``*_dt`` entry points."""
+
+    if t.dtype == torch.float32:
+        return RS_F32
+    if t.dtype == torch.bfloat16:
+        return RS_BF16
+    raise TypeError("robosat_amd: activations are fp32 or bf16, got {}".format(t.dtype))
 
 
 def _dev(t, name, dtype=torch.float32):
@@ -61,8 +73,12 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     ``relu_mask``: tensor shaped like ``out``; the result is zeroed where it is <= 0 (fused ReLU backward)."""
 
     d = conv_desc(src1, weight, src2, ups, stride, pad, relu, stem, out_hw)
+    act = src1.dtype  # fp32: exact-fp32 MFMA kernels; bf16: bf16 operands, fp32 accumulation
+    bf = act == BF16
+    if bf and stem:
+        raise ValueError("the 7x7 stem runs on the fp32 kernel (cast happens at the stem max-pool)")
     if out is None:
-        out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=src1.device, dtype=torch.float32)
+        out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=src1.device, dtype=act)
     if src2 is not None:
         assert src2.shape[:3] == src1.shape[:3]
     if not stem:
@@ -74,20 +90,31 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = _lib.lib().rs_conv2d_fwd(
-        ctypes.byref(d), _dev(src1, "src1"), _dev(src2, "src2"), _dev(weight, "weight"), _dev(scale, "scale"),
-        _dev(shift, "shift"), _dev(residual, "residual"), _dev(relu_mask, "relu_mask"), _dev(out, "out"), _stream(),
+    fn = _lib.lib().rs_conv2d_fwd_bf16 if bf else _lib.lib().rs_conv2d_fwd
+    rc = fn(
+        ctypes.byref(d), _dev(src1, "src1", act), _dev(src2, "src2", act), _dev(weight, "weight", act), _dev(scale, "scale"),
+        _dev(shift, "shift"), _dev(residual, "residual", act), _dev(relu_mask, "relu_mask", act), _dev(out, "out", act), _stream(),
     )
-    check(rc, "rs_conv2d_fwd")
+    check(rc, "rs_conv2d_fwd_bf16" if bf else "rs_conv2d_fwd")
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((conv_tile_name(d), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
+        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
     return out
 
 
-def conv_tile_name(d):
+def conv_tile_name(d, bf16=False):
     lib = _lib.lib()
+    if bf16:
+        return lib.rs_conv2d_tile_name_bf16(lib.rs_conv2d_tile_bf16(ctypes.byref(d))).decode()
     return lib.rs_conv2d_tile_name(lib.rs_conv2d_tile(ctypes.byref(d))).decode()
+
+
+def cast_bf16(t):
+    """fp32 -> bf16 copy (round to nearest even); used for the per-step compute copies of the fp32 master weights."""
+
+    out = torch.empty(t.shape, device=t.device, dtype=BF16)
+    check(_lib.lib().rs_cast_f32_to_bf16(_dev(t, "src"), _dev(out, "dst", BF16), t.numel(), _stream()), "rs_cast_f32_to_bf16")
+    return out
 
 
 def pack_stem_weight(w_krsc):
@@ -107,14 +134,16 @@ def nchw_to_nhwc4(x):
     return out
 
 
-def maxpool2d(x, k, stride, pad, want_argmax=False):
+def maxpool2d(x, k, stride, pad, want_argmax=False, out_dtype=None):
+    """``out_dtype`` (default: x.dtype): torch.bfloat16 on an fp32 input is the precision boundary of the bf16 path."""
+
     n, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    out = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    out = torch.empty((n, ho, wo, c), device=x.device, dtype=out_dtype or x.dtype)
     amax = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
-    rc = _lib.lib().rs_maxpool2d_fwd(_dev(x, "x"), _dev(out, "out"), _dev(amax, "argmax", torch.uint8), n, h, w, c, k,
-                                     stride, pad, ho, wo, _stream())
-    check(rc, "rs_maxpool2d_fwd")
+    rc = _lib.lib().rs_maxpool2d_fwd_dt(_dev(x, "x", x.dtype), _dt(x), _dev(out, "out", out.dtype), _dt(out),
+                                        _dev(amax, "argmax", torch.uint8), n, h, w, c, k, stride, pad, ho, wo, _stream())
+    check(rc, "rs_maxpool2d_fwd_dt")
     return (out, amax) if want_argmax else out
 
 
@@ -134,9 +163,9 @@ def final_conv1x1(x, w, bias, softmax=False):
     n, h, wd, cin = x.shape
     c = w.shape[0]
     out = torch.empty((n, c, h, wd), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().rs_final_conv1x1(_dev(x, "x"), _dev(w, "w"), _dev(bias, "bias"), _dev(out, "out"), n, h, wd, cin, c,
-                                     int(softmax), _stream())
-    check(rc, "rs_final_conv1x1")
+    rc = _lib.lib().rs_final_conv1x1_dt(_dev(x, "x", x.dtype), _dt(x), _dev(w, "w"), _dev(bias, "bias"), _dev(out, "out"), n, h,
+                                        wd, cin, c, int(softmax), _stream())
+    check(rc, "rs_final_conv1x1_dt")
     return out
 
 
@@ -159,13 +188,13 @@ def _workspace(nbytes, device):
     return ctypes.c_void_p(ws.data_ptr())
 
 
-def pack_dgrad_weight(w_krsc):
-    """[Cout,kh,kw,Cin] -> [Cin,kh,kw,Cout], taps flipped (weights of the data-gradient convolution)."""
+def pack_dgrad_weight(w_krsc, dtype=torch.float32):
+    """fp32 [Cout,kh,kw,Cin] -> [Cin,kh,kw,Cout] in ``dtype``, taps flipped (weights of the data-gradient convolution)."""
 
     cout, kh, kw, cin = w_krsc.shape
-    out = torch.empty((cin, kh, kw, cout), device=w_krsc.device, dtype=torch.float32)
-    check(_lib.lib().rs_pack_dgrad_weight(_dev(w_krsc, "w"), _dev(out, "out"), cout, kh, kw, cin, _stream()),
-          "rs_pack_dgrad_weight")
+    out = torch.empty((cin, kh, kw, cout), device=w_krsc.device, dtype=dtype)
+    fn = _lib.lib().rs_pack_dgrad_weight_bf16 if dtype == BF16 else _lib.lib().rs_pack_dgrad_weight
+    check(fn(_dev(w_krsc, "w"), _dev(out, "out", dtype), cout, kh, kw, cin, _stream()), "rs_pack_dgrad_weight")
     return out
 
 
@@ -187,19 +216,23 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
     c2 = 0 if src2 is None else src2.shape[3]
     d = ConvDesc(n, hs, ws, c1, c2, ups, kh, kw, stride, pad, ho, wo, cout, 0, int(bool(stem)))
     lib = _lib.lib()
+    act = dy.dtype
+    bf = act == BF16
     shape = (cout, kh, 8, 4) if stem else (cout, kh, kw, c1 + c2)
     dw = out if out is not None else torch.empty(shape, device=dy.device, dtype=torch.float32)
     assert tuple(dw.shape) == shape
-    wsb = lib.rs_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    wsb = (lib.rs_conv2d_wgrad_bf16_workspace_bytes if bf else lib.rs_conv2d_wgrad_workspace_bytes)(ctypes.byref(d))
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.rs_conv2d_wgrad(ctypes.byref(d), _dev(dy, "dy"), _dev(src1, "src1"), _dev(src2, "src2"), _dev(dw, "dw"),
-                             _workspace(wsb, dy.device), _stream())
-    check(rc, "rs_conv2d_wgrad")
+    fn = lib.rs_conv2d_wgrad_bf16 if bf else lib.rs_conv2d_wgrad
+    rc = fn(ctypes.byref(d), _dev(dy, "dy", act), _dev(src1, "src1", act), _dev(src2, "src2", act), _dev(dw, "dw"),
+            _workspace(wsb, dy.device), _stream())
+    check(rc, "rs_conv2d_wgrad_bf16" if bf else "rs_conv2d_wgrad")
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append(("conv_wgrad_f32", conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
+        PROFILE.append(("conv_wgrad_bf16" if bf else "conv_wgrad_f32", conv_flops(d),
+                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
     return dw
 
 
@@ -213,8 +246,8 @@ def bn_train_stats(y, gamma, beta, eps, momentum, running_mean=None, running_var
     c = y.shape[-1]
     m = y.numel() // c
     mean, invstd, scale, shift = (torch.empty(c, device=y.device, dtype=torch.float32) for _ in range(4))
-    rc = _lib.lib().rs_bn_train_stats(
-        _dev(y, "y"), m, c, ctypes.c_float(eps), ctypes.c_float(momentum), _dev(gamma, "gamma"), _dev(beta, "beta"),
+    rc = _lib.lib().rs_bn_train_stats_dt(
+        _dev(y, "y", y.dtype), _dt(y), m, c, ctypes.c_float(eps), ctypes.c_float(momentum), _dev(gamma, "gamma"), _dev(beta, "beta"),
         _dev(mean, "mean"), _dev(invstd, "invstd"), _dev(scale, "scale"), _dev(shift, "shift"),
         _dev(running_mean, "running_mean"), _dev(running_var, "running_var"),
         _dev(num_batches_tracked, "num_batches_tracked", torch.int64), _bn_ws(m, c, y.device), _stream())
@@ -225,8 +258,9 @@ def bn_train_stats(y, gamma, beta, eps, momentum, running_mean=None, running_var
 def bn_apply(y, scale, shift, residual=None, relu=False):
     c = y.shape[-1]
     out = torch.empty_like(y)
-    rc = _lib.lib().rs_bn_apply(_dev(y, "y"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(residual, "residual"),
-                                _dev(out, "out"), y.numel() // c, c, int(relu), _stream())
+    rc = _lib.lib().rs_bn_apply_dt(_dev(y, "y", y.dtype), _dev(scale, "scale"), _dev(shift, "shift"),
+                                   _dev(residual, "residual", y.dtype), _dev(out, "out", y.dtype), _dt(y), y.numel() // c, c,
+                                   int(relu), _stream())
     check(rc, "rs_bn_apply")
     return out
 
@@ -242,23 +276,26 @@ def bn_bwd(dz, zmask, y, mean, invstd, gamma, want_masked=False, dgamma=None, db
         dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
     if dbeta is None:
         dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
-    rc = _lib.lib().rs_bn_bwd(_dev(dz, "dz"), _dev(zmask, "zmask"), _dev(y, "y"), _dev(mean, "mean"), _dev(invstd, "invstd"),
-                              _dev(gamma, "gamma"), _dev(dy, "dy"), _dev(dmasked, "dmasked"), _dev(dgamma, "dgamma"),
-                              _dev(dbeta, "dbeta"), m, c, _bn_ws(m, c, y.device), _stream())
+    t = y.dtype
+    rc = _lib.lib().rs_bn_bwd_dt(_dev(dz, "dz", t), _dev(zmask, "zmask", t), _dev(y, "y", t), _dev(mean, "mean"),
+                                 _dev(invstd, "invstd"), _dev(gamma, "gamma"), _dev(dy, "dy", t), _dev(dmasked, "dmasked", t),
+                                 _dev(dgamma, "dgamma"), _dev(dbeta, "dbeta"), _dt(y), m, c, _bn_ws(m, c, y.device), _stream())
     check(rc, "rs_bn_bwd")
     return (dy, dgamma, dbeta, dmasked) if want_masked else (dy, dgamma, dbeta)
 
 
-def maxpool2d_bwd(dy, argmax, in_shape, k, stride, pad, out=None):
-    """Gradient wrt the pooling input [N,H,W,C]; ``out`` given => accumulate into it."""
+def maxpool2d_bwd(dy, argmax, in_shape, k, stride, pad, out=None, out_dtype=None):
+    """Gradient wrt the pooling input [N,H,W,C]; ``out`` given => accumulate into it.  ``out_dtype`` fp32 on a bf16 dy
+    is the precision boundary of the bf16 path (stem pool)."""
 
     n, h, w, c = in_shape
     ho, wo = dy.shape[1:3]
     acc = out is not None
     if out is None:
-        out = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
-    rc = _lib.lib().rs_maxpool2d_bwd(_dev(dy, "dy"), _dev(argmax, "argmax", torch.uint8), _dev(out, "dx"), n, h, w, c, k,
-                                     stride, pad, ho, wo, int(acc), _stream())
+        out = torch.empty(in_shape, device=dy.device, dtype=out_dtype or dy.dtype)
+    rc = _lib.lib().rs_maxpool2d_bwd_dt(_dev(dy, "dy", dy.dtype), _dt(dy), _dev(argmax, "argmax", torch.uint8),
+                                        _dev(out, "dx", out.dtype), _dt(out), n, h, w, c, k, stride, pad, ho, wo, int(acc),
+                                        _stream())
     check(rc, "rs_maxpool2d_bwd")
     return out
 
@@ -270,10 +307,11 @@ def upsample2x_bwd(dup, c1, c2=0, mask1=None, mask2=None, out1=None):
     assert ct == c1 + c2 and h2 % 2 == 0 and w2 % 2 == 0
     h, w = h2 // 2, w2 // 2
     acc = out1 is not None
-    d1 = out1 if acc else torch.empty((n, h, w, c1), device=dup.device, dtype=torch.float32)
-    d2 = torch.empty((n, h, w, c2), device=dup.device, dtype=torch.float32) if c2 else None
-    rc = _lib.lib().rs_upsample2x_bwd(_dev(dup, "dup"), _dev(d1, "d1"), _dev(d2, "d2"), _dev(mask1, "mask1"),
-                                      _dev(mask2, "mask2"), n, h, w, c1, c2, int(acc), _stream())
+    t = dup.dtype
+    d1 = out1 if acc else torch.empty((n, h, w, c1), device=dup.device, dtype=t)
+    d2 = torch.empty((n, h, w, c2), device=dup.device, dtype=t) if c2 else None
+    rc = _lib.lib().rs_upsample2x_bwd_dt(_dev(dup, "dup", t), _dev(d1, "d1", t), _dev(d2, "d2", t), _dev(mask1, "mask1", t),
+                                         _dev(mask2, "mask2", t), _dt(dup), n, h, w, c1, c2, int(acc), _stream())
     check(rc, "rs_upsample2x_bwd")
     return d1, d2
 
@@ -290,8 +328,8 @@ def final_conv1x1_bwd(x, w, dlogits, relu_mask=True, dw=None, db=None):
     if db is None:
         db = torch.empty(c, device=x.device, dtype=torch.float32)
     ws = _workspace(lib.rs_final_conv1x1_bwd_workspace_bytes(cin, c), x.device)
-    rc = lib.rs_final_conv1x1_bwd(_dev(x, "x"), _dev(w, "w"), _dev(dlogits, "dlogits"), _dev(dx, "dx"), _dev(dw, "dw"),
-                                  _dev(db, "db"), n, h, wd, cin, c, int(relu_mask), ws, _stream())
+    rc = lib.rs_final_conv1x1_bwd_dt(_dev(x, "x", x.dtype), _dev(w, "w"), _dev(dlogits, "dlogits"), _dev(dx, "dx", x.dtype),
+                                     _dev(dw, "dw"), _dev(db, "db"), _dt(x), n, h, wd, cin, c, int(relu_mask), ws, _stream())
     check(rc, "rs_final_conv1x1_bwd")
     return dx, dw, db
 

@@ -44,11 +44,22 @@ class _Conv(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def krsc(self):
-        """The weight as a contiguous [Cout,kh,kw,Cin] view (no copy while the parameter stays channels_last)."""
+    def krsc(self, dtype=torch.float32):
+        """The weight as a contiguous [Cout,kh,kw,Cin] view (no copy while the parameter stays channels_last).
+
+        ``dtype=torch.bfloat16`` returns the bf16 compute copy of the fp32 master weight (cast on the device, cached
+        until the parameter is modified -- i.e. re-cast once per optimizer step)."""
 
         w = self.weight.detach().permute(0, 2, 3, 1)
-        return w if w.is_contiguous() else w.contiguous()
+        w = w if w.is_contiguous() else w.contiguous()
+        if dtype == torch.float32:
+            return w
+        key = (self.weight.data_ptr(), self.weight._version)
+        c = getattr(self, "_bf16", None)
+        if c is None or c[0] != key:
+            c = (key, ops.cast_bf16(w))
+            self._bf16 = c
+        return c[1]
 
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(self.cin, self.cout, self.k, self.stride, self.padding)
@@ -156,13 +167,18 @@ class UNet(nn.Module):
 
     Args (reference unet.py:82): ``num_classes``; ``num_filters`` (32); ``pretrained`` -- load ImageNet encoder
     weights from ``$ROBOSAT_RESNET50_WEIGHTS`` or torch's cache (there is no network access here; if no file is found
-    the encoder keeps its random init and a warning is issued).  ``in_channels`` (extension, default 3)."""
+    the encoder keeps its random init and a warning is issued).  Extensions: ``in_channels`` (default 3, up to 4 bands)
+    and ``compute_dtype`` -- ``torch.float32`` (default: exact-fp32 MFMA kernels, the parity path) or
+    ``torch.bfloat16`` (BASELINE configs[2]: bf16 activations and MFMA operands, fp32 accumulation, fp32 master
+    weights / statistics / gradients / logits; the 7x7 stem stays fp32).  Parameters and checkpoints are fp32 either
+    way."""
 
-    def __init__(self, num_classes, num_filters=32, pretrained=True, in_channels=3):
+    def __init__(self, num_classes, num_filters=32, pretrained=True, in_channels=3, compute_dtype=torch.float32):
         super().__init__()
         assert 1 <= in_channels <= 4, "the stem kernel packs up to 4 input bands"
         nf = num_filters
         self.num_classes, self.in_channels = num_classes, in_channels
+        self.set_compute_dtype(compute_dtype)
 
         self.resnet = _ResNet50(in_channels)
 
@@ -188,6 +204,15 @@ class UNet(nn.Module):
                 self.resnet.load_state_dict(state, strict=in_channels == 3)
 
     # -- plumbing -----------------------------------------------------------------------------------------------
+
+    def set_compute_dtype(self, dtype):
+        if isinstance(dtype, str):
+            dtype = {"fp32": torch.float32, "float32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16,
+                     "bfloat16": torch.bfloat16}.get(dtype.lower())
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -233,30 +258,31 @@ class UNet(nn.Module):
         r = self.resnet
         x = x.detach().float().contiguous()
 
+        dt = self.compute_dtype  # activations after the stem pool (the stem itself always runs in fp32)
         h = ops.nchw_to_nhwc4(x)
         sc, sh = r.bn1.folded()
         h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7)
-        h = ops.maxpool2d(h, 3, 2, 1)
+        h = ops.maxpool2d(h, 3, 2, 1, out_dtype=dt)
 
         enc = []
         for layer in self._blocks():
             for blk in layer:
                 sc, sh = blk.bn1.folded()
-                o = ops.conv2d(h, blk.conv1.krsc(), scale=sc, shift=sh, relu=True)
+                o = ops.conv2d(h, blk.conv1.krsc(dt), scale=sc, shift=sh, relu=True)
                 sc, sh = blk.bn2.folded()
-                o = ops.conv2d(o, blk.conv2.krsc(), stride=blk.stride, pad=1, scale=sc, shift=sh, relu=True)
+                o = ops.conv2d(o, blk.conv2.krsc(dt), stride=blk.stride, pad=1, scale=sc, shift=sh, relu=True)
                 if blk.downsample is not None:
                     sc, sh = blk.downsample[1].folded()
-                    idt = ops.conv2d(h, blk.downsample[0].krsc(), stride=blk.stride, scale=sc, shift=sh)
+                    idt = ops.conv2d(h, blk.downsample[0].krsc(dt), stride=blk.stride, scale=sc, shift=sh)
                 else:
                     idt = h
                 sc, sh = blk.bn3.folded()
-                h = ops.conv2d(o, blk.conv3.krsc(), scale=sc, shift=sh, residual=idt, relu=True)
+                h = ops.conv2d(o, blk.conv3.krsc(dt), scale=sc, shift=sh, residual=idt, relu=True)
             enc.append(h)
         enc1, enc2, enc3, enc4 = enc
 
         def up(block, skip, prev=None):
-            return ops.conv2d(skip, block.block.block.krsc(), src2=prev, ups=1, pad=1, relu=True)
+            return ops.conv2d(skip, block.block.block.krsc(dt), src2=prev, ups=1, pad=1, relu=True)
 
         center = up(self.center, ops.maxpool2d(enc4, 2, 2, 0))
         dec0 = up(self.dec0, enc4, center)
@@ -264,7 +290,7 @@ class UNet(nn.Module):
         dec2 = up(self.dec2, enc2, dec1)
         dec3 = up(self.dec3, enc1, dec2)
         dec4 = up(self.dec4, dec3)
-        dec5 = ops.conv2d(dec4, self.dec5.block.krsc(), pad=1, relu=True)
+        dec5 = ops.conv2d(dec4, self.dec5.block.krsc(dt), pad=1, relu=True)
 
         wf = self.final.weight.detach().reshape(self.num_classes, -1)
         return ops.final_conv1x1(dec5, wf, self.final.bias.detach(), softmax=softmax)

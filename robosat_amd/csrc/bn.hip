@@ -64,26 +64,44 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y
       mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
       is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
     }
-    for (long r = r0 + rl; r < r1; r += rpb) {
-      const long o = r * C + q * 4;
-      const f32x4 v = rs_ld4(y + o);
-      if (MODE == 0) {
+    // 4 rows per trip: all loads of a trip are issued before the fp64 accumulation consumes them
+    constexpr int U = 4;
+    const long step = (long)rpb * U;
+    for (long rb = r0 + rl; rb < r1; rb += step) {
+      f32x4 v[U], g[U], z[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0[e] += (double)v[e];
-          s1[e] += (double)v[e] * (double)v[e];
+      for (int u = 0; u < U; ++u) {
+        const long r = rb + (long)u * rpb;
+        const bool in = r < r1;
+        const long o = (in ? r : rb) * C + q * 4;
+        v[u] = rs_ld4(y + o);
+        if (MODE == 1) {
+          g[u] = rs_ld4(dz + o);
+          if (zmask) z[u] = rs_ld4(zmask + o);
         }
-      } else {
-        f32x4 g = rs_ld4(dz + o);
-        if (zmask) {
-          const f32x4 z = rs_ld4(zmask + o);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+        if (!in) {
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (MODE == 1) g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0[e] += (double)g[e];
-          s1[e] += (double)g[e] * (double)((v[e] - mu[e]) * is[e]);
+      for (int u = 0; u < U; ++u) {
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += (double)v[u][e];
+            s1[e] += (double)v[u][e] * (double)v[u][e];
+          }
+        } else {
+          if (zmask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[u][e] = z[u][e] > 0.f ? g[u][e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += (double)g[u][e];
+            s1[e] += (double)g[u][e] * (double)((v[u][e] - mu[e]) * is[e]);
+          }
         }
       }
     }
@@ -113,19 +131,42 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int R, long M, int C, float eps, float momentum,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                         float* __restrict__ shift, float* __restrict__ running_mean,
-                                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s = 0, ss = 0;
-  for (int r = 0; r < R; ++r) {
-    s += part[((long)r * 2) * C + c];
-    ss += part[((long)r * 2 + 1) * C + c];
+// Stage 2: 16 channels x 16 split lanes per block; lane l sums splits l, l+16, ... in fp64, LDS tree over the lanes.
+__device__ __forceinline__ void bn_reduce_splits(const double* __restrict__ part, int R, int C, int c, int lane, bool ok,
+                                                 double& s0, double& s1) {
+  __shared__ double red[2][16][17];
+  double a = 0, b = 0;
+  if (ok) {
+    for (int r = lane; r < R; r += 16) {
+      a += part[((long)r * 2) * C + c];
+      b += part[((long)r * 2 + 1) * C + c];
+    }
   }
+  const int cl = threadIdx.x & 15;
+  red[0][lane][cl] = a;
+  red[1][lane][cl] = b;
+  __syncthreads();
+  s0 = 0;
+  s1 = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      s0 += red[0][l][cl];
+      s1 += red[1][l][cl];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(
+    const double* __restrict__ part, int R, long M, int C, float eps, float momentum, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ running_mean, float* __restrict__ running_var,
+    long long* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  double s, ss;
+  bn_reduce_splits(part, R, C, c, lane, c < C, s, ss);
+  if (c >= C || lane != 0) return;
   const double mu = s / (double)M;
   double var = ss / (double)M - mu * mu;
   if (var < 0) var = 0;
@@ -143,16 +184,14 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int R,
 }
 
 // coef[0][c] = k1 = gamma*invstd, coef[1][c] = k2 = k1*sum(g)/M, coef[2][c] = k3 = k1*invstd*sum(g*xhat)/M
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int R, long M, int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0;
-  for (int r = 0; r < R; ++r) {
-    s0 += part[((long)r * 2) * C + c];
-    s1 += part[((long)r * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int R, long M, int C,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  double s0, s1;
+  bn_reduce_splits(part, R, C, c, lane, c < C, s0, s1);
+  if (c >= C || lane != 0) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
   const double k1 = (double)gamma[c] * (double)invstd[c];
@@ -216,7 +255,7 @@ int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const
   double* part = reinterpret_cast<double*>(workspace);
   bn_partial_kernel<0, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
                                                           g.rows_per_split);
-  bn_stats_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd, scale,
+  bn_stats_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd, scale,
                                                            shift, running_mean, running_var, num_batches_tracked);
   return RS_LAUNCH_RESULT();
 }
@@ -229,7 +268,7 @@ int bn_bwd_t(const T* dz, const T* zmask, const T* y, const float* mean, const f
   float* coef = reinterpret_cast<float*>(part + (long)g.R * 2 * C);  // 3*C floats behind the partials
   bn_partial_kernel<1, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb,
                                                           g.rows_per_split);
-  bn_bwd_finalize_kernel<<<rs_cdiv(C, 256), 256, 0, s>>>(part, g.R, M, C, gamma, invstd, dgamma, dbeta, coef);
+  bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, gamma, invstd, dgamma, dbeta, coef);
   const long total4 = M * (C / 4);
   bn_bwd_apply_kernel<T><<<rs_cdiv(total4, 256), 256, 0, s>>>(dz, zmask, y, mean, coef, dy, dmasked, total4, C / 4);
   return RS_LAUNCH_RESULT();

@@ -75,3 +75,15 @@ __host__ __device__ __forceinline__ unsigned int rs_div(unsigned int n, const rs
   return (unsigned int)((((unsigned long long)n * f.mul) >> 32) + n) >> f.shift;
 #endif
 }
+
+// conv_wgrad_thin_bf16.hip (library-internal): all-taps-per-block weight gradient of the Cout = 32 3x3 layers.
+// plan: 1 if `d` qualifies (+ grid size and number of fp32 partial slices [32][9*Cin] it writes); launch: the kernel.
+__attribute__((visibility("hidden"))) int rs_wgrad_thin_plan(const rs_conv_desc* d, int* blocks, int* slices);
+__attribute__((visibility("hidden"))) int rs_wgrad_thin_launch(const rs_conv_desc* d, const void* dy, const void* src,
+                                                               float* partial, void* stream);
+
+// reduce.hip (library-internal): out[i] = sum over `splits` partial tiles of n floats (n % 4 == 0); `scratch` needs
+// rs_reduce_scratch_floats(n, splits) floats (may be NULL when that is 0).
+__attribute__((visibility("hidden"))) long rs_reduce_scratch_floats(long n, int splits);
+__attribute__((visibility("hidden"))) int rs_reduce_splits(const float* ws, float* out, long n, int splits, float* scratch,
+                                                           void* stream);

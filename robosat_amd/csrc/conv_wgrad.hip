@@ -236,18 +236,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
     }
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int splits) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(ws + i * 4);
-  for (int k = 1; k < splits; ++k) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((long)k * n4 + i) * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] += v[e];
-  }
-  *reinterpret_cast<f32x4*>(out + i * 4) = s;
-}
-
 // [Cout][kh][8][4] (packed stem gradient) -> KRSC [Cout][kh][kw][Cin]
 __global__ void unpack_stem_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, int Cout, int kh, int kw,
                                           int Cin) {
@@ -360,7 +348,8 @@ Plan plan(const rs_conv_desc* d) {
 extern "C" long rs_conv2d_wgrad_workspace_bytes(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
   const Plan pl = plan(d);
-  return (long)pl.splits * d->Cout * pl.K * (long)sizeof(float);
+  const long n = (long)d->Cout * pl.K;
+  return (pl.splits * n + rs_reduce_scratch_floats(n, pl.splits)) * (long)sizeof(float);
 }
 
 extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const float* src1, const float* src2, float* dw,
@@ -407,9 +396,10 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
     case VSTEM: conv_wgrad_f32<64, 32, 2, 1, 1><<<grid, 128, 0, s>>>(a); break;
     default: return RS_EINVAL;
   }
+  const int rc = RS_LAUNCH_RESULT();
+  if (rc) return rc;
   const long n = (long)d->Cout * pl.K;  // multiple of 4
-  reduce_splits_kernel<<<rs_cdiv(n / 4, 256), 256, 0, s>>>(a.out, dw, n / 4, pl.splits);
-  return RS_LAUNCH_RESULT();
+  return rs_reduce_splits(a.out, dw, n, pl.splits, a.out + (long)pl.splits * n, stream);
 }
 
 extern "C" int rs_unpack_stem_weight(const float* packed, float* w_krsc, int Cout, int kh, int kw, int Cin,

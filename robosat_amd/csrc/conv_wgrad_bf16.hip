@@ -282,18 +282,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
     }
 }
 
-__global__ void reduce_splits_bf_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int splits) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(ws + i * 4);
-  for (int k = 1; k < splits; ++k) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((long)k * n4 + i) * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] += v[e];
-  }
-  *reinterpret_cast<f32x4*>(out + i * 4) = s;
-}
-
 struct Plan {
   int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split;
   long K;
@@ -358,14 +346,30 @@ Plan plan(const rs_conv_desc* d) {
 
 extern "C" long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
+  int tb = 0, tslices = 0;
+  if (rs_wgrad_thin_plan(d, &tb, &tslices)) {
+    const long n = 32L * 9 * d->C1;
+    return (tslices * n + rs_reduce_scratch_floats(n, tslices)) * (long)sizeof(float);
+  }
   const Plan pl = plan(d);
-  return (long)pl.splits * d->Cout * pl.K * (long)sizeof(float);
+  const long n = (long)d->Cout * pl.K;
+  return (pl.splits * n + rs_reduce_scratch_floats(n, pl.splits)) * (long)sizeof(float);
 }
 
 extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, const rs_bf16* src1, const rs_bf16* src2,
                                     float* dw, void* workspace, rs_stream_t stream) {
   if (!valid(d) || !dy || !src1 || !dw || !workspace) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
+  {
+    int tb = 0, tslices = 0;
+    if (rs_wgrad_thin_plan(d, &tb, &tslices)) {  // Cout = 32 3x3 layers: all nine taps in one block
+      const int rc = rs_wgrad_thin_launch(d, dy, src1, reinterpret_cast<float*>(workspace), stream);
+      if (rc) return rc;
+      const long n = 32L * 9 * d->C1;
+      float* ws = reinterpret_cast<float*>(workspace);
+      return rs_reduce_splits(ws, dw, n, tslices, ws + (long)tslices * n, stream);
+    }
+  }
   const Plan pl = plan(d);
   WgradArgsB a;
   a.dy = reinterpret_cast<const bf16_t*>(dy);
@@ -405,7 +409,8 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
     case V32x32: conv_wgrad_bf16<32, 32, 1, 1><<<grid, 64, 0, s>>>(a); break;
     default: return RS_EINVAL;
   }
+  const int rc = RS_LAUNCH_RESULT();
+  if (rc) return rc;
   const long n = (long)d->Cout * pl.K;  // multiple of 4
-  reduce_splits_bf_kernel<<<rs_cdiv(n / 4, 256), 256, 0, s>>>(a.out, dw, n / 4, pl.splits);
-  return RS_LAUNCH_RESULT();
+  return rs_reduce_splits(a.out, dw, n, pl.splits, a.out + (long)pl.splits * n, stream);
 }

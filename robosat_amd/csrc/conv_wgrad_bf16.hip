@@ -6,20 +6,25 @@
 // i.e. the filter gradients autograd synthesises for every nn.Conv2d of UNet.forward when the reference calls
 // loss.backward() (robosat/tools/train.py:186).  GEMM view as conv_wgrad.hip: rows = Cout tile, cols = one filter tap
 // x a Cin tile, REDUCTION over pixels; `in` is read through the forward gather (nearest-x2 upsample, 2-source concat).
+// (The Cout = 32 3x3 layers take conv_wgrad_thin_bf16.hip instead: all nine taps per block.)
 //
 //   block  = BMo couts x BNo cins of one tap over a contiguous pixel range (split-P), walked in chunks of 64 pixels
-//            (4 MFMA k-steps); LDS double buffered, the next chunk is fetched into registers during the MFMAs.
-//   gather = one wave-sized job per chunk: threads 0..63 decode pixel m -> source pixel (mul-hi divisions) for chunk
-//            k+2 into a double-buffered 64-entry LDS table; every staging thread then needs two ds_read_b128 and a
-//            multiply-add per load instead of 8 coordinate decodes.
-//   LDS    = channel-major [channel'][64 pixels] bf16 (128-byte rows, 16-byte pieces XOR-swizzled with (row>>1)&7).
-//            Both operands arrive pixel-major from HBM ([pixel][channel]); a staging thread owns an 8-pixel x
-//            8-channel block: eight 16-byte loads (consecutive lanes = consecutive channel octets of one pixel: full
-//            lines), an 8x8 16-bit transpose in registers (32 v_perm_b32) and eight ds_write_b128.  LDS row
-//            R = ch*Q + cq holds channel 8*cq + ch (Q = channels/8): consecutive lanes write consecutive rows (conflict
-//            free); the epilogue's addressing undoes the permutation.  MFMA operands are then read exactly as in the
-//            forward kernel: one ds_read_b128 = 8 pixels of the reduction per lane.
-//   split-P: partial tiles -> workspace [split][Cout][K], summed by a streaming kernel: deterministic, no atomics.
+//            (4 MFMA k-steps); two LDS buffers, one barrier per chunk.
+//   HBM -> LDS = LDS-DMA (buffer_load_dwordx4 ... lds): both operands are pixel-major in HBM ([pixel][channel]) and are
+//            copied AS THEY LIE -- no VGPR round trip, no ds_write, no register transpose.  A wave instruction moves
+//            64 x 16 B = 1 KiB: whole [pixel] rows of the tile (256 / 128 / 64 bytes), each lane supplying its own global
+//            offset (so the gather -- tap shift, padding, upsample, concat source -- costs one table lookup + one
+//            multiply-add per lane, and out-of-image / tail rows are offset -1: the hardware writes zeros,
+//            scripts/probes/probe_glds.hip).  The LDS image is lane-linear, so the bank swizzle is applied on the SOURCE
+//            side: 64-byte piece P of LDS row R holds channel piece P ^ swz(R).
+//   gather = threads 0..63 decode pixel m -> source pixel (mul-hi divisions) for chunk k+2 into a double-buffered
+//            64-entry LDS table.
+//   MFMA operands = ds_read_b64_tr_b16 (the LDS transposing read, semantics pinned by scripts/probes/probe_tr16.hip):
+//            MFMA wants, per lane, 8 consecutive REDUCTION indices (pixels) of one channel, the tile is stored
+//            pixel-major; within a 16-lane group 4-lane sets address four pixel rows and every lane receives its
+//            channel's column.  Two reads = one 8-pixel fragment.  With the swizzle the four rows of a read sit in four
+//            different 64-byte bank quarters: conflict free.
+//   split-P: partial tiles -> workspace [split][Cout][K], summed by reduce.hip: deterministic, no atomics.
 #include "common.h"
 
 namespace {
@@ -35,52 +40,77 @@ struct WgradArgsB {
   rs_fastdiv div_howo, div_wo;
 };
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wb_make_rsrc(const void* base, long bytes) {
   const unsigned int n = bytes > 0xFFFFFFFEL ? 0xFFFFFFFEu : (unsigned int)(bytes < 0 ? 0 : bytes);
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
 }
 
-__device__ __forceinline__ u32x4 wb_buffer_load(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+// One LDS-DMA wave instruction: lane l's 16 bytes at buffer offset `voff` land at LDS byte `lds_dst` + 16*l (lds_dst
+// wave-uniform, in M0).  Inline asm on purpose: through the builtin hipcc cannot tell that the DMA's LDS destination
+// (the OTHER pipeline buffer) is disjoint from the operand reads that follow and drains the queue (s_waitcnt vmcnt(0))
+// before the first ds_read of every chunk, serialising copy and MFMA.  As asm the copy is invisible to its counters, so
+// the kernel waits itself: wb_dma_wait() ahead of the barrier that publishes the buffer.
+__device__ __forceinline__ void wb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int lds_dst, int voff) {
+  unsigned int keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_dst), "s"(r)
+      : "memory");
 }
 
-// 8 pixels x 8 channels (in[e] = 8 channels of pixel e) -> out[ch] = 8 pixels of channel ch
-__device__ __forceinline__ void wb_transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
-#pragma unroll
-  for (int w = 0; w < 4; ++w)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned int x = in[2 * j][w], y = in[2 * j + 1][w];
-      out[2 * w][j] = __builtin_amdgcn_perm(y, x, 0x05040100u);      // (lo x, lo y)
-      out[2 * w + 1][j] = __builtin_amdgcn_perm(y, x, 0x07060302u);  // (hi x, hi y)
-    }
+__device__ __forceinline__ void wb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned int wb_lds_addr(const void* p) {
+  return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
-constexpr int PK = 64;    // pixels per chunk
-constexpr int ROWB = 128;  // bytes per LDS row
+__device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+  s16x8 v;
+  v[0] = lo[0];
+  v[1] = lo[1];
+  v[2] = lo[2];
+  v[3] = lo[3];
+  v[4] = hi[0];
+  v[5] = hi[1];
+  v[6] = hi[2];
+  v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int PK = 64;  // pixels per chunk
 
 template <int BMo, int BNo, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const WgradArgsB p) {
-  constexpr int NT = 64 * WGM * WGN;
+  constexpr int NW = WGM * WGN;          // waves
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int AQ = BMo / 8, BQ = BNo / 8;            // channel octets per tile
-  constexpr int ASL = BMo < 64 ? 64 : BMo;             // staging slots of the A tile (one 8x8 block each), wave aligned
-  constexpr int BSL = BNo < 64 ? 64 : BNo;
-  constexpr int NJ = (ASL + BSL + NT - 1) / NT;        // staging blocks per thread
-  constexpr int BUF = (BMo + BNo) * ROWB;
-  static_assert(TM >= 1 && TN >= 1 && (ASL % 64) == 0 && (BSL % 64) == 0, "bad tile");
-  static_assert(NT >= 64 && (ASL % NT == 0 || NT % ASL == 0 || NJ == 1), "slot layout");
+  constexpr int ROWA = BMo * 2, ROWB_ = BNo * 2;        // bytes per LDS row (one pixel)
+  constexpr int WA = BMo / 32, WB = BNo / 32;           // 64-byte pieces per row
+  constexpr int RPBA = WA >= 4 ? 1 : 4 / WA, RPBB = WB >= 4 ? 1 : 4 / WB;  // rows per 256-byte bank row
+  constexpr int RIA = 1024 / ROWA, RIB = 1024 / ROWB_;  // rows per DMA instruction
+  constexpr int IA = PK / RIA, IB = PK / RIB;           // DMA instructions per chunk
+  constexpr int NI = (IA + IB) / NW;                    // per wave
+  constexpr int ABYTES = PK * ROWA, BBYTES = PK * ROWB_;
+  constexpr int BUF = ABYTES + BBYTES;
+  static_assert(TM >= 1 && TN >= 1 && (IA % NW) == 0 && (IB % NW) == 0, "bad tile");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 2 * PK * 4];
   int* tabs = reinterpret_cast<int*>(smem + 2 * BUF);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
   int bid = rs_xcd_remap(blockIdx.x, gridDim.x);
@@ -135,64 +165,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
     }
   };
 
-  // staging roles: slot = tid + NT*j; slots [0, ASL) stage dy blocks, [ASL, ASL+BSL) input blocks (wave uniform)
-  u32x4 rg[NJ][8];
-  int lchunk = chunk0;  // next chunk to fetch
+  // ---- DMA roles: instruction ii = wave + NW*j (j < NI); ii < IA copies dy rows, else input rows.  Lane constants:
+  //      row within the instruction, 16-byte position, and the (swizzled) channel piece it fetches.
+  const int ra_a = lane / (ROWA / 16), pp_a = lane % (ROWA / 16);
+  const int ra_b = lane / (ROWB_ / 16), pp_b = lane % (ROWB_ / 16);
+  const int swa = WA > 1 ? ((ra_a / RPBA) & (WA - 1)) : 0;  // swz(R) for R = RIA*jj + ra_a (RIA is a multiple of 4)
+  const int swb = WB > 1 ? ((ra_b / RPBB) & (WB - 1)) : 0;
+  const int gpa = (((pp_a >> 2) ^ swa) << 2) | (pp_a & 3);  // global 16-byte piece (8 channels) of the row
+  const int gpb = (((pp_b >> 2) ^ swb) << 2) | (pp_b & 3);
+  const int cola = (co0 + gpa * 8) * 2;                     // byte offset of the piece inside a dy row
+  const int colb = (cs + gpb * 8) * 2;
+  const int cout2 = p.Cout * 2, cs2 = Cs * 2;
 
-  auto load_block = [&](int j, int e0, int e1, int which) __attribute__((always_inline)) {
-    const int slot = tid + NT * j;
-    if (slot < ASL) {
-      const int cq = slot % AQ, pg = slot / AQ;
-      const bool act = slot < BMo;
-      const int mb = lchunk * PK + pg * 8;
+  const unsigned int lds0 = __builtin_amdgcn_readfirstlane(wb_lds_addr(smem));
+  auto issue_dma = [&](int chunk, int buf, int which) __attribute__((always_inline)) {
+    const unsigned int L = lds0 + buf * BUF;
+    int pix[NI];
 #pragma unroll
-      for (int e = e0; e < e1; ++e) {
-        const int m = mb + e;
-        const int off = (act && m < p.M) ? ((m - m_first) * p.Cout + co0 + cq * 8) * 2 : -1;
-        rg[j][e] = wb_buffer_load(rsrc_dy, off);
-      }
-    } else if (slot < ASL + BSL) {
-      const int s2 = slot - ASL;
-      const int cq = s2 % BQ, pg = s2 / BQ;
-      const bool act = s2 < BNo;
-      const int cb = (cs + cq * 8) * 2, cs2 = Cs * 2;
-      const i32x4 t0 = *reinterpret_cast<const i32x4*>(&tabs[which * PK + (pg & 7) * 8]);
-      const i32x4 t1 = *reinterpret_cast<const i32x4*>(&tabs[which * PK + (pg & 7) * 8 + 4]);
+    for (int j = 0; j < NI; ++j)  // table lookups of all of this wave's input-row instructions first (one LDS round trip)
+      pix[j] = (NW * j >= IA) ? tabs[which * PK + RIB * (wave + NW * j - IA) + ra_b] : 0;
 #pragma unroll
-      for (int e = e0; e < e1; ++e) {
-        const int pix = e < 4 ? t0[e & 3] : t1[e & 3];
-        const int off = (act && pix >= 0) ? pix * cs2 + cb : -1;
-        rg[j][e] = wb_buffer_load(rsrc_x, off);
-      }
-    }
-  };
-
-  auto store_block = [&](int j, int buf) __attribute__((always_inline)) {
-    unsigned char* L = smem + buf * BUF;
-    const int slot = tid + NT * j;
-    int rbase, cq, pg, Q;
-    bool act;
-    if (slot < ASL) {
-      cq = slot % AQ;
-      pg = slot / AQ;
-      Q = AQ;
-      rbase = 0;
-      act = slot < BMo;
-    } else {
-      const int s2 = slot - ASL;
-      cq = s2 % BQ;
-      pg = s2 / BQ;
-      Q = BQ;
-      rbase = BMo;
-      act = s2 < BNo && slot < ASL + BSL;
-    }
-    if (act) {
-      u32x4 t[8];
-      wb_transpose8x8(rg[j], t);
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        const int R = ch * Q + cq;  // tile-local LDS row of channel 8*cq + ch
-        *reinterpret_cast<u32x4*>(L + (rbase + R) * ROWB + ((pg ^ ((R >> 1) & 7)) * 16)) = t[ch];
+    for (int j = 0; j < NI; ++j) {
+      const int ii = wave + NW * j;  // wave-uniform; IA is a multiple of NW, so the role depends on j alone
+      if (NW * j < IA) {
+        const int R = RIA * ii + ra_a;
+        const int m = chunk * PK + R;
+        wb_dma16(rsrc_dy, L + ii * 1024, (m - m_first) * cout2 + cola);  // rows >= M lie past the descriptor: zeros
+      } else {
+        wb_dma16(rsrc_x, L + ABYTES + (ii - IA) * 1024, pix[j] >= 0 ? pix[j] * cs2 + colb : -1);
       }
     }
   };
@@ -205,78 +205,63 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int frow = lane & 31;
-  const int fl = (frow >> 1) & 7;
-  int foff[4];
+  // ---- operand addressing for ds_read_b64_tr_b16: lane = 16*g + q; group g covers channels 16*(g&1)..+15 of a 32-wide
+  //      piece and LDS rows R = 16s + 8*(g>>1) + 4t + (q>>2); lane q addresses row (q>>2), channels 4*(q&3)..+3.
+  const int g = lane >> 4, q = lane & 15, jr = q >> 2;
+  const int chb = (16 * (g & 1) + 4 * (q & 3)) * 2;
+  const int rsw_a = WA > 1 ? ((jr / RPBA) & (WA - 1)) : 0;  // swz(R): R = 4*(...) + jr
+  const int rsw_b = WB > 1 ? ((jr / RPBB) & (WB - 1)) : 0;
+  int aoff[TM], boff[TN];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + (lane >> 5)) ^ fl) * 16;
-  const int abase = (wm * WM + frow) * ROWB;
-  const int bbase = (BMo + wn * WN + frow) * ROWB;
-
-  auto read_frag = [&](const unsigned char* L, int s, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) __attribute__((always_inline)) {
+  for (int tm = 0; tm < TM; ++tm) aoff[tm] = (8 * (g >> 1) + jr) * ROWA + (((wm * TM + tm) ^ rsw_a) * 64) + chb;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(L + abase + 32 * tm * ROWB + foff[s]);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const bf16x8*>(L + bbase + 32 * tn * ROWB + foff[s]);
-  };
-  auto mma_frag = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-  };
+  for (int tn = 0; tn < TN; ++tn) boff[tn] = ABYTES + (8 * (g >> 1) + jr) * ROWB_ + (((wn * TN + tn) ^ rsw_b) * 64) + chb;
 
   if (chunk0 < chunk1) {
     fill_table(chunk0, 0);
     fill_table(chunk0 + 1, 1);
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) load_block(j, 0, 8, 0);
-    ++lchunk;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) store_block(j, 0);
+    issue_dma(chunk0, 0, 0);
+    wb_dma_wait();
     __syncthreads();
     for (int c = chunk0; c < chunk1; ++c) {
       const int it = c - chunk0;
       const unsigned char* L = smem + (it & 1) * BUF;
-      const int tw = (it + 1) & 1;  // table of chunk c+1
-      bf16x8 fa[2][TM], fb[2][TN];
-      read_frag(L, 0, fa[0], fb[0]);
+      // chunk c+1 -> the other buffer (its last readers passed the barrier that ended iteration it-1); past the last
+      // chunk this fetches zeros / the next split's pixels, harmlessly
+      issue_dma(c + 1, (it + 1) & 1, (it + 1) & 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (s < 3) {
-          read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-          // loads of chunk c+1: thirds (3 + 3 + 2 pixels of every block); past the last chunk they read zeros / the
-          // next split's pixels, harmlessly
+        bf16x8 fa[TM], fb[TN];
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) load_block(j, s * 3, s == 2 ? 8 : s * 3 + 3, tw);
-        }
-        mma_frag(fa[s & 1], fb[s & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int tm = 0; tm < TM; ++tm)
+          fa[tm] = wb_tr_read8(L + aoff[tm] + (16 * s) * ROWA, L + aoff[tm] + (16 * s + 4) * ROWA);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          fb[tn] = wb_tr_read8(L + boff[tn] + (16 * s) * ROWB_, L + boff[tn] + (16 * s + 4) * ROWB_);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
       }
-      ++lchunk;
       fill_table(c + 2, it & 1);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) store_block(j, (it + 1) & 1);
+      wb_dma_wait();  // this wave's share of chunk c+1 has landed; the barrier publishes everybody's
       __syncthreads();
     }
   }
 
-  // D[i][j]: i = (r&3) + 8*(r>>2) + 4*(lane>>5) is an LDS row of the dy tile, j = lane&31 one of the input tile;
-  // LDS row R <-> channel 8*(R % Q) + R / Q
+  // D[i][j]: i = cout (tile-local) = (r&3) + 8*(r>>2) + 4*(lane>>5), j = cin (tile-local) = lane&31
   float* out = p.out + (long)split * p.Cout * p.K;
   const int kbase = tap * (p.C1 + p.C2) + ci0;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int Rb = wn * WN + tn * 32 + (lane & 31);
-      const int kk = kbase + 8 * (Rb % BQ) + Rb / BQ;
+      const int kk = kbase + wn * WN + tn * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int Ra = wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int co = co0 + 8 * (Ra % AQ) + Ra / AQ;
+        const int co = co0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         out[(long)co * p.K + kk] = acc[tm][tn][r];
       }
     }

@@ -12,13 +12,15 @@
 //            (taps x BM ints, -1 = padding / zero-insert hole / tail row); per chunk a thread fetches its rows'
 //            entries with one ds_read and forms byte offsets with a multiply-add: the fp32 kernel's per-chunk
 //            coordinate arithmetic (~10 VALU per load) would no longer hide under 8x shorter MFMA phases.
-//            Loads are buffer_load_dwordx4 through SRSRC descriptors (offset -1 => hardware returns zeros).
+//   HBM->LDS = LDS-DMA (buffer_load_dwordx4 ... lds through SRSRC descriptors; offset -1 => the hardware writes zeros):
+//            no VGPR round trip and no ds_write -- at bf16 MFMA rates the 32 KB per chunk a register-staged tile pushes
+//            through ds_write_b128 (~79 B/clk/CU) costs as many LDS cycles as the MFMAs of the chunk take.  One wave
+//            instruction = 1 KiB = 8 (16) whole rows, every lane with its own source offset (the gather).
 //   LDS     = UNPADDED rows of KC bf16, 16-byte pieces XOR-swizzled: piece c of row r is stored at position
-//            c ^ f(r), f(r) = (r>>1)&7 for 128-byte rows, (r>>2)&3 for 64-byte rows.  Staging writes are lane-linear
-//            (thread t -> byte 16*t of the pass: conflict-free ds_write_b128, and the image a wave writes is the one
-//            a `buffer_load ... lds` DMA would produce, so the staging primitive can be swapped without touching the
-//            readers); MFMA fragment reads (ds_read_b128: lane l reads row l&31, piece 2s + (l>>5)) hit 16 distinct
-//            16-byte slots in each of the instruction's four 16-lane groups.
+//            c ^ f(r), f(r) = (r>>1)&7 for 128-byte rows, (r>>2)&3 for 64-byte rows.  The DMA image is lane-linear
+//            (lane l -> byte 16*l), so the swizzle is applied on the source side: lane l fetches piece (l % CPR) ^ f(row).
+//            MFMA fragment reads (ds_read_b128: lane l reads row l&31, piece 2s + (l>>5)) hit 16 distinct 16-byte slots
+//            in each of the instruction's four 16-lane groups.
 //   MFMA    = 32x32x16: lane l feeds A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31]: one b128
 //            per 32-row sub-tile per k-step.  The weight fragment is the A operand: D[i = cout][j = pixel].
 //   store   = accumulators -> LDS [pixel][cout] fp32 -> row-wise: 8 couts per thread, fp32 scale/shift, bf16 residual /
@@ -49,8 +51,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_make_rsrc(const void* base,
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
 }
 
-__device__ __forceinline__ bf16x8 rb_buffer_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+// One LDS-DMA wave instruction (buffer_load_dwordx4 ... lds): lane l's 16 bytes at buffer offset `voff` land at LDS byte
+// `lds_dst` + 16*l (lds_dst wave-uniform, in M0); offset -1 is out of range => zeros (scripts/probes/probe_glds.hip).
+// Inline asm on purpose: through the builtin hipcc cannot tell that the DMA's destination (the OTHER pipeline buffer) is
+// disjoint from the fragment reads that follow and drains the queue (s_waitcnt vmcnt(0)) before the first ds_read of
+// every chunk.  As asm the copy is invisible to its counters, so the kernel waits itself (rb_dma_wait) ahead of the
+// barrier that publishes the buffer.
+__device__ __forceinline__ void rb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int lds_dst, int voff) {
+  unsigned int keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_dst), "s"(r)
+      : "memory");
+}
+
+__device__ __forceinline__ void rb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
+  return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
 constexpr int kMaxTaps = 9;
@@ -59,37 +82,34 @@ template <int BM, int BN, int WGM, int WGN, int KC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(KC == 64 || KC == 32, "K-chunk is 64 or 32 channels");
+  constexpr int NW = 4;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int ROWB = KC * 2;        // bytes per LDS row
   constexpr int CPR = KC / 8;         // 16-byte pieces per row
-  constexpr int RPP = 256 / CPR;      // rows staged per pass of the block
-  constexpr int AR = (BM + RPP - 1) / RPP, BR = (BN + RPP - 1) / RPP;  // loads per thread per chunk
+  constexpr int RI = 64 / CPR;        // rows per LDS-DMA wave instruction (1 KiB)
+  constexpr int IA = BM / RI, IB = BN / RI;  // DMA instructions per chunk: pixel rows / weight rows
+  constexpr int NI = (IA + IB + NW - 1) / NW;  // per wave
   constexpr int KS = KC / 16;         // MFMA k-steps per chunk
   constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline buffer
   constexpr int LDO = BN + 4;         // epilogue staging row (floats)
   constexpr int PIPE = 2 * BUF, STAGE = BM * LDO * 4;
   constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
-  constexpr int TABN = (kMaxTaps + 1) * RPP * AR;  // (tap, row) -> source pixel
+  constexpr int TABN = (kMaxTaps + 1) * BM;  // (tap, row) -> source pixel
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
-  static_assert(BM % RPP == 0 || BM < RPP, "A tile rows vs staging pass");
+  static_assert((IA % NW) == 0 && IB >= 1 && (BM % RI) == 0 && (BN % RI) == 0, "DMA instruction split");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAINB + TABN * 4];
   int* tab = reinterpret_cast<int*>(smem + MAINB);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
   const int bid = rs_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
-
-  const int prow = tid / CPR;  // row within a staging pass
-  const int ppos = tid % CPR;  // LDS piece position written by this thread
-  const int fsw = KC == 64 ? ((prow >> 1) & 7) : ((prow >> 2) & 3);
-  const int pc = ppos ^ fsw;   // global piece (8 channels) this thread fetches
 
   const int HoWo = p.Ho * p.Wo;
   const int nfirst = m0 / HoWo;
@@ -112,79 +132,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
       const bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv) && (((iy | ix) & upar) == 0);
       if (ok) pix = ((n - nfirst) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
     }
-    tab[(tap * RPP + (row % RPP)) * AR + row / RPP] = pix;
+    tab[e] = pix;
   }
-  for (int e = tid; e < RPP * AR; e += 256) tab[p.ntaps * RPP * AR + e] = -1;  // the prefetch past the last chunk
+  for (int e = tid; e < BM; e += 256) tab[p.ntaps * BM + e] = -1;  // the prefetch past the last chunk
 
   const long img1 = (long)p.Hs * p.Ws * p.C1;
   const long img2 = (long)p.Hs * p.Ws * p.C2;
   const __amdgpu_buffer_rsrc_t rsrc1 = rb_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * 2);
   const __amdgpu_buffer_rsrc_t rsrc2 = rb_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * 2);
   const __amdgpu_buffer_rsrc_t rsrcw = rb_make_rsrc(p.wgt, (long)p.Cout * p.Kw * 2);
-  int woff[BR];
+
+  // ---- LDS-DMA roles.  Instruction ii = wave + 4j copies 1 KiB = RI whole rows: ii < IA pixel rows RI*ii.., else
+  //      weight rows RI*(ii-IA)...  Lane l: row ra = l / CPR of the instruction, 16-byte position pp = l % CPR, which
+  //      must receive channel piece pp ^ f(row) (the swizzle lives on the SOURCE address; the LDS image is lane-linear).
+  const int ra = lane / CPR, pp = lane % CPR;
+  const int fsw = KC == 64 ? ((4 * (wave & 1) + (ra >> 1)) & 7) : ((ra >> 2) & 3);  // f(RI*ii + ra): ii = wave (mod 2)
+  const int gp = pp ^ fsw;
+  const unsigned int lds0 = __builtin_amdgcn_readfirstlane(rb_lds_addr(smem));
+  int wrow[NI];  // byte offset of this lane's piece in weight row (n0 + RI*jj + ra), chunk 0
 #pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int row = prow + RPP * i;
-    woff[i] = (row < BN) ? ((n0 + row) * p.Kw + pc * 8) * 2 : -1;
-  }
+  for (int j = 0; j < NI; ++j) wrow[j] = ((n0 + RI * (wave + NW * j - IA) + ra) * p.Kw + gp * 8) * 2;
   __syncthreads();
 
-  bf16x8 ra[AR], rb[BR];
   int lt = 0, lc = 0, lk = 0;  // next chunk to fetch: tap / channel chunk within the tap / linear index
-
-  // issues part `part` (of NP) of the loads of the NEXT chunk
-  auto load_part = [&](int part, int np) __attribute__((always_inline)) {
+  auto issue_dma = [&](int buf) __attribute__((always_inline)) {
+    const unsigned int L = lds0 + buf * BUF;
     const int c0 = lc * KC;
     const bool first = c0 < p.C1;
     const __amdgpu_buffer_rsrc_t rs = first ? rsrc1 : rsrc2;
     const int cs2 = (first ? p.C1 : p.C2) * 2;
-    const int cb = ((first ? c0 : c0 - p.C1) + pc * 8) * 2;
-    int pix[AR];
-    if constexpr (AR == 4) {
-      const i32x4 v = *reinterpret_cast<const i32x4*>(&tab[(lt * RPP + prow) * AR]);
-      pix[0] = v[0];
-      pix[1] = v[1];
-      pix[2] = v[2];
-      pix[3] = v[3];
-    } else if constexpr (AR == 2) {
-      const i32x2 v = *reinterpret_cast<const i32x2*>(&tab[(lt * RPP + prow) * AR]);
-      pix[0] = v[0];
-      pix[1] = v[1];
-    } else {
+    const int cb = ((first ? c0 : c0 - p.C1) + gp * 8) * 2;
+    int pix[NI];
 #pragma unroll
-      for (int i = 0; i < AR; ++i) pix[i] = tab[(lt * RPP + prow) * AR + i];
-    }
+    for (int j = 0; j < NI; ++j) pix[j] = (NW * j < IA) ? tab[lt * BM + RI * (wave + NW * j) + ra] : 0;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      if ((i % np) != part) continue;
-      const bool ok = pix[i] >= 0 && (BM >= RPP || prow < BM);
-      const int off = ok ? pix[i] * cs2 + cb : -1;
-      ra[i] = rb_buffer_load8(rs, off);
+    for (int j = 0; j < NI; ++j) {
+      const int ii = wave + NW * j;  // wave-uniform; IA % 4 == 0, so the role depends on j alone
+      if (NW * j < IA) {
+        rb_dma16(rs, L + ii * 1024, pix[j] >= 0 ? pix[j] * cs2 + cb : -1);
+      } else if ((IB % NW) == 0 || ii < IA + IB) {
+        rb_dma16(rsrcw, L + ii * 1024, wrow[j] + lk * ROWB);
+      }
     }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      if (((i + 1) % np) != part) continue;
-      rb[i] = rb_buffer_load8(rsrcw, woff[i] < 0 ? -1 : woff[i] + lk * ROWB);
-    }
-  };
-
-  auto advance = [&]() __attribute__((always_inline)) {
-    ++lk;
+    ++lk;  // advance to the following chunk
     ++lc;
     const int w1 = (lc == p.cpt) ? 1 : 0;
     lc = w1 ? 0 : lc;
     lt += w1;
-  };
-
-  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* L = smem + buf * BUF;
-#pragma unroll
-    for (int i = 0; i < AR; ++i)
-      if (BM >= RPP || prow < BM) *reinterpret_cast<bf16x8*>(L + (prow + RPP * i) * ROWB + ppos * 16) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BR; ++i)
-      if (BN >= RPP * (i + 1) || prow + RPP * i < BN)
-        *reinterpret_cast<bf16x8*>(L + (BM + prow + RPP * i) * ROWB + ppos * 16) = rb[i];
   };
 
   f32x16 acc[TN][TM];  // [cout sub-tile][pixel sub-tile]; D rows = couts, D cols = pixels
@@ -218,31 +212,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
   };
 
-  // ---- main loop: per k-step { LDS fragments of step s+1 | a share of chunk k+1's global loads | MFMAs of step s };
-  //      then registers -> LDS (other buffer) | barrier.  The last k-step carries no global load (latency cover).
-  constexpr int NP = KS > 1 ? KS - 1 : 1;
-#pragma unroll
-  for (int part = 0; part < NP; ++part) load_part(part, NP);
-  advance();
-  store_chunk(0);
+  // ---- main loop: chunk k+1 streams HBM -> LDS (other buffer) by DMA while the MFMAs of chunk k run; one barrier per
+  //      chunk, each wave having waited for its own DMA instructions first.
+  issue_dma(0);
+  rb_dma_wait();
   __syncthreads();
   for (int kc = 0; kc < p.nk; ++kc) {
     const unsigned char* L = smem + (kc & 1) * BUF;
+    issue_dma((kc + 1) & 1);  // past the last chunk: tap = ntaps reads the -1 guard rows (zeros), weights out of range
     bf16x8 fa[2][TM], fb[2][TN];
     read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) {
-        read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-        load_part(s, NP);
-      } else if (KS == 1) {
-        load_part(0, 1);
-      }
+      if (s + 1 < KS) read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
       mma_frag(fa[s & 1], fb[s & 1]);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    advance();
-    store_chunk((kc + 1) & 1);
+    rb_dma_wait();
     __syncthreads();
   }
 

@@ -87,3 +87,11 @@ __attribute__((visibility("hidden"))) int rs_wgrad_thin_launch(const rs_conv_des
 __attribute__((visibility("hidden"))) long rs_reduce_scratch_floats(long n, int splits);
 __attribute__((visibility("hidden"))) int rs_reduce_splits(const float* ws, float* out, long n, int splits, float* scratch,
                                                            void* stream);
+
+// conv_igemm_dma.hip (library-internal): the LDS-DMA implicit-GEMM kernel instantiated for fp32 (non-stem convolutions of
+// rs_conv2d_fwd) and the tile it picks (index order: 128x128, 128x64, 128x32, 64x64).
+__attribute__((visibility("hidden"))) int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2,
+                                                          const float* weight, const float* scale, const float* shift,
+                                                          const float* residual, const float* relu_mask, float* out,
+                                                          void* stream);
+__attribute__((visibility("hidden"))) int rs_conv_dma_tile(const rs_conv_desc* d);

@@ -332,7 +332,10 @@ int pick_tile(const rs_conv_desc* d) {
 
 }  // namespace
 
-extern "C" int rs_conv2d_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+extern "C" int rs_conv2d_tile(const rs_conv_desc* d) {
+  if (!valid(d)) return RS_EINVAL;
+  return d->stem ? (int)TSTEM : rs_conv_dma_tile(d);  // same index order as kTileNames
+}
 
 extern "C" const char* rs_conv2d_tile_name(int tile) { return (tile >= 0 && tile < NTILES) ? kTileNames[tile] : ""; }
 
@@ -341,6 +344,9 @@ extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const flo
                              float* out, rs_stream_t stream) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
+  // every non-stem convolution: the LDS-DMA kernel (conv_igemm_dma.hip, fp32 instantiation); the kernel below keeps the
+  // 7x7 stem, whose rows (8 taps x 4 channels) need per-tap bounds checks inside a 128-byte row
+  if (!d->stem) return rs_conv_dma_f32(d, src1, src2, weight, scale, shift, residual, relu_mask, out, stream);
   ConvArgs a;
   a.src1 = src1;
   a.src2 = src2;
@@ -384,14 +390,8 @@ extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const flo
   a.ntiles = d->Cout / kTileBN[tile];
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles;
   hipStream_t s = (hipStream_t)stream;
-  switch (tile) {
-    case T128x128: conv_igemm_f32<128, 128, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case T128x64: conv_igemm_f32<128, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case T128x32: conv_igemm_f32<128, 32, 4, 1, 0><<<grid, 256, 0, s>>>(a); break;
-    case T64x64: conv_igemm_f32<64, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case TSTEM: conv_igemm_f32<128, 64, 2, 2, 1><<<grid, 256, 0, s>>>(a); break;
-    default: return RS_EINVAL;
-  }
+  if (tile != TSTEM) return RS_EINVAL;
+  conv_igemm_f32<128, 64, 2, 2, 1><<<grid, 256, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }
 

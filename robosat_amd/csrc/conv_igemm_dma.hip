@@ -1,5 +1,10 @@
-// Implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulation; dense chip
-// peak ~2.5 PFLOP/s): the bf16 training path of BASELINE configs[2] (`rs train ... bf16`).
+// Implicit-GEMM convolution for gfx950 with LDS-DMA staging, templated on the activation type:
+//   bf16_t : v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulation; dense chip peak ~2.5 PFLOP/s): the bf16 training
+//            path of BASELINE configs[2] (`rs train ... bf16`);
+//   float  : v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s): every non-stem convolution of the fp32 parity path
+//            (rs_conv2d_fwd; the 7x7 stem keeps the register-staged kernel of conv_igemm.hip).
+// A K-chunk is always a 128-byte row per pixel (64 bf16 / 32 fp32 channels; 64-byte rows for the 32-channel bf16 layers),
+// so both types share the LDS image, the swizzle and the fragment addressing; only the MFMA issue differs.
 //
 // Same operator as conv_igemm.hip (every nn.Conv2d / F.interpolate / torch.cat of UNet.forward, reference
 // robosat/unet.py:122-141, and through `ups = 2` every data-gradient convolution of loss.backward(),
@@ -29,22 +34,64 @@
 
 namespace {
 
-struct ConvArgsB {
-  const bf16_t* src1;
-  const bf16_t* src2;
-  const bf16_t* wgt;
+template <typename T>
+struct ConvArgsT {
+  const T* src1;
+  const T* src2;
+  const T* wgt;
   const float* scale;
   const float* shift;
-  const bf16_t* res;
-  const bf16_t* mask;
-  bf16_t* out;
+  const T* res;
+  const T* mask;
+  T* out;
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles, ntaps;
 };
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16 bytes of activations <-> fp32 lanes
+template <typename T>
+struct Piece;
+template <>
+struct Piece<float> {
+  __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = v[e];
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <>
+struct Piece<bf16_t> {
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+// one MFMA k-step on 16-byte operand fragments: D[i][j] += sum_k A[i][k] B[k][j]
+__device__ __forceinline__ void mma16(f32x16& acc, const u32x4 a, const u32x4 b, bf16_t) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x16& acc, const u32x4 a, const u32x4 b, float) {
+  const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_make_rsrc(const void* base, long bytes) {
   const unsigned int n = bytes > 0xFFFFFFFEL ? 0xFFFFFFFEu : (unsigned int)(bytes < 0 ? 0 : bytes);
@@ -78,19 +125,21 @@ __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
 
 constexpr int kMaxTaps = 9;
 
-template <int BM, int BN, int WGM, int WGN, int KC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   static_assert(WGM * WGN == 4, "4 waves per block");
-  static_assert(KC == 64 || KC == 32, "K-chunk is 64 or 32 channels");
+  static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
   constexpr int NW = 4;
+  constexpr int ES = (int)sizeof(T);  // element size
+  constexpr int EPP = 16 / ES;        // elements per 16-byte piece
+  constexpr int KC = ROWB / ES;       // channels per chunk
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int ROWB = KC * 2;        // bytes per LDS row
-  constexpr int CPR = KC / 8;         // 16-byte pieces per row
+  constexpr int CPR = ROWB / 16;      // 16-byte pieces per row
   constexpr int RI = 64 / CPR;        // rows per LDS-DMA wave instruction (1 KiB)
   constexpr int IA = BM / RI, IB = BN / RI;  // DMA instructions per chunk: pixel rows / weight rows
   constexpr int NI = (IA + IB + NW - 1) / NW;  // per wave
-  constexpr int KS = KC / 16;         // MFMA k-steps per chunk
+  constexpr int KS = CPR / 2;         // k-steps per chunk (two pieces each: lanes 0-31 / 32-63)
   constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline buffer
   constexpr int LDO = BN + 4;         // epilogue staging row (floats)
   constexpr int PIPE = 2 * BUF, STAGE = BM * LDO * 4;
@@ -138,20 +187,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
 
   const long img1 = (long)p.Hs * p.Ws * p.C1;
   const long img2 = (long)p.Hs * p.Ws * p.C2;
-  const __amdgpu_buffer_rsrc_t rsrc1 = rb_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * 2);
-  const __amdgpu_buffer_rsrc_t rsrc2 = rb_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * 2);
-  const __amdgpu_buffer_rsrc_t rsrcw = rb_make_rsrc(p.wgt, (long)p.Cout * p.Kw * 2);
+  const __amdgpu_buffer_rsrc_t rsrc1 = rb_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * ES);
+  const __amdgpu_buffer_rsrc_t rsrc2 = rb_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * ES);
+  const __amdgpu_buffer_rsrc_t rsrcw = rb_make_rsrc(p.wgt, (long)p.Cout * p.Kw * ES);
 
   // ---- LDS-DMA roles.  Instruction ii = wave + 4j copies 1 KiB = RI whole rows: ii < IA pixel rows RI*ii.., else
   //      weight rows RI*(ii-IA)...  Lane l: row ra = l / CPR of the instruction, 16-byte position pp = l % CPR, which
   //      must receive channel piece pp ^ f(row) (the swizzle lives on the SOURCE address; the LDS image is lane-linear).
   const int ra = lane / CPR, pp = lane % CPR;
-  const int fsw = KC == 64 ? ((4 * (wave & 1) + (ra >> 1)) & 7) : ((ra >> 2) & 3);  // f(RI*ii + ra): ii = wave (mod 2)
+  const int fsw = ROWB == 128 ? ((4 * (wave & 1) + (ra >> 1)) & 7) : ((ra >> 2) & 3);  // f(RI*ii + ra): ii = wave (mod 2)
   const int gp = pp ^ fsw;
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane(rb_lds_addr(smem));
   int wrow[NI];  // byte offset of this lane's piece in weight row (n0 + RI*jj + ra), chunk 0
 #pragma unroll
-  for (int j = 0; j < NI; ++j) wrow[j] = ((n0 + RI * (wave + NW * j - IA) + ra) * p.Kw + gp * 8) * 2;
+  for (int j = 0; j < NI; ++j) wrow[j] = ((n0 + RI * (wave + NW * j - IA) + ra) * p.Kw + gp * EPP) * ES;
   __syncthreads();
 
   int lt = 0, lc = 0, lk = 0;  // next chunk to fetch: tap / channel chunk within the tap / linear index
@@ -160,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
     const int c0 = lc * KC;
     const bool first = c0 < p.C1;
     const __amdgpu_buffer_rsrc_t rs = first ? rsrc1 : rsrc2;
-    const int cs2 = (first ? p.C1 : p.C2) * 2;
-    const int cb = ((first ? c0 : c0 - p.C1) + gp * 8) * 2;
+    const int cs2 = (first ? p.C1 : p.C2) * ES;
+    const int cb = ((first ? c0 : c0 - p.C1) + gp * EPP) * ES;
     int pix[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) pix[j] = (NW * j < IA) ? tab[lt * BM + RI * (wave + NW * j) + ra] : 0;
@@ -191,25 +240,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
 
   // fragment addressing: row (lane&31) of a 32-row sub-tile, piece 2s + (lane>>5), swizzled
   const int frow = lane & 31;
-  const int fl = KC == 64 ? ((frow >> 1) & 7) : ((frow >> 2) & 3);
+  const int fl = ROWB == 128 ? ((frow >> 1) & 7) : ((frow >> 2) & 3);
   int foff[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) foff[s] = ((2 * s + (lane >> 5)) ^ fl) * 16;
   const int abase = (wm * WM + frow) * ROWB;
   const int bbase = (BM + wn * WN + frow) * ROWB;
 
-  auto read_frag = [&](const unsigned char* L, int s, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) __attribute__((always_inline)) {
+  auto read_frag = [&](const unsigned char* L, int s, u32x4 (&a)[TM], u32x4 (&b)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(L + abase + 32 * tm * ROWB + foff[s]);
+    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const u32x4*>(L + abase + 32 * tm * ROWB + foff[s]);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const bf16x8*>(L + bbase + 32 * tn * ROWB + foff[s]);
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(L + bbase + 32 * tn * ROWB + foff[s]);
   };
-  auto mma_frag = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) __attribute__((always_inline)) {
+  auto mma_frag = [&](const u32x4 (&a)[TM], const u32x4 (&b)[TN]) __attribute__((always_inline)) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
+      for (int tn = 0; tn < TN; ++tn) mma16(acc[tn][tm], b[tn], a[tm], T());
   };
 
   // ---- main loop: chunk k+1 streams HBM -> LDS (other buffer) by DMA while the MFMAs of chunk k run; one barrier per
@@ -220,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
   for (int kc = 0; kc < p.nk; ++kc) {
     const unsigned char* L = smem + (kc & 1) * BUF;
     issue_dma((kc + 1) & 1);  // past the last chunk: tap = ntaps reads the -1 guard rows (zeros), weights out of range
-    bf16x8 fa[2][TM], fb[2][TN];
+    u32x4 fa[2][TM], fb[2][TN];
     read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -252,13 +300,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
   }
   __syncthreads();
   {
-    constexpr int TPR = BN / 8;                // threads per row (8 couts each)
+    constexpr int TPR = BN / EPP;              // threads per row (one 16-byte piece of couts each)
     constexpr int RPI = 256 / TPR;             // rows per iteration
     const int cc = tid % TPR, rr = tid / TPR;
-    const int col = n0 + cc * 8;
-    float sc[8], sh[8];
+    const int col = n0 + cc * EPP;
+    float sc[EPP], sh[EPP];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPP; ++e) {
       sc[e] = p.scale ? p.scale[col + e] : 1.f;
       sh[e] = p.shift ? p.shift[col + e] : 0.f;
     }
@@ -267,32 +315,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvArgsB p) {
       const int m = m0 + row;
       if (m >= p.M) break;
       const long o = (long)m * p.Cout + col;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * 8]);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * 8 + 4]);
-      float v[8];
+      float v[EPP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = v0[e] * sc[e] + sh[e];
-        v[4 + e] = v1[e] * sc[4 + e] + sh[4 + e];
+      for (int h = 0; h < EPP / 4; ++h) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * EPP + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * h + e] = t[e] * sc[4 * h + e] + sh[4 * h + e];
       }
       if (p.res) {
-        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.res + o);
+        float r[EPP];
+        Piece<T>::load(p.res + o, r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        for (int e = 0; e < EPP; ++e) v[e] += r[e];
       }
       if (p.relu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < EPP; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (p.mask) {
-        const bf16x8 z = *reinterpret_cast<const bf16x8*>(p.mask + o);
+        float z[EPP];
+        Piece<T>::load(p.mask + o, z);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)z[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < EPP; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
       }
-      bf16x8 ov;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-      *reinterpret_cast<bf16x8*>(p.out + o) = ov;
+      Piece<T>::store(p.out + o, v);
     }
   }
 }
@@ -317,8 +363,8 @@ __global__ void pack_dgrad_weight_bf16_kernel(const float* __restrict__ w, bf16_
 }
 
 enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, NTILES };
-const char* const kTileNames[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
-                                        "conv_igemm_bf16<64x64>"};
+const char* const kTileNamesBf16[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
+                                            "conv_igemm_bf16<64x64>"};
 const int kTileBM[NTILES] = {128, 128, 128, 64};
 const int kTileBN[NTILES] = {128, 64, 32, 64};
 
@@ -343,36 +389,31 @@ int pick_tile(const rs_conv_desc* d) {
   return T128x32;
 }
 
-template <int KC>
-void launch(int tile, int grid, hipStream_t s, const ConvArgsB& a) {
+template <typename T, int ROWB>
+void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
   switch (tile) {
-    case T128x128: conv_igemm_bf16<128, 128, 2, 2, KC><<<grid, 256, 0, s>>>(a); break;
-    case T128x64: conv_igemm_bf16<128, 64, 2, 2, KC><<<grid, 256, 0, s>>>(a); break;
-    case T128x32: conv_igemm_bf16<128, 32, 4, 1, KC><<<grid, 256, 0, s>>>(a); break;
-    default: conv_igemm_bf16<64, 64, 2, 2, KC><<<grid, 256, 0, s>>>(a); break;
+    case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, ROWB><<<grid, 256, 0, s>>>(a); break;
+    case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, ROWB><<<grid, 256, 0, s>>>(a); break;
+    case T128x32: conv_igemm_dma<T, 128, 32, 4, 1, ROWB><<<grid, 256, 0, s>>>(a); break;
+    default: conv_igemm_dma<T, 64, 64, 2, 2, ROWB><<<grid, 256, 0, s>>>(a); break;
   }
 }
 
-}  // namespace
-
-extern "C" int rs_conv2d_tile_bf16(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
-
-extern "C" const char* rs_conv2d_tile_name_bf16(int tile) { return (tile >= 0 && tile < NTILES) ? kTileNames[tile] : ""; }
-
-extern "C" int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, const rs_bf16* src2, const rs_bf16* weight,
-                                  const float* scale, const float* shift, const rs_bf16* residual, const rs_bf16* relu_mask,
-                                  rs_bf16* out, rs_stream_t stream) {
+template <typename T>
+int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
+             const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
-  ConvArgsB a;
-  a.src1 = reinterpret_cast<const bf16_t*>(src1);
-  a.src2 = reinterpret_cast<const bf16_t*>(src2);
-  a.wgt = reinterpret_cast<const bf16_t*>(weight);
+  constexpr long ES = (long)sizeof(T);
+  ConvArgsT<T> a;
+  a.src1 = reinterpret_cast<const T*>(src1);
+  a.src2 = reinterpret_cast<const T*>(src2);
+  a.wgt = reinterpret_cast<const T*>(weight);
   a.scale = scale;
   a.shift = shift;
-  a.res = reinterpret_cast<const bf16_t*>(residual);
-  a.mask = reinterpret_cast<const bf16_t*>(relu_mask);
-  a.out = reinterpret_cast<bf16_t*>(out);
+  a.res = reinterpret_cast<const T*>(residual);
+  a.mask = reinterpret_cast<const T*>(relu_mask);
+  a.out = reinterpret_cast<T*>(out);
   a.N = d->N;
   a.Hs = d->Hs;
   a.Ws = d->Ws;
@@ -394,12 +435,14 @@ extern "C" int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, co
   {
     // 32-bit byte offsets relative to the first image of a tile (<= 128 output pixels: 128/(Ho*Wo) + 2 images)
     const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
-    const long img_bytes = (long)d->Hs * d->Ws * cmax * 2;
+    const long img_bytes = (long)d->Hs * d->Ws * cmax * ES;
     const long span = (128 / ((long)d->Ho * d->Wo) + 2) * img_bytes;
     if (span >= (1L << 31)) return RS_EINVAL;
-    if ((long)d->Cout * d->kh * d->kw * (d->C1 + d->C2) * 2 >= (1L << 31)) return RS_EINVAL;
+    if ((long)d->Cout * d->kh * d->kw * (d->C1 + d->C2) * ES >= (1L << 31)) return RS_EINVAL;
   }
-  const int kc = (d->C1 % 64 == 0 && d->C2 % 64 == 0) ? 64 : 32;
+  // channels per K-chunk: a 128-byte row, or 64 bytes for the 32-channel bf16 layers
+  const int kc128 = 128 / (int)ES;
+  const int kc = (d->C1 % kc128 == 0 && d->C2 % kc128 == 0) ? kc128 : kc128 / 2;
   a.cpt = (d->C1 + d->C2) / kc;
   a.ntaps = d->kh * d->kw;
   a.nk = a.ntaps * a.cpt;
@@ -410,9 +453,32 @@ extern "C" int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, co
   a.ntiles = d->Cout / kTileBN[tile];
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles;
   hipStream_t s = (hipStream_t)stream;
-  if (kc == 64) launch<64>(tile, grid, s, a);
-  else launch<32>(tile, grid, s, a);
+  if (kc == kc128) launch<T, 128>(tile, grid, s, a);
+  else if constexpr (sizeof(T) == 2) launch<T, 64>(tile, grid, s, a);
+  else return RS_EINVAL;
   return RS_LAUNCH_RESULT();
+}
+
+}  // namespace
+
+// fp32 entry for conv_igemm.hip (declared in common.h): every non-stem convolution of rs_conv2d_fwd
+int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2, const float* weight, const float* scale,
+                    const float* shift, const float* residual, const float* relu_mask, float* out, void* stream) {
+  return conv_fwd<float>(d, src1, src2, weight, scale, shift, residual, relu_mask, out, stream);
+}
+
+int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+
+extern "C" int rs_conv2d_tile_bf16(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+
+extern "C" const char* rs_conv2d_tile_name_bf16(int tile) {
+  return (tile >= 0 && tile < NTILES) ? kTileNamesBf16[tile] : "";
+}
+
+extern "C" int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, const rs_bf16* src2, const rs_bf16* weight,
+                                  const float* scale, const float* shift, const rs_bf16* residual, const rs_bf16* relu_mask,
+                                  rs_bf16* out, rs_stream_t stream) {
+  return conv_fwd<bf16_t>(d, src1, src2, weight, scale, shift, residual, relu_mask, out, stream);
 }
 
 extern "C" int rs_pack_dgrad_weight_bf16(const float* w_krsc, rs_bf16* out, int Cout, int kh, int kw, int Cin,

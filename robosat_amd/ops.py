@@ -53,6 +53,14 @@ def conv_flops(d):
     return 2.0 * d.N * d.Cout * cin * d.kh * d.kw * d.Ho * d.Wo
 
 
+def conv_bytes(d, esize):
+    """Algorithmic HBM bytes of one launch: every tensor once -- the PRE-upsample sources, the
+    weights, the output."""
+
+    cin = 4 if d.stem else d.C1 + d.C2
+    return esize * (d.N * d.Hs * d.Ws * cin + d.Cout * d.kh * d.kw * cin + d.N * d.Ho * d.Wo * d.Cout)
+
+
 def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=0, out_hw=None):
     n, hs, ws, c1 = src1.shape
     cout, kh, kw_, _ = weight.shape
@@ -98,7 +106,8 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     check(rc, "rs_conv2d_fwd_bf16" if bf else "rs_conv2d_fwd")
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
+        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                        conv_bytes(d, 2 if bf else 4)))
     return out
 
 
@@ -231,8 +240,10 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
     check(rc, "rs_conv2d_wgrad_bf16" if bf else "rs_conv2d_wgrad")
     if PROFILE is not None:
         ev1.record()
+        es = 2 if bf else 4
+        nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
         PROFILE.append(("conv_wgrad_bf16" if bf else "conv_wgrad_f32", conv_flops(d),
-                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1))
+                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes))
     return dw
 
 

@@ -7,7 +7,9 @@ classes: layout conversion -> 61 convolutions -> fused final 1x1 + softmax, i.e.
 device per batch (reference tools/predict.py:83-87).  Inputs are synthetic and already resident in HBM when the timed
 region starts.  Tiles shard across ranks with no data-path collective ("weak" scaling: B tiles per GPU per step).
 
-One JSON line on stdout (rank 0): metric/value/unit..., plus
+One JSON line on stdout (rank 0): metric/value/unit... (the predict leg), plus
+  "train"        -- the train leg of the metric (configs[2]: bf16, bs 32 per GPU, fwd + Lovasz + bwd + gradient
+                    all-reduce + Adam): value (tiles/s over all ranks), ms_per_step, its own roofline object;
   "roofline"     -- dominant kernel, algorithmic FLOPs / HIP-event time over the launches of one pass, vs the fp32
                     MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
   "cpu_baseline" -- the CPU oracle (oracle/robosat_ref.py, kind "port") timed on this box's host cores on a bounded
@@ -48,6 +50,8 @@ def parse():
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
                     help="compute dtype: fp32 (exact-fp32 MFMA, the parity path; BASELINE configs[1]) or bf16 (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="predict phase only: skip the bf16 train leg reported under \"train\"")
+    ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU per step of the train leg (configs[2]: 32)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
     ap.add_argument("--layers-json", type=str, default="", help="also dump the per-layer roofline table here")
     return ap.parse_args()
@@ -175,30 +179,22 @@ def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
                 n, size, size, bs, what, best, avail, cands)}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
-    if dist:
-        import torch.distributed as td
+def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
+    """Builds the model for `phase`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
+    returns (max-over-ranks seconds, step function)."""
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    import torch.distributed as td
 
-    train = args.phase == "train"
-    net = build_model(args.classes, device, train, args.dtype)
+    train = phase == "train"
+    net = build_model(args.classes, device, train, dtype)
     g = torch.Generator().manual_seed(100 + rank)
-    x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM
+    x = torch.randn(batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM
 
     if train:
         from robosat_amd import losses
         from robosat_amd.parallel import GradReducer
 
-        tgt = torch.randint(0, args.classes, (args.batch, args.size, args.size), generator=g).to(device)
+        tgt = torch.randint(0, args.classes, (batch, args.size, args.size), generator=g).to(device)
         crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=torch.ones(args.classes)),
                 "Focal": lambda: losses.FocalLoss2d(weight=torch.ones(args.classes)),
                 "Lovasz": lambda: losses.LovaszLoss2d()}[args.loss]().to(device)
@@ -222,11 +218,11 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     el = time.perf_counter() - t0
@@ -234,7 +230,34 @@ def main():
         t = torch.tensor([el], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         el = float(t.item())
+    return el, step
 
+
+def workload(args, phase, dtype, batch, world):
+    train = phase == "train"
+    return {"workload": ("rs predict ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes (BASELINE configs[1])" if not train else
+                         "rs train ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes, " + args.loss + " loss + Adam (BASELINE configs[2])").format(
+        batch, args.size, args.size, dtype, args.classes), "phase": phase, "tiles_per_gpu_per_step": batch,
+        "tile": args.size, "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
+                                           "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    el, step = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)
+    line = None
     if rank == 0:
         roof, layers = roofline(step)
         if args.layers_json:
@@ -245,13 +268,26 @@ def main():
             "value": round(world * args.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": ("rs predict ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes (BASELINE configs[1])" if not train else
-                                    "rs train ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes, " + args.loss + " loss + Adam (BASELINE configs[2])").format(
-                args.batch, args.size, args.size, args.dtype, args.classes), "phase": args.phase, "tiles_per_gpu_per_step": args.batch,
-                "tile": args.size, "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
-                                                   "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)},
+            "config": workload(args, args.phase, args.dtype, args.batch, world),
             "roofline": roof,
         }
+    del step
+    torch.cuda.empty_cache()
+
+    # The metric is "train+predict": the headline `value` above is the predict leg (BASELINE configs[1]); the train leg
+    # (configs[2]: bf16, bs 32 per GPU, fwd + Lovasz + bwd + RCCL gradient all-reduce + Adam) rides in the same line.
+    if args.phase == "predict" and not args.no_train_leg:
+        tb, ts, tw = args.train_batch, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+        tel, tstep = run_phase(args, "train", "bf16", tb, ts, tw, device, dist, rank)
+        if rank == 0:
+            troof, _ = roofline(tstep)
+            line["train"] = {"value": round(world * tb * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
+                             "ms_per_step": round(tel / ts * 1e3, 3), "dtype": "bf16", "scaling": "weak",
+                             "config": workload(args, "train", "bf16", tb, world), "roofline": troof}
+        del tstep
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds, args.phase, args.loss)
         print(json.dumps(line), flush=True)

@@ -235,6 +235,23 @@ int rs_bn_bwd_dt(const void* dz, const void* zmask, const void* y, const float* 
 int rs_upsample2x_bwd_dt(const void* dup, void* d1, void* d2, const void* mask1, const void* mask2, int dtype, int N, int H,
                          int W, int C1, int C2, int accumulate1, rs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Device-side input / output of `rs predict`: only bytes cross PCIe.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Decoded tiles as uint8 HWC [N][H][W][C<=4] -> normalised NHWC4 fp32, i.e. ToTensor + Normalize of the reference's
+ * transform chain (tools/predict.py:71: x/255 then (x - mean[c])/std[c], fp32, IEEE division: bit-identical to the
+ * host ops) + the stem's layout.  `mean`, `std`: HOST arrays of C floats. */
+int rs_u8_to_nhwc4_norm(const uint8_t* img, float* out, const float* mean, const float* std, int N, int H, int W, int C,
+                        rs_stream_t stream);
+
+/* self.final + softmax + un-buffer crop + 8-bit quantisation in one pass (tools/predict.py:87,96-103), binary models:
+ * out[n][y][x] = uint8(np.digitize(p_foreground, anchors)) for the central (H-2*overlap) x (W-2*overlap) window, with
+ * `anchors` = the 256 float64 values of np.linspace(0, 1, 256) in device memory (1-based bins, 256 wraps to 0 -- the
+ * reference's behaviour).  x: NHWC [N][H][W][Cin] of `x_dtype`; w [2][Cin], bias [2]. */
+int rs_final_conv1x1_quantize_dt(const void* x, int x_dtype, const float* w, const float* bias, const double* anchors,
+                                 uint8_t* out, int N, int H, int W, int Cin, int overlap, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

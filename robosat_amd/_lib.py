@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 3
+ABI_VERSION = 4
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -82,6 +82,9 @@ SIGNATURES = {
     "rs_bn_apply_dt": (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, P]),
     "rs_bn_bwd_dt": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_long, c_int, P, P]),
     "rs_upsample2x_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    # device-side predict input / output (N1)
+    "rs_u8_to_nhwc4_norm": (c_int, [P, P, POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, P]),
+    "rs_final_conv1x1_quantize_dt": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
 
 _lib = None

@@ -19,6 +19,21 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restr
   *reinterpret_cast<f32x4*>(y + i * 4) = v;
 }
 
+// N1: the image side of `rs predict` on the device.  Decoded tiles travel as uint8 HWC (1 byte
+// per sample instead of 4) and ToTensor + Normalize (reference tools/predict.py:71: x/255, then (x - mean)/std, both in
+// fp32 and in that order) + the NHWC4 layout the stem wants happen here.  IEEE divisions: bit-identical to the host ops.
+__global__ void u8_to_nhwc4_norm_kernel(const uint8_t* __restrict__ img, float* __restrict__ y, f32x4 mean, f32x4 stdv, int C,
+                                        long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint8_t* px = img + i * C;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C) v[c] = ((float)px[c] / 255.0f - mean[c]) / stdv[c];
+  *reinterpret_cast<f32x4*>(y + i * 4) = v;
+}
+
 // F.max_pool2d on NHWC, 4 channels per thread.  Window scanned row-major with a strict '>' so the FIRST maximum
 // wins, as torch's max_pool2d_with_indices does; padding is -inf (never selected when any tap is valid).
 template <typename TI, typename TO>
@@ -74,10 +89,16 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 // self.final (+ optional softmax): 256 pixels per block.  The block's [256][Cin] slab is read with fully coalesced
 // 16-byte loads into LDS (row stride Cin+1: conflict-free per-pixel reads), then one thread owns one pixel, keeps
 // the C class sums in registers and writes C coalesced NCHW planes.
+// softmax = 2 (N1): instead of the C probability planes write ONE byte per pixel of the
+// un-buffered crop: np.digitize(p_foreground, np.linspace(0, 1, 256)).astype(uint8) (reference tools/predict.py:98-103:
+// 1-based bin = number of anchors <= p, 256 wraps to 0), anchors passed in as the host's own float64 linspace so the
+// comparison is the one numpy does.  `qout` is [N][H-2*ov][W-2*ov]; only S*S bytes per tile go back to the host.
 template <int C, typename T>
 __global__ __launch_bounds__(256) void final_conv1x1_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            long P, long HW, int Cin, int softmax) {
+                                                            long P, long HW, int Cin, int softmax,
+                                                            const double* __restrict__ anchors = nullptr,
+                                                            uint8_t* __restrict__ qout = nullptr, int Wimg = 0, int ov = 0) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = Cin + 1;
   float* xs = sm;             // [256][Cin+1]
@@ -125,6 +146,20 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const T* __restrict_
     for (int c = 0; c < C; ++c) acc[c] = acc[c] / sum;
   }
   const long n = pix / HW, hw = pix - n * HW;
+  if (softmax == 2) {
+    if (C < 2) return;
+    const int Himg = (int)(HW / Wimg);
+    const int yy = (int)(hw / Wimg), xx = (int)(hw - (long)yy * Wimg);
+    const int S_h = Himg - 2 * ov, S_w = Wimg - 2 * ov;
+    if (yy < ov || yy >= Himg - ov || xx < ov || xx >= Wimg - ov) return;
+    const double pf = (double)acc[C > 1 ? 1 : 0];
+    int q = (int)(pf * 255.0);  // anchors[i] ~ i/255: first guess, then settle on the exact table (anchors ascending)
+    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+    while (q < 255 && anchors[q + 1] <= pf) ++q;
+    while (q >= 0 && anchors[q] > pf) --q;
+    qout[(n * S_h + (yy - ov)) * (long)S_w + (xx - ov)] = (uint8_t)((q + 1) & 0xff);  // bins are 1-based; 256 wraps to 0
+    return;
+  }
   float* o = out + n * C * HW + hw;
 #pragma unroll
   for (int c = 0; c < C; ++c) o[c * HW] = acc[c];
@@ -132,14 +167,14 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const T* __restrict_
 
 template <int C, typename T>
 int launch_final(const T* x, const float* w, const float* bias, float* out, long P, long HW, int Cin, int softmax,
-                 hipStream_t s) {
+                 hipStream_t s, const double* anchors = nullptr, uint8_t* qout = nullptr, int Wimg = 0, int ov = 0) {
   const size_t smem = (size_t)(256 * (Cin + 1) + C * Cin + C) * sizeof(float);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_conv1x1_kernel<C, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  final_conv1x1_kernel<C, T><<<rs_cdiv(P, 256), 256, smem, s>>>(x, w, bias, out, P, HW, Cin, softmax);
+  final_conv1x1_kernel<C, T><<<rs_cdiv(P, 256), 256, smem, s>>>(x, w, bias, out, P, HW, Cin, softmax, anchors, qout, Wimg, ov);
   return RS_LAUNCH_RESULT();
 }
 
@@ -185,7 +220,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 
 }  // namespace
 
-extern "C" int rs_abi_version(void) { return 3; }
+extern "C" int rs_abi_version(void) { return 4; }
 
 extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
@@ -239,4 +274,32 @@ extern "C" int rs_final_conv1x1_dt(const void* x, int x_dtype, const float* w, c
 extern "C" int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
                                 int C, int softmax, rs_stream_t stream) {
   return rs_final_conv1x1_dt(x, RS_F32, w, bias, out, N, H, W, Cin, C, softmax, stream);
+}
+
+extern "C" int rs_u8_to_nhwc4_norm(const uint8_t* img, float* out, const float* mean, const float* stdv, int N, int H, int W,
+                                   int C, rs_stream_t stream) {
+  if (!img || !out || !mean || !stdv || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return RS_EINVAL;
+  f32x4 m = {0.f, 0.f, 0.f, 0.f}, sd = {1.f, 1.f, 1.f, 1.f};
+  for (int c = 0; c < C; ++c) {
+    m[c] = mean[c];  // host arrays: three or four floats
+    sd[c] = stdv[c];
+  }
+  const long total = (long)N * H * W;
+  u8_to_nhwc4_norm_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, m, sd, C, total);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_final_conv1x1_quantize_dt(const void* x, int x_dtype, const float* w, const float* bias,
+                                            const double* anchors, uint8_t* out, int N, int H, int W, int Cin, int overlap,
+                                            rs_stream_t stream) {
+  if (!x || !w || !anchors || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cin > 128 || overlap < 0 ||
+      2 * overlap >= H || 2 * overlap >= W)
+    return RS_EINVAL;
+  const long HW = (long)H * W, P = (long)N * HW;
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == RS_F32)
+    return launch_final<2>(reinterpret_cast<const float*>(x), w, bias, (float*)nullptr, P, HW, Cin, 2, s, anchors, out, W, overlap);
+  if (x_dtype == RS_BF16)
+    return launch_final<2>(reinterpret_cast<const bf16_t*>(x), w, bias, (float*)nullptr, P, HW, Cin, 2, s, anchors, out, W, overlap);
+  return RS_EINVAL;
 }

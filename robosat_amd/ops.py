@@ -143,6 +143,41 @@ def nchw_to_nhwc4(x):
     return out
 
 
+def u8_to_nhwc4_norm(img, mean, std):
+    """uint8 HWC tiles [N,H,W,C] -> normalised NHWC4 fp32: ToTensor + Normalize (tools/predict.py:71) on the device."""
+
+    n, h, w, c = img.shape
+    assert len(mean) == c and len(std) == c
+    out = torch.empty((n, h, w, 4), device=img.device, dtype=torch.float32)
+    fm, fs = (ctypes.c_float * c)(*mean), (ctypes.c_float * c)(*std)
+    check(_lib.lib().rs_u8_to_nhwc4_norm(_dev(img, "img", torch.uint8), _dev(out, "out"), fm, fs, n, h, w, c, _stream()),
+          "rs_u8_to_nhwc4_norm")
+    return out
+
+
+_ANCHORS = {}
+
+
+def final_conv1x1_quantize(x, w, bias, overlap):
+    """self.final + softmax + crop of the `overlap` border + np.digitize(p_fg, linspace(0,1,256)).astype(uint8)
+    (tools/predict.py:87,96-103) in one kernel: uint8 [N, H-2*overlap, W-2*overlap]."""
+
+    import numpy as np
+
+    n, h, wd, cin = x.shape
+    assert w.shape[0] == 2, "single channel requires binary model"  # the reference's assertion (predict.py:98)
+    anchors = _ANCHORS.get(x.device)
+    if anchors is None:
+        anchors = torch.from_numpy(np.linspace(0, 1, 256)).to(x.device)  # numpy's own float64 anchors
+        _ANCHORS[x.device] = anchors
+    out = torch.empty((n, h - 2 * overlap, wd - 2 * overlap), device=x.device, dtype=torch.uint8)
+    rc = _lib.lib().rs_final_conv1x1_quantize_dt(_dev(x, "x", x.dtype), _dt(x), _dev(w, "w"), _dev(bias, "bias"),
+                                                 _dev(anchors, "anchors", torch.float64), _dev(out, "out", torch.uint8), n, h,
+                                                 wd, cin, overlap, _stream())
+    check(rc, "rs_final_conv1x1_quantize_dt")
+    return out
+
+
 def maxpool2d(x, k, stride, pad, want_argmax=False, out_dtype=None):
     """``out_dtype`` (default: x.dtype): torch.bfloat16 on an fp32 input is the precision boundary of the bf16 path."""
 

@@ -20,6 +20,17 @@ class ImageToTensor:
         return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1))).float().div_(255)
 
 
+class ImageToUint8:
+    """PIL image -> uint8 [H,W,C] tensor, untouched: ToTensor + Normalize then run on the device
+    (``UNet.predict_quantized``), so a tile crosses PCIe as 1 byte per sample."""
+
+    def __call__(self, image):
+        arr = np.asarray(image, dtype=np.uint8)
+        if arr.ndim == 2:
+            arr = arr[:, :, None]
+        return torch.from_numpy(np.ascontiguousarray(arr))
+
+
 class MaskToTensor:
     """PIL label image -> int64 [H,W]."""
 

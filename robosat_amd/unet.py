@@ -251,15 +251,32 @@ class UNet(nn.Module):
         assert not self.training, "predict_probs is an eval-mode call"
         return self._forward_eval(x, softmax=True)
 
-    def _forward_eval(self, x, softmax):
-        if not x.is_cuda:
-            raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
-        assert x.size(1) == self.in_channels
-        r = self.resnet
-        x = x.detach().float().contiguous()
+    @torch.no_grad()
+    def predict_quantized(self, images_u8, overlap=0, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """The whole device side of ``rs predict`` for a batch of decoded tiles:
+        uint8 HWC ``[N,H,W,C]`` in -> ToTensor + Normalize -> U-Net -> softmax -> crop of the ``overlap`` border ->
+        ``np.digitize(p_foreground, np.linspace(0,1,256)).astype(uint8)`` out, ``[N,H-2*overlap,W-2*overlap]`` uint8:
+        exactly the bytes the reference writes into its probability PNGs (tools/predict.py:71-103), 1 byte per pixel each
+        way over PCIe instead of 12 in / 8 out."""
 
+        assert not self.training, "predict_quantized is an eval-mode call"
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.size(3) == self.in_channels
+        assert images_u8.size(1) % 32 == 0 and images_u8.size(2) % 32 == 0, "image resolution has to be divisible by 32 for resnet"
+        if not images_u8.is_cuda:
+            raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(images_u8.device))
+        x4 = ops.u8_to_nhwc4_norm(images_u8.contiguous(), list(mean)[:self.in_channels], list(std)[:self.in_channels])
+        return self._forward_eval(None, softmax=False, x4=x4, quantize_overlap=overlap)
+
+    def _forward_eval(self, x, softmax, x4=None, quantize_overlap=None):
+        r = self.resnet
         dt = self.compute_dtype  # activations after the stem pool (the stem itself always runs in fp32)
-        h = ops.nchw_to_nhwc4(x)
+        if x4 is None:
+            if not x.is_cuda:
+                raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
+            assert x.size(1) == self.in_channels
+            x = x.detach().float().contiguous()
+            x4 = ops.nchw_to_nhwc4(x)
+        h = x4
         sc, sh = r.bn1.folded()
         h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7)
         h = ops.maxpool2d(h, 3, 2, 1, out_dtype=dt)
@@ -293,4 +310,6 @@ class UNet(nn.Module):
         dec5 = ops.conv2d(dec4, self.dec5.block.krsc(dt), pad=1, relu=True)
 
         wf = self.final.weight.detach().reshape(self.num_classes, -1)
+        if quantize_overlap is not None:
+            return ops.final_conv1x1_quantize(dec5, wf, self.final.bias.detach(), quantize_overlap)
         return ops.final_conv1x1(dec5, wf, self.final.bias.detach(), softmax=softmax)

@@ -16,5 +16,5 @@ echo "== bench train bf16 bs8"
 timeout 600 python bench.py --phase train --dtype bf16 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --layers-json gpurun_out/layers_train_bf16_$TAG.json > gpurun_out/bench_train_bf16_$TAG.log 2>&1
 echo "exit $?"; tail -2 gpurun_out/bench_train_bf16_$TAG.log
 echo "== bench predict bf16 bs16"
-timeout 600 python bench.py --dtype bf16 --steps 10 --warmup 2 --no-cpu-baseline --layers-json gpurun_out/layers_bf16_$TAG.json > gpurun_out/bench_bf16_$TAG.log 2>&1
+timeout 600 python bench.py --dtype bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-train-leg --layers-json gpurun_out/layers_bf16_$TAG.json > gpurun_out/bench_bf16_$TAG.log 2>&1
 echo "exit $?"; tail -2 gpurun_out/bench_bf16_$TAG.log

@@ -18,7 +18,7 @@ echo "bench train exit $?"; tail -3 gpurun_out/bench_train_$TAG.log
 if [ -n "$ROCPROF" ]; then
 echo "== rocprofv3 kernel trace (predict bench)"
 REPO=$(pwd); cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o predict -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/rocprof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o predict -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-leg > $REPO/gpurun_out/rocprof_$TAG.log 2>&1
 echo "rocprof exit $?"; tail -2 $REPO/gpurun_out/rocprof_$TAG.log
 find $REPO/gpurun_out/prof_$TAG -name "*stats*" | head
 cd $REPO

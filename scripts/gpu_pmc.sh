@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 REPO=$(pwd); mkdir -p gpurun_out; cd /tmp
 run() { # name counters...
   name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $REPO/gpurun_out/pmc_$TAG/$name -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/pmc_${TAG}_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $REPO/gpurun_out/pmc_$TAG/$name -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg > $REPO/gpurun_out/pmc_${TAG}_$name.log 2>&1
   echo "pass $name exit $?"
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE

@@ -7,7 +7,7 @@
 TAG=${1:-r01}
 export TMPDIR=/tmp
 REPO=$(pwd); OUT=$REPO/gpurun_out/profile_$TAG; mkdir -p $OUT; cd /tmp
-B="python $REPO/bench.py --no-cpu-baseline"
+B="python $REPO/bench.py --no-cpu-baseline --no-train-leg"
 echo "== kernel trace: predict (default bench config)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/predict_trace -o p -- $B --steps 5 --warmup 2 > $OUT/predict_trace.log 2>&1; echo "exit $?"
 echo "== kernel trace: train bf16 bs32"

@@ -75,6 +75,55 @@ def test_rs_train_then_predict(tmp_path):
     assert worst <= 1
 
 
+def test_device_side_predict_pipeline_is_bit_identical_to_host_steps(tmp_path):
+    """N1: uint8 tiles in, quantised bytes out, all on the device, must reproduce the bytes of the
+    reference's host-side steps -- ToTensor + Normalize (fp32), softmax, unbuffer, np.digitize -- exactly."""
+    from robosat_amd.tools import predict as predict_tool
+    from robosat_amd.tools.predict import quantize
+    from robosat_amd.transforms import ImageToTensor, Normalize
+    from robosat_amd.unet import UNet
+
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    net = UNet(2, pretrained=False)
+    net.load_state_dict(seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 6))
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (3, 192, 256, 3), generator=g, dtype=torch.uint8)
+    u8[0, :, :, :] = 0  # extremes of the input range
+    u8[1, :40] = 255
+    overlap = 32
+    got = net.predict_quantized(u8.to(DEV), overlap=overlap, mean=mean, std=std).cpu().numpy()
+    assert got.dtype == np.uint8 and got.shape == (3, 192 - 64, 256 - 64)
+    # host steps as the reference does them (PIL -> ToTensor -> Normalize; softmax output -> crop -> digitize)
+    norm = Normalize(mean, std)
+    x = torch.stack([norm(ImageToTensor()(Image.fromarray(im.numpy(), mode="RGB"))) for im in u8])
+    probs = net.predict_probs(x.to(DEV)).cpu().numpy()
+    want = np.stack([quantize(p[1:, overlap:-overlap, overlap:-overlap]).squeeze() for p in probs])
+    assert np.array_equal(got, want), int((got != want).sum())
+
+    # and through the tool: both pipelines write identical PNG pixels
+    tmp = str(tmp_path)
+    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=2, n_val=4, size=256, seed=7)
+    model_toml, ds_toml = synth.write_configs(tmp, ds_root, os.path.join(tmp, "pth"), batch_size=2, image_size=256)
+    ck_path = os.path.join(tmp, "ck.pth")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in net.state_dict().items()}}, ck_path)
+    tiles_dir = os.path.join(ds_root, "validation", "images")
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["ROBOSAT_PREDICT_HOST_PIPELINE"] = mode
+        try:
+            probs_dir = os.path.join(tmp, "probs" + mode)
+            predict_tool.main(argparse.Namespace(batch_size=2, checkpoint=ck_path, overlap=32, tile_size=256, workers=0,
+                                                 tiles=tiles_dir, probs=probs_dir, model=model_toml, dataset=ds_toml))
+        finally:
+            os.environ.pop("ROBOSAT_PREDICT_HOST_PIPELINE", None)
+        files = sorted(os.path.join(d, f) for d, _, fs in os.walk(probs_dir) for f in fs)
+        assert len(files) == 4
+        outs[mode] = [np.array(Image.open(f)) for f in files]
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b)
+
+
 def test_training_trajectory_matches_cpu_oracle(tmp_path):
     """Same initial weights, same batches, same Adam: per-step losses and epoch metrics of the GPU path track the CPU
     oracle (fp32 tolerance grows with the step count, Adam normalises even tiny gradient differences)."""

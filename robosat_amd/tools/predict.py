@@ -67,7 +67,7 @@ def main(args):
     num_classes = len(dataset["common"]["classes"])
 
     chkpt = torch.load(args.checkpoint, map_location=device)
-    net = UNet(num_classes, pretrained=False).to(device)
+    net = UNet(num_classes, pretrained=False, compute_dtype=model.get("model", {}).get("compute_dtype", "fp32")).to(device)
     net.load_state_dict(strip_module_prefix(chkpt["state_dict"]))
     net.eval()
 

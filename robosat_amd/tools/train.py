@@ -83,7 +83,9 @@ def main(args):
     os.makedirs(model["common"]["checkpoint"], exist_ok=True)
 
     num_classes = len(dataset["common"]["classes"])
-    net = Replica(UNet(num_classes)).to(device)
+    # [model] compute_dtype = "bf16" (extension key; default "fp32" = the parity path) selects the bf16 MFMA kernels
+    compute_dtype = model.get("model", {}).get("compute_dtype", "fp32")
+    net = Replica(UNet(num_classes, compute_dtype=compute_dtype)).to(device)
     if world > 1:
         net.module.grad_reducer = parallel.GradReducer()
 

@@ -235,6 +235,19 @@ int rs_bn_bwd_dt(const void* dz, const void* zmask, const void* y, const float* 
 int rs_upsample2x_bwd_dt(const void* dup, void* d1, void* d2, const void* mask1, const void* mask2, int dtype, int N, int H,
                          int W, int C1, int C2, int accumulate1, rs_stream_t stream);
 
+/* Train-mode convolution that also produces the BatchNorm forward statistics of its output (the conv -> bn pairs of
+ * torchvision's Bottleneck, unet.py:127-130): out = conv(gather(src1|src2)) with NO epilogue, plus per-M-tile partial
+ * sums stats_partial[tile][0][co] = sum, [tile][1][co] = sum of squares of the values as stored (tiles =
+ * rs_conv2d_bnstats_rows(d)); rs_bn_finalize_stats turns them into what rs_bn_train_stats returns, saving that
+ * kernel's read pass over the activation.  Not for the stem. */
+long rs_conv2d_bnstats_rows(const rs_conv_desc* d);
+int rs_conv2d_fwd_bnstats_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2, const void* weight,
+                             void* out, float* stats_partial, rs_stream_t stream);
+int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float eps, float momentum, const float* gamma,
+                         const float* beta, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, void* workspace, rs_stream_t stream);
+/* (workspace: 64 * 2 * C doubles, optional -- enables the parallel first-level reduction when rows > 256) */
+
 /* ------------------------------------------------------------------------------------------------------------
  * Device-side input / output of `rs predict`: only bytes cross PCIe.
  * ---------------------------------------------------------------------------------------------------------- */

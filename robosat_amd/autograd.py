@@ -72,12 +72,28 @@ class _Tape:
         self.t = {}
 
 
-def _bn_train(bn, y, residual=None, relu=True):
-    mean, invstd, scale, shift = ops.bn_train_stats(
-        y, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+def _bn_train(bn, y, residual=None, relu=True, partial=None):
+    """Train-mode BatchNorm (+ residual, ReLU).  ``partial``: the statistics' partial sums when the producing convolution
+    already reduced them in its epilogue (``ops.conv2d_bnstats``) -- otherwise a read pass over ``y`` computes them."""
+
+    if partial is None:
+        mean, invstd, scale, shift = ops.bn_train_stats(
+            y, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+    else:
+        mean, invstd, scale, shift = ops.bn_finalize_stats(
+            partial, y.numel() // y.shape[-1], bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean,
+            bn.running_var, bn.num_batches_tracked)
     bn._folded = None
     z = ops.bn_apply(y, scale, shift, residual=residual, relu=relu)
     return z, (mean, invstd)
+
+
+def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
+    """conv -> train-mode BatchNorm (-> + residual -> ReLU) with the statistics fused into the convolution."""
+
+    y, partial = ops.conv2d_bnstats(src, w, stride=stride, pad=pad)
+    z, st = _bn_train(bn, y, residual=residual, relu=relu, partial=partial)
+    return y, z, st
 
 
 def _forward(net, x, tape):
@@ -96,18 +112,14 @@ def _forward(net, x, tape):
     for layer in net._blocks():
         for blk in layer:
             rec = {"blk": blk, "h": h}
-            y1 = ops.conv2d(h, blk.conv1.krsc(dt))
-            z1, rec["st1"] = _bn_train(blk.bn1, y1)
-            y2 = ops.conv2d(z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1)
-            z2, rec["st2"] = _bn_train(blk.bn2, y2)
-            y3 = ops.conv2d(z2, blk.conv3.krsc(dt))
+            y1, z1, rec["st1"] = _conv_bn(blk.bn1, h, blk.conv1.krsc(dt))
+            y2, z2, rec["st2"] = _conv_bn(blk.bn2, z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1)
             if blk.downsample is not None:
-                yd = ops.conv2d(h, blk.downsample[0].krsc(dt), stride=blk.stride)
-                idt, rec["std"] = _bn_train(blk.downsample[1], yd, relu=False)
+                yd, idt, rec["std"] = _conv_bn(blk.downsample[1], h, blk.downsample[0].krsc(dt), stride=blk.stride, relu=False)
                 rec["yd"] = yd
             else:
                 idt = h
-            z3, rec["st3"] = _bn_train(blk.bn3, y3, residual=idt, relu=True)
+            y3, z3, rec["st3"] = _conv_bn(blk.bn3, z2, blk.conv3.krsc(dt), residual=idt, relu=True)
             rec.update(y1=y1, z1=z1, y2=y2, z2=z2, y3=y3, z3=z3)
             tape.blocks.append(rec)
             h = z3

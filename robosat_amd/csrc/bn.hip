@@ -132,14 +132,15 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y
 }
 
 // Stage 2: 16 channels x 16 split lanes per block; lane l sums splits l, l+16, ... in fp64, LDS tree over the lanes.
-__device__ __forceinline__ void bn_reduce_splits(const double* __restrict__ part, int R, int C, int c, int lane, bool ok,
+template <typename P>
+__device__ __forceinline__ void bn_reduce_splits(const P* __restrict__ part, int R, int C, int c, int lane, bool ok,
                                                  double& s0, double& s1) {
   __shared__ double red[2][16][17];
   double a = 0, b = 0;
   if (ok) {
     for (int r = lane; r < R; r += 16) {
-      a += part[((long)r * 2) * C + c];
-      b += part[((long)r * 2 + 1) * C + c];
+      a += (double)part[((long)r * 2) * C + c];
+      b += (double)part[((long)r * 2 + 1) * C + c];
     }
   }
   const int cl = threadIdx.x & 15;
@@ -157,8 +158,9 @@ __device__ __forceinline__ void bn_reduce_splits(const double* __restrict__ part
   }
 }
 
+template <typename P>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(
-    const double* __restrict__ part, int R, long M, int C, float eps, float momentum, const float* __restrict__ gamma,
+    const P* __restrict__ part, int R, long M, int C, float eps, float momentum, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ running_mean, float* __restrict__ running_var,
     long long* __restrict__ num_batches_tracked) {
@@ -255,8 +257,9 @@ int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const
   double* part = reinterpret_cast<double*>(workspace);
   bn_partial_kernel<0, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
                                                           g.rows_per_split);
-  bn_stats_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd, scale,
-                                                           shift, running_mean, running_var, num_batches_tracked);
+  bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd,
+                                                                   scale, shift, running_mean, running_var,
+                                                                   num_batches_tracked);
   return RS_LAUNCH_RESULT();
 }
 
@@ -299,6 +302,50 @@ extern "C" int rs_bn_train_stats(const float* y, long M, int C, float eps, float
                                  rs_stream_t stream) {
   return rs_bn_train_stats_dt(y, RS_F32, M, C, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean,
                               running_var, num_batches_tracked, workspace, stream);
+}
+
+// First level for many conv-epilogue partial rows: slice s of the rows -> one fp64 partial row [s][2][C]
+__global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __restrict__ part, int R, int C, int rows_per_slice,
+                                                                double* __restrict__ out) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  const int r0 = blockIdx.y * rows_per_slice;
+  int r1 = r0 + rows_per_slice;
+  if (r1 > R) r1 = R;
+  double s0, s1;
+  bn_reduce_splits(part + (long)r0 * 2 * C, r1 - r0, C, c, lane, c < C, s0, s1);
+  if (c < C && lane == 0) {
+    out[((long)blockIdx.y * 2) * C + c] = s0;
+    out[((long)blockIdx.y * 2 + 1) * C + c] = s1;
+  }
+}
+
+// Finalize from the per-tile fp32 partial sums the convolution epilogue wrote (rs_conv2d_fwd_bnstats_dt): replaces the
+// separate read pass of rs_bn_train_stats.
+extern "C" int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float eps, float momentum,
+                                    const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                                    float* shift, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    void* workspace, rs_stream_t stream) {
+  if (!partial || rows <= 0 || rows >= (1L << 31) || !gamma || !beta || !mean || !invstd || !scale || !shift || M <= 0 ||
+      C <= 0)
+    return RS_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return RS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (rows > 256 && workspace) {  // two levels: <= 64 slices of the rows in parallel, then the usual fp64 finalize
+    int slices = (int)((rows + 63) / 64);
+    if (slices > 64) slices = 64;
+    const int rps = (int)((rows + slices - 1) / slices);
+    slices = (int)((rows + rps - 1) / rps);
+    double* part2 = reinterpret_cast<double*>(workspace);
+    bn_partial_reduce_kernel<<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2);
+    bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, eps, momentum, gamma, beta, mean,
+                                                                     invstd, scale, shift, running_mean, running_var,
+                                                                     num_batches_tracked);
+    return RS_LAUNCH_RESULT();
+  }
+  bn_stats_finalize_kernel<float><<<rs_cdiv(C, 16), 256, 0, s>>>(partial, (int)rows, M, C, eps, momentum, gamma, beta, mean,
+                                                                  invstd, scale, shift, running_mean, running_var,
+                                                                  num_batches_tracked);
+  return RS_LAUNCH_RESULT();
 }
 
 extern "C" int rs_bn_apply_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,

@@ -30,6 +30,8 @@
 //            per 32-row sub-tile per k-step.  The weight fragment is the A operand: D[i = cout][j = pixel].
 //   store   = accumulators -> LDS [pixel][cout] fp32 -> row-wise: 8 couts per thread, fp32 scale/shift, bf16 residual /
 //            ReLU / ReLU-mask, one 16-byte bf16x8 store.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -44,6 +46,7 @@ struct ConvArgsT {
   const T* res;
   const T* mask;
   T* out;
+  float* stats;  // optional [M tiles][2][Cout]: per-tile sum / sum of squares of the STORED output (train-mode BatchNorm)
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles, ntaps;
@@ -61,6 +64,10 @@ struct Piece<float> {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = t[e];
   }
+  __device__ static __forceinline__ void round(const float (&v)[4], float (&w)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = v[e];
+  }
   __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
     f32x4 t;
 #pragma unroll
@@ -74,6 +81,10 @@ struct Piece<bf16_t> {
     const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  __device__ static __forceinline__ void round(const float (&v)[8], float (&w)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = (float)(bf16_t)v[e];
   }
   __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     bf16x8 t;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   constexpr int KS = CPR / 2;         // k-steps per chunk (two pieces each: lanes 0-31 / 32-63)
   constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline buffer
   constexpr int LDO = BN + 4;         // epilogue staging row (floats)
-  constexpr int PIPE = 2 * BUF, STAGE = BM * LDO * 4;
+  constexpr int PIPE = 2 * BUF, STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
   constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
   constexpr int TABN = (kMaxTaps + 1) * BM;  // (tap, row) -> source pixel
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   __syncthreads();
   for (int kc = 0; kc < p.nk; ++kc) {
     const unsigned char* L = smem + (kc & 1) * BUF;
-    issue_dma((kc + 1) & 1);  // past the last chunk: tap = ntaps reads the -1 guard rows (zeros), weights out of range
+    if (kc + 1 < p.nk) issue_dma((kc + 1) & 1);  // (uniform branch) nothing to fetch behind the last chunk
     u32x4 fa[2][TM], fb[2][TN];
     read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
@@ -279,15 +290,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     __syncthreads();
   }
 
-  // ---- epilogue: registers -> LDS [pixel][cout] fp32 -> 8 couts per thread, 16-byte bf16 stores --------------------
+  // ---- epilogue: registers -> LDS [pixel][cout] fp32 -> one 16-byte piece of couts per thread, row-wise stores.
+  //      TM passes of WGM*32 rows each (pass t = sub-tile tm = t of every wave) keep the staging tile at
+  //      WGM*32 x (BN+4) floats: the LDS footprint, hence the blocks per CU, is set by the pipeline buffers alone.
   float* lds = reinterpret_cast<float*>(smem);
-  {
-    const int pr = wm * WM + (lane & 31);
-    const int ccol = wn * WN + 4 * (lane >> 5);
+  constexpr int TPR = BN / EPP;              // threads per row
+  constexpr int RPI = 256 / TPR;             // rows per iteration
+  const int cc = tid % TPR, rr = tid / TPR;
+  const int col = n0 + cc * EPP;
+  float sc[EPP], sh[EPP];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+  for (int e = 0; e < EPP; ++e) {
+    sc[e] = p.scale ? p.scale[col + e] : 1.f;
+    sh[e] = p.shift ? p.shift[col + e] : 0.f;
+  }
+  float st0[EPP], st1[EPP];  // BatchNorm forward statistics of this thread's rows (only when p.stats)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+  for (int e = 0; e < EPP; ++e) st0[e] = st1[e] = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if (tm > 0) __syncthreads();  // the previous pass has been read out
+    {
+      const int pr = wm * 32 + (lane & 31);  // pass-local row
+      const int ccol = wn * WN + 4 * (lane >> 5);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 v;
@@ -295,50 +322,69 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
           v[1] = acc[tn][tm][4 * g + 1];
           v[2] = acc[tn][tm][4 * g + 2];
           v[3] = acc[tn][tm][4 * g + 3];
-          *reinterpret_cast<f32x4*>(&lds[(pr + 32 * tm) * LDO + ccol + 32 * tn + 8 * g]) = v;
+          *reinterpret_cast<f32x4*>(&lds[pr * LDO + ccol + 32 * tn + 8 * g]) = v;
         }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int lrow = rr; lrow < WGM * 32; lrow += RPI) {
+      const int row = (lrow >> 5) * WM + 32 * tm + (lrow & 31);  // tile row of pass-local row lrow
+      const int m = m0 + row;
+      if (m < p.M) {
+        const long o = (long)m * p.Cout + col;
+        float v[EPP];
+#pragma unroll
+        for (int h = 0; h < EPP / 4; ++h) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&lds[lrow * LDO + cc * EPP + 4 * h]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * h + e] = t[e] * sc[4 * h + e] + sh[4 * h + e];
+        }
+        if (p.res) {
+          float r[EPP];
+          Piece<T>::load(p.res + o, r);
+#pragma unroll
+          for (int e = 0; e < EPP; ++e) v[e] += r[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < EPP; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.mask) {
+          float z[EPP];
+          Piece<T>::load(p.mask + o, z);
+#pragma unroll
+          for (int e = 0; e < EPP; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
+        }
+        Piece<T>::store(p.out + o, v);
+        if (p.stats) {
+          float w[EPP];
+          Piece<T>::round(v, w);  // statistics of the values as stored (bf16-rounded on the bf16 path)
+#pragma unroll
+          for (int e = 0; e < EPP; ++e) {
+            st0[e] += w[e];
+            st1[e] += w[e] * w[e];
+          }
+        }
+      }
+    }
   }
-  __syncthreads();
-  {
-    constexpr int TPR = BN / EPP;              // threads per row (one 16-byte piece of couts each)
-    constexpr int RPI = 256 / TPR;             // rows per iteration
-    const int cc = tid % TPR, rr = tid / TPR;
-    const int col = n0 + cc * EPP;
-    float sc[EPP], sh[EPP];
+  if (p.stats) {  // (uniform) block reduction over the RPI row lanes -> one partial row per M tile
+    __syncthreads();
+    float* r0 = lds;             // [RPI][BN]
+    float* r1 = lds + RPI * BN;  // [RPI][BN]
 #pragma unroll
     for (int e = 0; e < EPP; ++e) {
-      sc[e] = p.scale ? p.scale[col + e] : 1.f;
-      sh[e] = p.shift ? p.shift[col + e] : 0.f;
+      r0[rr * BN + cc * EPP + e] = st0[e];
+      r1[rr * BN + cc * EPP + e] = st1[e];
     }
-#pragma unroll 2
-    for (int row = rr; row < BM; row += RPI) {
-      const int m = m0 + row;
-      if (m >= p.M) break;
-      const long o = (long)m * p.Cout + col;
-      float v[EPP];
-#pragma unroll
-      for (int h = 0; h < EPP / 4; ++h) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(&lds[row * LDO + cc * EPP + 4 * h]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * h + e] = t[e] * sc[4 * h + e] + sh[4 * h + e];
-      }
-      if (p.res) {
-        float r[EPP];
-        Piece<T>::load(p.res + o, r);
-#pragma unroll
-        for (int e = 0; e < EPP; ++e) v[e] += r[e];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < EPP; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (p.mask) {
-        float z[EPP];
-        Piece<T>::load(p.mask + o, z);
-#pragma unroll
-        for (int e = 0; e < EPP; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
-      }
-      Piece<T>::store(p.out + o, v);
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const float* r = tid < BN ? r0 : r1;
+      const int c = tid < BN ? tid : tid - BN;
+      float a = 0.f;
+#pragma unroll 4
+      for (int l = 0; l < RPI; ++l) a += r[l * BN + c];
+      p.stats[((long)mt * 2 + (tid < BN ? 0 : 1)) * p.Cout + n0 + c] = a;
     }
   }
 }
@@ -389,6 +435,25 @@ int pick_tile(const rs_conv_desc* d) {
   return T128x32;
 }
 
+// 128-byte rows (4 k-steps per barrier, 2 blocks per CU) or 64-byte rows (2 k-steps per barrier, 4 blocks per CU)?
+// RS_CONV_ROWB=64|128 overrides (measurement knob).
+int pick_rowb(const rs_conv_desc* d, int es) {
+  static const int forced = [] {
+    const char* e = getenv("RS_CONV_ROWB");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 64 || forced == 128) return forced;
+  // Measured on both paths (bs-32 bf16 train, bs-16 fp32 predict, per-layer A/B): 64-byte rows win when the grid can use the
+  // doubled occupancy (>= 2048 blocks) and the K loop is short (<= 16 chunks of 128 bytes) -- the 1x1 convolutions at
+  // 64^2..128^2 gain 25-35 % -- or, for fp32, at any K (the 64-cycle fp32 MFMAs hide the extra barriers); long-K layers
+  // with few blocks (layer3/4, dec0/dec1) keep 128-byte rows (+8..20 % there).
+  const int tile = pick_tile(d);
+  const long blocks = (long)rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[tile]) * (d->Cout / kTileBN[tile]);
+  const long nk128 = (long)d->kh * d->kw * (d->C1 + d->C2) * es / 128;
+  if (blocks >= 2048 && (nk128 <= 16 || es == 4)) return 64;
+  return 128;
+}
+
 template <typename T, int ROWB>
 void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
   switch (tile) {
@@ -401,7 +466,8 @@ void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
 
 template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
-             const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream) {
+             const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
+             float* stats = nullptr) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
   constexpr long ES = (long)sizeof(T);
@@ -414,6 +480,7 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.res = reinterpret_cast<const T*>(residual);
   a.mask = reinterpret_cast<const T*>(relu_mask);
   a.out = reinterpret_cast<T*>(out);
+  a.stats = stats;
   a.N = d->N;
   a.Hs = d->Hs;
   a.Ws = d->Ws;
@@ -440,9 +507,11 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
     if (span >= (1L << 31)) return RS_EINVAL;
     if ((long)d->Cout * d->kh * d->kw * (d->C1 + d->C2) * ES >= (1L << 31)) return RS_EINVAL;
   }
-  // channels per K-chunk: a 128-byte row, or 64 bytes for the 32-channel bf16 layers
+  // channels per K-chunk: a 128-byte row, or 64 bytes (the 32-channel bf16 layers; also half the LDS: 4 blocks per CU
+  // instead of 2, which is what the short-K layers want -- see pick_rowb)
   const int kc128 = 128 / (int)ES;
-  const int kc = (d->C1 % kc128 == 0 && d->C2 % kc128 == 0) ? kc128 : kc128 / 2;
+  const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
+  const int kc = (can128 && pick_rowb(d, (int)ES) == 128) ? kc128 : kc128 / 2;
   a.cpt = (d->C1 + d->C2) / kc;
   a.ntaps = d->kh * d->kw;
   a.nk = a.ntaps * a.cpt;
@@ -454,8 +523,7 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles;
   hipStream_t s = (hipStream_t)stream;
   if (kc == kc128) launch<T, 128>(tile, grid, s, a);
-  else if constexpr (sizeof(T) == 2) launch<T, 64>(tile, grid, s, a);
-  else return RS_EINVAL;
+  else launch<T, 64>(tile, grid, s, a);
   return RS_LAUNCH_RESULT();
 }
 
@@ -468,6 +536,19 @@ int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2,
 }
 
 int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+
+extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
+  if (!valid(d)) return RS_EINVAL;
+  return rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[pick_tile(d)]);
+}
+
+extern "C" int rs_conv2d_fwd_bnstats_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2,
+                                        const void* weight, void* out, float* stats_partial, rs_stream_t stream) {
+  if (!stats_partial) return RS_EINVAL;
+  if (dtype == RS_F32) return conv_fwd<float>(d, src1, src2, weight, nullptr, nullptr, nullptr, nullptr, out, stream, stats_partial);
+  if (dtype == RS_BF16) return conv_fwd<bf16_t>(d, src1, src2, weight, nullptr, nullptr, nullptr, nullptr, out, stream, stats_partial);
+  return RS_EINVAL;
+}
 
 extern "C" int rs_conv2d_tile_bf16(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
 

@@ -227,9 +227,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
     for (int c = chunk0; c < chunk1; ++c) {
       const int it = c - chunk0;
       const unsigned char* L = smem + (it & 1) * BUF;
-      // chunk c+1 -> the other buffer (its last readers passed the barrier that ended iteration it-1); past the last
-      // chunk this fetches zeros / the next split's pixels, harmlessly
-      issue_dma(c + 1, (it + 1) & 1, (it + 1) & 1);
+      // chunk c+1 -> the other buffer (its last readers passed the barrier that ended iteration it-1)
+      if (c + 1 < chunk1) issue_dma(c + 1, (it + 1) & 1, (it + 1) & 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         bf16x8 fa[TM], fb[TN];

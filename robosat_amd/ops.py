@@ -111,6 +111,48 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     return out
 
 
+def conv2d_bnstats(src1, weight, src2=None, ups=0, stride=1, pad=0):
+    """Train-mode ``conv -> BatchNorm`` front half: the raw convolution output plus the per-tile partial sums of its
+    BatchNorm statistics, produced in the convolution's epilogue (``rs_conv2d_fwd_bnstats_dt``).
+    Returns (out, partial [tiles,2,Cout] fp32)."""
+
+    d = conv_desc(src1, weight, src2, ups, stride, pad, False, 0, None)
+    act = src1.dtype
+    lib = _lib.lib()
+    out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=src1.device, dtype=act)
+    rows = lib.rs_conv2d_bnstats_rows(ctypes.byref(d))
+    if rows <= 0:
+        raise ValueError("rs_conv2d_bnstats_rows: invalid arguments")
+    partial = torch.empty((rows, 2, d.Cout), device=src1.device, dtype=torch.float32)
+    assert weight.shape[3] == d.C1 + d.C2
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.rs_conv2d_fwd_bnstats_dt(ctypes.byref(d), _dt(src1), _dev(src1, "src1", act), _dev(src2, "src2", act),
+                                      _dev(weight, "weight", act), _dev(out, "out", act), _dev(partial, "partial"), _stream())
+    check(rc, "rs_conv2d_fwd_bnstats_dt")
+    if PROFILE is not None:
+        ev1.record()
+        bf = act == BF16
+        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                        conv_bytes(d, 2 if bf else 4)))
+    return out, partial
+
+
+def bn_finalize_stats(partial, m, gamma, beta, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """(mean, invstd, scale, shift) from ``conv2d_bnstats``'s partial sums; updates the running buffers like bn_train_stats."""
+
+    rows, _, c = partial.shape
+    mean, invstd, scale, shift = (torch.empty(c, device=partial.device, dtype=torch.float32) for _ in range(4))
+    rc = _lib.lib().rs_bn_finalize_stats(
+        _dev(partial, "partial"), rows, m, c, ctypes.c_float(eps), ctypes.c_float(momentum), _dev(gamma, "gamma"),
+        _dev(beta, "beta"), _dev(mean, "mean"), _dev(invstd, "invstd"), _dev(scale, "scale"), _dev(shift, "shift"),
+        _dev(running_mean, "running_mean"), _dev(running_var, "running_var"),
+        _dev(num_batches_tracked, "num_batches_tracked", torch.int64), _workspace(64 * 2 * c * 8, partial.device), _stream())
+    check(rc, "rs_bn_finalize_stats")
+    return mean, invstd, scale, shift
+
+
 def conv_tile_name(d, bf16=False):
     lib = _lib.lib()
     if bf16:

@@ -213,6 +213,38 @@ def test_bn_train_bf16():
     close(nchw(dm), dz * (z.detach() > 0), TOL_BF, "dmasked")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+@pytest.mark.parametrize("case", [(2, 64, 24, 20, 128, 3, 1, 1), (3, 128, 16, 16, 64, 1, 2, 0), (1, 32, 37, 19, 32, 3, 1, 1)],
+                         ids=["128x128", "64x64_s2", "128x32_tail"])
+def test_conv_with_fused_bn_statistics(case, dtype):
+    """rs_conv2d_fwd_bnstats_dt + rs_bn_finalize_stats == rs_conv2d_fwd followed by rs_bn_train_stats (same stored
+    output, statistics of the stored values), and both match torch's batch statistics."""
+    from robosat_amd import ops
+
+    n, cin, h, w, cout, k, stride, pad = case
+    x = q(rnd(n, cin, h, w, seed=1)) if dtype == BF else rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2) * (2.0 / (cin * k * k)) ** 0.5
+    wt = q(wt) if dtype == BF else wt
+    gamma, beta = rnd(cout, seed=3).abs() + 0.5, rnd(cout, seed=4)
+    xd, wd = nhwc(x, dtype), krsc(wt, dtype)
+    y_ref = ops.conv2d(xd, wd, stride=stride, pad=pad)
+    y, partial = ops.conv2d_bnstats(xd, wd, stride=stride, pad=pad)
+    assert torch.equal(y, y_ref)
+    m = y.numel() // cout
+    rm, rv, nbt = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    got = ops.bn_finalize_stats(partial, m, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm, rv, nbt)
+    rm2, rv2, nbt2 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    want = ops.bn_train_stats(y_ref, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm2, rv2, nbt2)
+    for a, b, name in zip(got, want, ("mean", "invstd", "scale", "shift")):
+        close(a.cpu(), b.cpu(), 2e-5, name)
+    close(rm.cpu(), rm2.cpu(), 2e-5, "running_mean")
+    close(rv.cpu(), rv2.cpu(), 2e-5, "running_var")
+    assert int(nbt) == 1 == int(nbt2)
+    yf = nchw(y)
+    close(got[0].cpu(), yf.mean((0, 2, 3)), 1e-4, "mean vs torch")
+    close(got[1].cpu(), 1 / torch.sqrt(yf.var((0, 2, 3), unbiased=False) + 1e-5), 1e-4, "invstd vs torch")
+
+
 def test_pool_upsample_final_bf16():
     from robosat_amd import ops
 

@@ -248,6 +248,18 @@ int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float e
                          float* running_var, long long* num_batches_tracked, void* workspace, rs_stream_t stream);
 /* (workspace: 64 * 2 * C doubles, optional -- enables the parallel first-level reduction when rows > 256) */
 
+/* The same fusion for BatchNorm's BACKWARD (conv -> bn -> relu read right to left): the data-gradient convolution that
+ * produces g = d loss / d z (rs_conv2d_fwd semantics on `dy` with rs_pack_dgrad_weight weights, optional residual,
+ * relu_mask = z) also accumulates, per M tile, sum g and sum g * xhat with xhat = (bn_y - bn_mean) * bn_invstd;
+ * rs_bn_bwd_from_partials_dt then needs one streaming pass (dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)))
+ * instead of rs_bn_bwd's two.  workspace: 64*2*C doubles + 3*C floats. */
+int rs_conv2d_dgrad_bnstats_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight, const void* residual,
+                               const void* relu_mask, const void* bn_y, const float* bn_mean, const float* bn_invstd,
+                               void* out, float* stats_partial, rs_stream_t stream);
+int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const float* mean, const float* invstd, const float* gamma,
+                               void* dy, float* dgamma, float* dbeta, const float* partial, long rows, int dtype, long M,
+                               int C, void* workspace, rs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Device-side input / output of `rs predict`: only bytes cross PCIe.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 5
+ABI_VERSION = 6
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -85,6 +85,8 @@ SIGNATURES = {
     "rs_conv2d_bnstats_rows": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_fwd_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P]),
     "rs_bn_finalize_stats": (c_int, [P, c_long, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "rs_conv2d_dgrad_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),
+    "rs_bn_bwd_from_partials_dt": (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, c_long, c_int, P, P]),
     # device-side predict input / output (N1)
     "rs_u8_to_nhwc4_norm": (c_int, [P, P, POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, P]),
     "rs_final_conv1x1_quantize_dt": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -200,24 +200,39 @@ def _backward(net, tape, dlogits, arena):
     skip_grad = {id(r.layer2[0]): g_enc1, id(r.layer3[0]): g_enc2, id(r.layer4[0]): g_enc3}
     layer_heads = {id(r.layer1[0]), id(r.layer2[0]), id(r.layer3[0]), id(r.layer4[0])}
 
-    for rec in reversed(tape.blocks):
+    def dgrad_into_bn(dy, conv, out_hw, y, st, z, residual=None):
+        """Gradient at the OUTPUT of a BatchNorm+ReLU (z) from the convolution that consumed z, with the ReLU mask and
+        BatchNorm's two backward reductions done in the convolution's epilogue: returns (g, partial)."""
+        wd = ops.pack_dgrad_weight(conv.krsc(), dy.dtype)
+        return ops.conv2d_dgrad_bnstats(dy, wd, out_hw, y, st[0], st[1], ups=2 if conv.stride == 2 else 0,
+                                        pad=conv.k - 1 - conv.padding, residual=residual, relu_mask=z)
+
+    g_partial = None  # partial sums riding with g when a fused dgrad produced it
+    blocks = tape.blocks
+    for bi in range(len(blocks) - 1, -1, -1):
+        rec = blocks[bi]
         blk, h = rec["blk"], rec["h"]
         hw_in = (h.shape[1], h.shape[2])
-        dy3, _, _, gm = ops.bn_bwd(g, rec["z3"], rec["y3"], rec["st3"][0], rec["st3"][1], blk.bn3.weight.detach(),
-                                   want_masked=True, **bn_grads(blk.bn3))
+        if g_partial is None:  # g arrives unmasked from the decoder: the two-pass kernel masks, reduces and applies
+            dy3, _, _, gm = ops.bn_bwd(g, rec["z3"], rec["y3"], rec["st3"][0], rec["st3"][1], blk.bn3.weight.detach(),
+                                       want_masked=True, **bn_grads(blk.bn3))
+        else:  # g is already masked (it IS the residual-branch gradient) and its reductions are done
+            dy3, _, _ = ops.bn_bwd_from_partials(g, rec["y3"], rec["st3"][0], rec["st3"][1], blk.bn3.weight.detach(), g_partial,
+                                                 **bn_grads(blk.bn3))
+            gm = g
         del g
         ops.conv2d_wgrad(dy3, rec["z2"], 1, 1, out=arena.conv(blk.conv3))
-        dz2 = _dgrad(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]))
+        g2, p2 = dgrad_into_bn(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]), rec["y2"], rec["st2"], rec["z2"])
         del dy3
-        dy2, _, _ = ops.bn_bwd(dz2, rec["z2"], rec["y2"], rec["st2"][0], rec["st2"][1], blk.bn2.weight.detach(),
-                               **bn_grads(blk.bn2))
-        del dz2
+        dy2, _, _ = ops.bn_bwd_from_partials(g2, rec["y2"], rec["st2"][0], rec["st2"][1], blk.bn2.weight.detach(), p2,
+                                             **bn_grads(blk.bn2))
+        del g2
         ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=arena.conv(blk.conv2))
-        dz1 = _dgrad(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]))
+        g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"])
         del dy2
-        dy1, _, _ = ops.bn_bwd(dz1, rec["z1"], rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(),
-                               **bn_grads(blk.bn1))
-        del dz1
+        dy1, _, _ = ops.bn_bwd_from_partials(g1, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), p1,
+                                             **bn_grads(blk.bn1))
+        del g1
         ops.conv2d_wgrad(dy1, h, 1, 1, out=arena.conv(blk.conv1))
         extra = skip_grad.get(id(blk))
         if blk.downsample is not None:
@@ -229,7 +244,11 @@ def _backward(net, tape, dlogits, arena):
         else:
             assert extra is None
             res = gm
-        g = _dgrad(dy1, blk.conv1, hw_in, residual=res)
+        if bi > 0:  # h is the previous bottleneck's z3 = relu(bn3(y3) + identity): fuse its mask + reductions
+            prev = blocks[bi - 1]
+            g, g_partial = dgrad_into_bn(dy1, blk.conv1, hw_in, prev["y3"], prev["st3"], prev["z3"], residual=res)
+        else:  # h is the stem's pooled output
+            g, g_partial = _dgrad(dy1, blk.conv1, hw_in, residual=res), None
         del dy1, res, gm
         if id(blk) in layer_heads:
             arena.flush()  # one bucket per finished ResNet layer

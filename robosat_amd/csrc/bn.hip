@@ -388,6 +388,38 @@ extern "C" int rs_bn_bwd_dt(const void* dz, const void* zmask, const void* y, co
   return RS_EINVAL;
 }
 
+// BatchNorm backward whose two reductions were already done by the data-gradient convolution that produced g
+// (rs_conv2d_dgrad_bnstats_dt): finalize the per-tile partials, then ONE streaming pass dy = k1*g - k2 - k3*(y - mean).
+extern "C" int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const float* mean, const float* invstd,
+                                          const float* gamma, void* dy, float* dgamma, float* dbeta, const float* partial,
+                                          long rows, int dtype, long M, int C, void* workspace, rs_stream_t stream) {
+  if (!g || !y || !mean || !invstd || !gamma || !dy || !dgamma || !dbeta || !partial || !workspace || rows <= 0 ||
+      rows >= (1L << 31) || M <= 0 || C <= 0 || (C & 3))
+    return RS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  // workspace: [64][2][C] doubles (first-level sums) + 3*C floats (coefficients)
+  double* part2 = reinterpret_cast<double*>(workspace);
+  float* coef = reinterpret_cast<float*>(part2 + 64L * 2 * C);
+  int slices = (int)((rows + 63) / 64);
+  if (slices > 64) slices = 64;
+  const int rps = (int)((rows + slices - 1) / slices);
+  slices = (int)((rows + rps - 1) / rps);
+  bn_partial_reduce_kernel<<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2);
+  bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, gamma, invstd, dgamma, dbeta, coef);
+  const long total4 = M * (C / 4);
+  if (dtype == RS_F32)
+    bn_bwd_apply_kernel<float><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const float*>(g), nullptr,
+                                                                    reinterpret_cast<const float*>(y), mean, coef,
+                                                                    reinterpret_cast<float*>(dy), nullptr, total4, C / 4);
+  else if (dtype == RS_BF16)
+    bn_bwd_apply_kernel<bf16_t><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(g), nullptr,
+                                                                     reinterpret_cast<const bf16_t*>(y), mean, coef,
+                                                                     reinterpret_cast<bf16_t*>(dy), nullptr, total4, C / 4);
+  else
+    return RS_EINVAL;
+  return RS_LAUNCH_RESULT();
+}
+
 extern "C" int rs_bn_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
                          const float* gamma, float* dy, float* dmasked, float* dgamma, float* dbeta, long M, int C,
                          void* workspace, rs_stream_t stream) {

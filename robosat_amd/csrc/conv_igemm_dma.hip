@@ -47,6 +47,12 @@ struct ConvArgsT {
   const T* mask;
   T* out;
   float* stats;  // optional [M tiles][2][Cout]: per-tile sum / sum of squares of the STORED output (train-mode BatchNorm)
+  // optional (data-gradient launches, with stats): the output is g = d loss / d z of a BatchNorm layer (ReLU mask
+  // applied); the partial rows then hold sum g and sum g * xhat, xhat = (bn_y - bn_mean) * bn_invstd: the two reductions
+  // of BatchNorm's backward, which otherwise cost a separate pass over (dz, z, y)
+  const T* bn_y;
+  const float* bn_mean;
+  const float* bn_invstd;
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles, ntaps;
@@ -304,9 +310,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     sc[e] = p.scale ? p.scale[col + e] : 1.f;
     sh[e] = p.shift ? p.shift[col + e] : 0.f;
   }
-  float st0[EPP], st1[EPP];  // BatchNorm forward statistics of this thread's rows (only when p.stats)
+  float st0[EPP], st1[EPP];  // BatchNorm statistics of this thread's rows (only when p.stats)
+  float bmu[EPP], bis[EPP];
 #pragma unroll
-  for (int e = 0; e < EPP; ++e) st0[e] = st1[e] = 0.f;
+  for (int e = 0; e < EPP; ++e) {
+    st0[e] = st1[e] = 0.f;
+    bmu[e] = p.bn_y ? p.bn_mean[col + e] : 0.f;
+    bis[e] = p.bn_y ? p.bn_invstd[col + e] : 0.f;
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (tm > 0) __syncthreads();  // the previous pass has been read out
@@ -359,10 +370,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
         if (p.stats) {
           float w[EPP];
           Piece<T>::round(v, w);  // statistics of the values as stored (bf16-rounded on the bf16 path)
+          if (p.bn_y) {
+            float yv[EPP];
+            Piece<T>::load(p.bn_y + o, yv);
 #pragma unroll
-          for (int e = 0; e < EPP; ++e) {
-            st0[e] += w[e];
-            st1[e] += w[e] * w[e];
+            for (int e = 0; e < EPP; ++e) {
+              st0[e] += w[e];
+              st1[e] += w[e] * ((yv[e] - bmu[e]) * bis[e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) {
+              st0[e] += w[e];
+              st1[e] += w[e] * w[e];
+            }
           }
         }
       }
@@ -467,7 +488,8 @@ void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
 template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
-             float* stats = nullptr) {
+             float* stats = nullptr, const void* bn_y = nullptr, const float* bn_mean = nullptr,
+             const float* bn_invstd = nullptr) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
   constexpr long ES = (long)sizeof(T);
@@ -481,6 +503,9 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.mask = reinterpret_cast<const T*>(relu_mask);
   a.out = reinterpret_cast<T*>(out);
   a.stats = stats;
+  a.bn_y = reinterpret_cast<const T*>(bn_y);
+  a.bn_mean = bn_mean;
+  a.bn_invstd = bn_invstd;
   a.N = d->N;
   a.Hs = d->Hs;
   a.Ws = d->Ws;
@@ -540,6 +565,20 @@ int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : R
 extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
   return rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[pick_tile(d)]);
+}
+
+extern "C" int rs_conv2d_dgrad_bnstats_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight,
+                                          const void* residual, const void* relu_mask, const void* bn_y,
+                                          const float* bn_mean, const float* bn_invstd, void* out, float* stats_partial,
+                                          rs_stream_t stream) {
+  if (!stats_partial || !bn_y || !bn_mean || !bn_invstd || (d && d->C2 != 0)) return RS_EINVAL;
+  if (dtype == RS_F32)
+    return conv_fwd<float>(d, dy, nullptr, weight, nullptr, nullptr, residual, relu_mask, out, stream, stats_partial, bn_y,
+                           bn_mean, bn_invstd);
+  if (dtype == RS_BF16)
+    return conv_fwd<bf16_t>(d, dy, nullptr, weight, nullptr, nullptr, residual, relu_mask, out, stream, stats_partial, bn_y,
+                            bn_mean, bn_invstd);
+  return RS_EINVAL;
 }
 
 extern "C" int rs_conv2d_fwd_bnstats_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2,

@@ -25,6 +25,8 @@
 //            channel's column.  Two reads = one 8-pixel fragment.  With the swizzle the four rows of a read sit in four
 //            different 64-byte bank quarters: conflict free.
 //   split-P: partial tiles -> workspace [split][Cout][K], summed by reduce.hip: deterministic, no atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -88,11 +90,13 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
   return __builtin_bit_cast(bf16x8, v);
 }
 
-constexpr int PK = 64;  // pixels per chunk
 
-template <int BMo, int BNo, int WGM, int WGN>
+// PK = pixels per chunk: 64 (4 k-steps per barrier, 64 KB of LDS for the 128x128 tile: 2 blocks per CU) or 32 (2 k-steps,
+// half the LDS: 4 blocks per CU -- the short reductions of the small layers)
+template <int BMo, int BNo, int WGM, int WGN, int PK>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const WgradArgsB p) {
   constexpr int NW = WGM * WGN;          // waves
+  constexpr int NS = PK / 16;            // MFMA k-steps per chunk
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int ROWA = BMo * 2, ROWB_ = BNo * 2;        // bytes per LDS row (one pixel)
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
       // chunk c+1 -> the other buffer (its last readers passed the barrier that ended iteration it-1)
       if (c + 1 < chunk1) issue_dma(c + 1, (it + 1) & 1, (it + 1) & 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         bf16x8 fa[TM], fb[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
 }
 
 struct Plan {
-  int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split;
+  int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split, pk;
   long K;
 };
 
@@ -305,9 +309,17 @@ Plan plan(const rs_conv_desc* d) {
   pl.tiles_co = d->Cout / pl.bmo;
   pl.tiles_k = pl.taps * pl.tiles_ci;
   const long tiles = (long)pl.tiles_co * pl.tiles_k;
+  // pixels per chunk: RS_WGRAD_PK=32|64 overrides (measurement knob); 32-wide tiles only come with 64
+  static const int forced = [] {
+    const char* e = getenv("RS_WGRAD_PK");
+    return e ? atoi(e) : 0;
+  }();
+  pl.pk = (forced == 32 || forced == 64) ? forced : 64;
+  if (pl.bmo == 32 || pl.bno == 32) pl.pk = 64;
+  const int PK = pl.pk;
   const long chunks = (M + PK - 1) / PK;
-  long s = (1024 + tiles - 1) / tiles;  // aim at >= 1024 blocks ...
-  const long smax = (chunks + 7) / 8;   // ... of at least 8 chunks (512 pixels) each
+  long s = (1024 + tiles - 1) / tiles;            // aim at >= 1024 blocks ...
+  const long smax = (chunks * PK / 64 + 7) / 8;   // ... of at least 512 pixels each
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   // 32-bit byte offsets inside a split: shrink the splits until dy and the input both fit
@@ -384,14 +396,24 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   a.chunks_per_split = pl.chunks_per_split;
   const int grid = pl.tiles_co * pl.tiles_k * pl.splits;
   hipStream_t s = (hipStream_t)stream;
-  switch (pl.variant) {
-    case V128x128: conv_wgrad_bf16<128, 128, 2, 2><<<grid, 256, 0, s>>>(a); break;
-    case V128x64: conv_wgrad_bf16<128, 64, 2, 2><<<grid, 256, 0, s>>>(a); break;
-    case V64x128: conv_wgrad_bf16<64, 128, 2, 2><<<grid, 256, 0, s>>>(a); break;
-    case V64x64: conv_wgrad_bf16<64, 64, 2, 2><<<grid, 256, 0, s>>>(a); break;
-    case V32x128: conv_wgrad_bf16<32, 128, 1, 4><<<grid, 256, 0, s>>>(a); break;
-    case V32x32: conv_wgrad_bf16<32, 32, 1, 1><<<grid, 64, 0, s>>>(a); break;
-    default: return RS_EINVAL;
+  if (pl.pk == 32) {
+    switch (pl.variant) {
+      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
+      default: return RS_EINVAL;
+    }
+  } else {
+    switch (pl.variant) {
+      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
+      case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64><<<grid, 256, 0, s>>>(a); break;
+      case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64><<<grid, 64, 0, s>>>(a); break;
+      default: return RS_EINVAL;
+    }
   }
   const int rc = RS_LAUNCH_RESULT();
   if (rc) return rc;

@@ -139,6 +139,56 @@ def conv2d_bnstats(src1, weight, src2=None, ups=0, stride=1, pad=0):
     return out, partial
 
 
+def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0, residual=None, relu_mask=None):
+    """Data-gradient convolution whose output g is the gradient at a BatchNorm+ReLU output: ``rs_conv2d_fwd`` semantics
+    (``wd`` = packed dgrad weights, optional residual, relu_mask = z) + per-tile partial sums of BatchNorm's two backward
+    reductions (``rs_conv2d_dgrad_bnstats_dt``).  Returns (g, partial [tiles,2,C])."""
+
+    d = conv_desc(dy, wd, None, ups, 1, pad, False, 0, out_hw)
+    act = dy.dtype
+    lib = _lib.lib()
+    out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=dy.device, dtype=act)
+    assert bn_y.shape == out.shape
+    rows = lib.rs_conv2d_bnstats_rows(ctypes.byref(d))
+    if rows <= 0:
+        raise ValueError("rs_conv2d_bnstats_rows: invalid arguments")
+    partial = torch.empty((rows, 2, d.Cout), device=dy.device, dtype=torch.float32)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.rs_conv2d_dgrad_bnstats_dt(
+        ctypes.byref(d), _dt(dy), _dev(dy, "dy", act), _dev(wd, "weight", act), _dev(residual, "residual", act),
+        _dev(relu_mask, "relu_mask", act), _dev(bn_y, "bn_y", act), _dev(bn_mean, "bn_mean"), _dev(bn_invstd, "bn_invstd"),
+        _dev(out, "out", act), _dev(partial, "partial"), _stream())
+    check(rc, "rs_conv2d_dgrad_bnstats_dt")
+    if PROFILE is not None:
+        ev1.record()
+        bf = act == BF16
+        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                        conv_bytes(d, 2 if bf else 4)))
+    return out, partial
+
+
+def bn_bwd_from_partials(g, y, mean, invstd, gamma, partial, dgamma=None, dbeta=None):
+    """BatchNorm backward from ``conv2d_dgrad_bnstats``'s partial sums: returns (dy, dgamma, dbeta); ``g`` is already
+    masked by the ReLU, so it is also the gradient of a residual branch."""
+
+    c = y.shape[-1]
+    m = y.numel() // c
+    dy = torch.empty_like(y)
+    if dgamma is None:
+        dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
+    if dbeta is None:
+        dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
+    t = y.dtype
+    rc = _lib.lib().rs_bn_bwd_from_partials_dt(
+        _dev(g, "g", t), _dev(y, "y", t), _dev(mean, "mean"), _dev(invstd, "invstd"), _dev(gamma, "gamma"), _dev(dy, "dy", t),
+        _dev(dgamma, "dgamma"), _dev(dbeta, "dbeta"), _dev(partial, "partial"), partial.shape[0], _dt(y), m, c,
+        _workspace(64 * 2 * c * 8 + 3 * c * 4, y.device), _stream())
+    check(rc, "rs_bn_bwd_from_partials_dt")
+    return dy, dgamma, dbeta
+
+
 def bn_finalize_stats(partial, m, gamma, beta, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
     """(mean, invstd, scale, shift) from ``conv2d_bnstats``'s partial sums; updates the running buffers like bn_train_stats."""
 

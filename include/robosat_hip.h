@@ -191,8 +191,8 @@ int rs_confusion_counts(const float* scores, const long long* targets, unsigned 
 /* ------------------------------------------------------------------------------------------------------------
  * bf16 path (BASELINE configs[2]: rs train bf16): the same operators with activations stored as bf16 NHWC, fp32
  * master weights cast per step, fp32 accumulation (v_mfma_f32_32x32x16_bf16), fp32 statistics / gradients of
- * parameters / logits / losses.  The 7x7 stem + bn1 stay on the fp32 kernels (0.7 % of the FLOPs); the precision
- * boundary is the stem max-pool (fp32 in, bf16 out; bf16 dy, fp32 dx in the backward).
+ * parameters / logits / losses.  The image is cast to bf16 on upload (rs_nchw_to_nhwc4_bf16); the 7x7 stem has its own
+ * bf16 kernels (rs_stem_conv_*_bf16).
  *
  * `_dt` variants: same contract as the fp32 entry point of the same name, activations typed by `dtype`
  * (RS_F32 | RS_BF16); per-channel vectors, parameter gradients, logits and workspaces are always fp32.
@@ -215,6 +215,18 @@ int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, const rs_bf16
  * rs_pack_dgrad_weight with a bf16 result. */
 int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stream);
 int rs_pack_dgrad_weight_bf16(const float* w_krsc, rs_bf16* out, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
+
+/* The 7x7/2 stem (resnet.conv1, unet.py:122) in bf16: x NHWC4 bf16 [N][H][W][4] (rs_nchw_to_nhwc4_bf16), weights packed
+ * bf16 [64][7][8][4] (rs_pack_stem_weight_bf16 from the fp32 KRSC master), out [N][H/2][W/2][64] bf16 with the optional
+ * eval-BatchNorm scale/shift + ReLU epilogue; rs_stem_conv_wgrad_bf16 returns the PACKED fp32 gradient [64][7][8][4]
+ * (-> rs_unpack_stem_weight).  H, W multiples of 32.  One block owns an output patch and all 49 taps (stem_bf16.hip). */
+int rs_nchw_to_nhwc4_bf16(const float* x, rs_bf16* y, int N, int C, int H, int W, rs_stream_t stream);
+int rs_pack_stem_weight_bf16(const float* w_krsc, rs_bf16* packed, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
+int rs_stem_conv_fwd_bf16(const rs_bf16* x, const rs_bf16* w_packed, const float* scale, const float* shift, rs_bf16* out,
+                          int N, int H, int W, int relu, rs_stream_t stream);
+long rs_stem_conv_wgrad_bf16_workspace_bytes(int N, int H, int W);
+int rs_stem_conv_wgrad_bf16(const rs_bf16* dy, const rs_bf16* x, float* dw_packed, int N, int H, int W, void* workspace,
+                            rs_stream_t stream);
 
 int rs_maxpool2d_fwd_dt(const void* x, int x_dtype, void* y, int y_dtype, uint8_t* argmax, int N, int H, int W, int C, int k,
                         int stride, int pad, int Ho, int Wo, rs_stream_t stream);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 6
+ABI_VERSION = 7
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -87,6 +87,11 @@ SIGNATURES = {
     "rs_bn_finalize_stats": (c_int, [P, c_long, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rs_conv2d_dgrad_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),
     "rs_bn_bwd_from_partials_dt": (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, c_long, c_int, P, P]),
+    "rs_nchw_to_nhwc4_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_pack_stem_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_stem_conv_fwd_bf16": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_stem_conv_wgrad_bf16_workspace_bytes": (c_long, [c_int, c_int, c_int]),
+    "rs_stem_conv_wgrad_bf16": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     # device-side predict input / output (N1)
     "rs_u8_to_nhwc4_norm": (c_int, [P, P, POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, P]),
     "rs_final_conv1x1_quantize_dt": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

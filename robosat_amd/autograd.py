@@ -99,12 +99,15 @@ def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
 def _forward(net, x, tape):
     r = net.resnet
     t = tape.t
-    dt = net.compute_dtype  # fp32, or bf16 activations from the stem pool on (stem conv + bn1 stay fp32)
-    x4 = ops.nchw_to_nhwc4(x)
+    dt = net.compute_dtype  # fp32 or bf16 activations (the image is cast on upload)
+    x4 = ops.nchw_to_nhwc4(x, dt)
     t["x4"] = x4
-    y0 = ops.conv2d(x4, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, stem=7)
+    if dt == torch.bfloat16:
+        y0 = ops.stem_conv_bf16(x4, ops.pack_stem_weight(r.conv1.krsc(), dt))
+    else:
+        y0 = ops.conv2d(x4, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, stem=7)
     z0, st0 = _bn_train(r.bn1, y0)
-    p0, am0 = ops.maxpool2d(z0, 3, 2, 1, want_argmax=True, out_dtype=dt)
+    p0, am0 = ops.maxpool2d(z0, 3, 2, 1, want_argmax=True)
     t.update(y0=y0, st0=st0, z0=z0, am0=am0)
 
     h = p0
@@ -254,9 +257,12 @@ def _backward(net, tape, dlogits, arena):
             arena.flush()  # one bucket per finished ResNet layer
 
     # ---- stem -------------------------------------------------------------------------------------------------
-    dz0 = ops.maxpool2d_bwd(g, t["am0"], tuple(t["z0"].shape), 3, 2, 1, out_dtype=torch.float32)  # back to the fp32 stem
+    dz0 = ops.maxpool2d_bwd(g, t["am0"], tuple(t["z0"].shape), 3, 2, 1)
     dy0, _, _ = ops.bn_bwd(dz0, t["z0"], t["y0"], t["st0"][0], t["st0"][1], r.bn1.weight.detach(), **bn_grads(r.bn1))
-    dwp = ops.conv2d_wgrad(dy0, t["x4"], 7, 7, stride=2, pad=3, stem=7)
+    if dy0.dtype == torch.bfloat16:
+        dwp = ops.stem_conv_wgrad_bf16(dy0, t["x4"])
+    else:
+        dwp = ops.conv2d_wgrad(dy0, t["x4"], 7, 7, stride=2, pad=3, stem=7)
     ops.unpack_stem_weight(dwp, 7, net.in_channels, out=arena.conv(r.conv1))
     arena.finish()
     return arena.grads

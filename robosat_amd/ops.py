@@ -218,21 +218,59 @@ def cast_bf16(t):
     return out
 
 
-def pack_stem_weight(w_krsc):
-    """[Cout,kh,kw<=8,Cin<=4] -> [Cout,kh,8,4] (zero padded)."""
+def pack_stem_weight(w_krsc, dtype=torch.float32):
+    """fp32 [Cout,kh,kw<=8,Cin<=4] -> [Cout,kh,8,4] (zero padded) in ``dtype``."""
 
     cout, kh, kw, cin = w_krsc.shape
-    out = torch.empty((cout, kh, 8, 4), device=w_krsc.device, dtype=torch.float32)
-    check(_lib.lib().rs_pack_stem_weight(_dev(w_krsc, "w"), _dev(out, "out"), cout, kh, kw, cin, _stream()),
-          "rs_pack_stem_weight")
+    out = torch.empty((cout, kh, 8, 4), device=w_krsc.device, dtype=dtype)
+    fn = _lib.lib().rs_pack_stem_weight_bf16 if dtype == BF16 else _lib.lib().rs_pack_stem_weight
+    check(fn(_dev(w_krsc, "w"), _dev(out, "out", dtype), cout, kh, kw, cin, _stream()), "rs_pack_stem_weight")
     return out
 
 
-def nchw_to_nhwc4(x):
+def nchw_to_nhwc4(x, dtype=torch.float32):
     n, c, h, w = x.shape
-    out = torch.empty((n, h, w, 4), device=x.device, dtype=torch.float32)
-    check(_lib.lib().rs_nchw_to_nhwc4(_dev(x, "x"), _dev(out, "out"), n, c, h, w, _stream()), "rs_nchw_to_nhwc4")
+    out = torch.empty((n, h, w, 4), device=x.device, dtype=dtype)
+    fn = _lib.lib().rs_nchw_to_nhwc4_bf16 if dtype == BF16 else _lib.lib().rs_nchw_to_nhwc4
+    check(fn(_dev(x, "x"), _dev(out, "out", dtype), n, c, h, w, _stream()), "rs_nchw_to_nhwc4")
     return out
+
+
+def stem_conv_bf16(x4, w_packed, scale=None, shift=None, relu=False):
+    """resnet.conv1 (7x7/2, pad 3) on NHWC4 bf16 input with packed bf16 weights [64,7,8,4] -> [N,H/2,W/2,64] bf16."""
+
+    n, h, w, _ = x4.shape
+    out = torch.empty((n, h // 2, w // 2, 64), device=x4.device, dtype=BF16)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_stem_conv_fwd_bf16(_dev(x4, "x4", BF16), _dev(w_packed, "w", BF16), _dev(scale, "scale"),
+                                          _dev(shift, "shift"), _dev(out, "out", BF16), n, h, w, int(relu), _stream())
+    check(rc, "rs_stem_conv_fwd_bf16")
+    if PROFILE is not None:
+        ev1.record()
+        flops = 2.0 * n * 64 * 3 * 49 * (h // 2) * (w // 2)
+        PROFILE.append(("stem_conv_bf16", flops, (3, 64, 7, 2, 0, h // 2, w // 2), ev0, ev1, 2 * (x4.numel() + out.numel())))
+    return out
+
+
+def stem_conv_wgrad_bf16(dy, x4):
+    """Packed fp32 gradient [64,7,8,4] of the stem filter from bf16 dy [N,H/2,W/2,64] and the NHWC4 bf16 input."""
+
+    n, h, w, _ = x4.shape
+    lib = _lib.lib()
+    dw = torch.empty((64, 7, 8, 4), device=dy.device, dtype=torch.float32)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.rs_stem_conv_wgrad_bf16(_dev(dy, "dy", BF16), _dev(x4, "x4", BF16), _dev(dw, "dw"), n, h, w,
+                                     _workspace(lib.rs_stem_conv_wgrad_bf16_workspace_bytes(n, h, w), dy.device), _stream())
+    check(rc, "rs_stem_conv_wgrad_bf16")
+    if PROFILE is not None:
+        ev1.record()
+        flops = 2.0 * n * 64 * 3 * 49 * (h // 2) * (w // 2)
+        PROFILE.append(("stem_wgrad_bf16", flops, (3, 64, 7, 2, 0, h // 2, w // 2), ev0, ev1, 2 * (x4.numel() + dy.numel())))
+    return dw
 
 
 def u8_to_nhwc4_norm(img, mean, std):

@@ -265,6 +265,8 @@ class UNet(nn.Module):
         if not images_u8.is_cuda:
             raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(images_u8.device))
         x4 = ops.u8_to_nhwc4_norm(images_u8.contiguous(), list(mean)[:self.in_channels], list(std)[:self.in_channels])
+        if self.compute_dtype == torch.bfloat16:
+            x4 = x4.to(torch.bfloat16)  # (device-side cast of the 4-channel image; the stem then runs in bf16)
         return self._forward_eval(None, softmax=False, x4=x4, quantize_overlap=overlap)
 
     def _forward_eval(self, x, softmax, x4=None, quantize_overlap=None):
@@ -275,11 +277,14 @@ class UNet(nn.Module):
                 raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
             assert x.size(1) == self.in_channels
             x = x.detach().float().contiguous()
-            x4 = ops.nchw_to_nhwc4(x)
+            x4 = ops.nchw_to_nhwc4(x, dt)
         h = x4
         sc, sh = r.bn1.folded()
-        h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7)
-        h = ops.maxpool2d(h, 3, 2, 1, out_dtype=dt)
+        if dt == torch.bfloat16:
+            h = ops.stem_conv_bf16(h, ops.pack_stem_weight(r.conv1.krsc(), dt), scale=sc, shift=sh, relu=True)
+        else:
+            h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7)
+        h = ops.maxpool2d(h, 3, 2, 1)
 
         enc = []
         for layer in self._blocks():

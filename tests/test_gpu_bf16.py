@@ -245,6 +245,31 @@ def test_conv_with_fused_bn_statistics(case, dtype):
     close(got[1].cpu(), 1 / torch.sqrt(yf.var((0, 2, 3), unbiased=False) + 1e-5), 1e-4, "invstd vs torch")
 
 
+@pytest.mark.parametrize("cin,n,h,w", [(3, 2, 64, 96), (4, 1, 128, 64), (3, 3, 32, 32)])
+def test_stem_bf16(cin, n, h, w):
+    """resnet.conv1 7x7/2 in bf16: forward (+ folded-BN/ReLU epilogue) and weight gradient vs fp32 PyTorch on bf16-rounded
+    operands (reference unet.py:122)."""
+    from robosat_amd import ops
+
+    x = q(rnd(n, cin, h, w, seed=14))
+    wt = q(rnd(64, cin, 7, 7, seed=15) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=2, padding=3)
+    x4 = ops.nchw_to_nhwc4(x.to(DEV), BF)
+    assert x4.dtype == BF and x4.shape == (n, h, w, 4)
+    assert torch.equal(x4[..., :cin].float().cpu(), x.permute(0, 2, 3, 1))
+    wp = ops.pack_stem_weight(krsc(wt.detach(), torch.float32), BF)
+    got = ops.stem_conv_bf16(x4, wp)
+    close(nchw(got), y.detach(), TOL_BF, "stem fwd")
+    sc, sh = rnd(64, seed=16), rnd(64, seed=17)
+    got2 = ops.stem_conv_bf16(x4, wp, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    close(nchw(got2), F.relu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), TOL_BF, "stem fwd epilogue")
+    gy = q(rnd(*y.shape, seed=18))
+    y.backward(gy)
+    dwp = ops.stem_conv_wgrad_bf16(nhwc(gy), x4)
+    dw = ops.unpack_stem_weight(dwp, 7, cin)
+    close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32, "stem wgrad")
+
+
 def test_pool_upsample_final_bf16():
     from robosat_amd import ops
 
@@ -340,7 +365,7 @@ class _RoundBF16(torch.autograd.Function):
 
 def _oracle_grads(loss_name, x, t, wts, emulate_bf16):
     """fp32 CPU oracle train step; with ``emulate_bf16`` every activation the bf16 path stores (conv / BN / ReLU / pool
-    outputs after the fp32 stem) is rounded to bf16, forward and backward: the CALIBRATION of what bf16 storage alone does
+    outputs, and the uploaded image) is rounded to bf16, forward and backward: the CALIBRATION of what bf16 storage alone does
     to the gradients of this network at this batch size."""
 
     ref = R.UNetRef(2)
@@ -348,9 +373,9 @@ def _oracle_grads(loss_name, x, t, wts, emulate_bf16):
     ref.train()
     if emulate_bf16:
         for name, m in ref.named_modules():
-            stem = name.startswith("resnet.conv1") or name == "resnet.bn1"
-            if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU, torch.nn.MaxPool2d)) and not stem and name != "final":
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU, torch.nn.MaxPool2d)) and name != "final":
                 m.register_forward_hook(lambda mod, inp, out: _RoundBF16.apply(out))
+        x = x.to(BF).float()  # the image is cast on upload
     out = ref(x)
     rl = R.cross_entropy2d(out, t, weight=wts) if loss_name == "CrossEntropy" else R.lovasz2d(out, t)
     rl.backward()

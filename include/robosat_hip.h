@@ -260,6 +260,16 @@ int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float e
                          float* running_var, long long* num_batches_tracked, void* workspace, rs_stream_t stream);
 /* (workspace: 64 * 2 * C doubles, optional -- enables the parallel first-level reduction when rows > 256) */
 
+/* Phase form of DecoderBlock (unet.py:73: conv3x3(pad 1) over interpolate(nearest, x2)): each output parity (oy&1, ox&1)
+ * sees a 2x2 convolution on the SOURCE grid whose taps are sums of the 3x3 taps that fall on the same source pixel, so
+ * the layer is four 2x2 convolutions with 4/9 of the multiply-adds and no duplicated gathers -- same result up to fp32
+ * summation order.  `d` describes the original layer (ups = 1, 3x3, stride 1, pad 1, Ho = 2*Hs); `weight_phase` is
+ * [4][Cout][2][2][C1+C2] from rs_pack_phase_weight_dt (fp32 KRSC master in, `dtype` out).  Epilogue as rs_conv2d_fwd. */
+int rs_pack_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
+int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2, const void* weight_phase,
+                           const float* scale, const float* shift, const void* residual, const void* relu_mask, void* out,
+                           rs_stream_t stream);
+
 /* The same fusion for BatchNorm's BACKWARD (conv -> bn -> relu read right to left): the data-gradient convolution that
  * produces g = d loss / d z (rs_conv2d_fwd semantics on `dy` with rs_pack_dgrad_weight weights, optional residual,
  * relu_mask = z) also accumulates, per M tile, sum g and sum g * xhat with xhat = (bn_y - bn_mean) * bn_invstd;

@@ -129,8 +129,8 @@ def _forward(net, x, tape):
         enc.append(h)
     enc1, enc2, enc3, enc4 = enc
 
-    def up(block, skip, prev=None):
-        return ops.conv2d(skip, block.block.block.krsc(dt), src2=prev, ups=1, pad=1, relu=True)
+    def up(block, skip, prev=None):  # DecoderBlock in phase form: four 2x2 convolutions on the source grid
+        return ops.conv2d_phase(skip, block.block.block.phase(dt), src2=prev, relu=True)
 
     pooled, amc = ops.maxpool2d(enc4, 2, 2, 0, want_argmax=True)
     center = up(net.center, pooled)

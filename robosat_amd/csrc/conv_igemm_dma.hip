@@ -55,7 +55,7 @@ struct ConvArgsT {
   const float* bn_invstd;
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
-  int M, cpt, nk, Kw, relu, ntiles, ntaps;
+  int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -140,7 +140,7 @@ __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
   return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
-constexpr int kMaxTaps = 9;
+constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 data gradient of an upsampled 3x3)
 
 template <typename T, int BM, int BN, int WGM, int WGN, int ROWB>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
@@ -161,52 +161,73 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   constexpr int LDO = BN + 4;         // epilogue staging row (floats)
   constexpr int PIPE = 2 * BUF, STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
   constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
-  constexpr int TABN = (kMaxTaps + 1) * BM;  // (tap, row) -> source pixel
+  constexpr int TABN = (2 * kMaxK + 1) * BM;  // separable gather table (tap row | tap column) x tile row + output rows
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
   static_assert((IA % NW) == 0 && IB >= 1 && (BM % RI) == 0 && (BN % RI) == 0, "DMA instruction split");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAINB + TABN * 4];
-  int* tab = reinterpret_cast<int*>(smem + MAINB);
+  int* taby = reinterpret_cast<int*>(smem + MAINB);  // [kh][BM]: ((n - nfirst)*Hs + iy) * Ws, or -1
+  int* tabx = taby + kMaxK * BM;                     // [kw][BM]: ix, or -1
+  int* orow = tabx + kMaxK * BM;                     // [BM]: output pixel index of the row, or -1 past M
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  const int bid = rs_xcd_remap(blockIdx.x, gridDim.x);
+  int bid = rs_xcd_remap(blockIdx.x, gridDim.x);
+  // phase mode (p.phase4): conv3x3(pad 1) over a nearest-x2 upsampled source == four 2x2 convolutions on the SOURCE grid,
+  // one per output parity (py, px), with pre-summed taps (rs_pack_phase_weight): 4/9 of the MACs and no duplicate
+  // gathers.  Block -> (phase, tile); the problem rows m then enumerate SOURCE pixels (n, a, b) and the output row is
+  // (n, 2a + py, 2b + px).
+  int py = 0, px = 0;
+  if (p.phase4) {
+    py = (bid >> 1) & 1;
+    px = bid & 1;
+    bid >>= 2;
+  }
   const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const int HoWo = p.Ho * p.Wo;
-  const int nfirst = m0 / HoWo;
+  const int Hd = p.phase4 ? p.Hs : p.Ho, Wd = p.phase4 ? p.Ws : p.Wo;  // the grid the rows m enumerate
+  const int HdWd = Hd * Wd;
+  const int nfirst = m0 / HdWd;
   const int ush = p.ups ? 1 : 0;
   const int upar = p.ups == 2 ? 1 : 0;
+  const int pad_y = p.phase4 ? 1 - py : p.pad, pad_x = p.phase4 ? 1 - px : p.pad;
 
-  // ---- (tap, row) -> source pixel table, relative to the tile's first image; -1 = contributes zeros ------------
-  for (int e = tid; e < p.ntaps * BM; e += 256) {
-    const int tap = e / BM, row = e - tap * BM;
+  // ---- separable gather table, relative to the tile's first image: source pixel of (row, tap (r, s)) =
+  //      taby[r][row] + tabx[s][row] when both are >= 0, else the tap contributes zeros ------------------------------
+  for (int e = tid; e < (p.kh + p.kw + 1) * BM; e += 256) {
+    const int t = e / BM, row = e - t * BM;
     const int m = m0 + row;
-    int pix = -1;
+    int v = -1;
     if (m < p.M) {
-      const int n = m / HoWo;
-      const int rem = m - n * HoWo;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
-      const int r = tap / p.kw, s = tap - r * p.kw;
-      const int iy = oy * p.stride - p.pad + r;
-      const int ix = ox * p.stride - p.pad + s;
-      const bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv) && (((iy | ix) & upar) == 0);
-      if (ok) pix = ((n - nfirst) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+      const int n = m / HdWd;
+      const int rem = m - n * HdWd;
+      const int oy = rem / Wd;
+      const int ox = rem - oy * Wd;
+      if (t < p.kh) {
+        const int iy = oy * p.stride - pad_y + t;
+        if (((unsigned)iy < (unsigned)p.Hv) && ((iy & upar) == 0)) v = ((n - nfirst) * p.Hs + (iy >> ush)) * p.Ws;
+      } else if (t < p.kh + p.kw) {
+        const int ix = ox * p.stride - pad_x + (t - p.kh);
+        if (((unsigned)ix < (unsigned)p.Wv) && ((ix & upar) == 0)) v = ix >> ush;
+      } else {
+        v = p.phase4 ? (n * p.Ho + 2 * oy + py) * p.Wo + 2 * ox + px : m;
+      }
     }
-    tab[e] = pix;
+    if (t < p.kh) taby[t * BM + row] = v;
+    else if (t < p.kh + p.kw) tabx[(t - p.kh) * BM + row] = v;
+    else orow[row] = v;
   }
-  for (int e = tid; e < BM; e += 256) tab[p.ntaps * BM + e] = -1;  // the prefetch past the last chunk
 
   const long img1 = (long)p.Hs * p.Ws * p.C1;
   const long img2 = (long)p.Hs * p.Ws * p.C2;
   const __amdgpu_buffer_rsrc_t rsrc1 = rb_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * ES);
   const __amdgpu_buffer_rsrc_t rsrc2 = rb_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * ES);
-  const __amdgpu_buffer_rsrc_t rsrcw = rb_make_rsrc(p.wgt, (long)p.Cout * p.Kw * ES);
+  const __amdgpu_buffer_rsrc_t rsrcw =
+      rb_make_rsrc(p.wgt + (long)(2 * py + px) * p.Cout * p.Kw, (long)p.Cout * p.Kw * ES);  // phase weights follow each other
 
   // ---- LDS-DMA roles.  Instruction ii = wave + 4j copies 1 KiB = RI whole rows: ii < IA pixel rows RI*ii.., else
   //      weight rows RI*(ii-IA)...  Lane l: row ra = l / CPR of the instruction, 16-byte position pp = l % CPR, which
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   for (int j = 0; j < NI; ++j) wrow[j] = ((n0 + RI * (wave + NW * j - IA) + ra) * p.Kw + gp * EPP) * ES;
   __syncthreads();
 
-  int lt = 0, lc = 0, lk = 0;  // next chunk to fetch: tap / channel chunk within the tap / linear index
+  int lr = 0, ls = 0, lc = 0, lk = 0;  // next chunk to fetch: tap row / tap column / channel chunk / linear index
   auto issue_dma = [&](int buf) __attribute__((always_inline)) {
     const unsigned int L = lds0 + buf * BUF;
     const int c0 = lc * KC;
@@ -230,7 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     const int cb = ((first ? c0 : c0 - p.C1) + gp * EPP) * ES;
     int pix[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) pix[j] = (NW * j < IA) ? tab[lt * BM + RI * (wave + NW * j) + ra] : 0;
+    for (int j = 0; j < NI; ++j) {
+      const int row = RI * (wave + NW * j) + ra;
+      const int y = (NW * j < IA) ? taby[lr * BM + row] : 0, x = (NW * j < IA) ? tabx[ls * BM + row] : 0;
+      pix[j] = (y | x) < 0 ? -1 : y + x;
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int ii = wave + NW * j;  // wave-uniform; IA % 4 == 0, so the role depends on j alone
@@ -244,7 +269,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     ++lc;
     const int w1 = (lc == p.cpt) ? 1 : 0;
     lc = w1 ? 0 : lc;
-    lt += w1;
+    ls += w1;
+    const int w2 = (ls == p.kw) ? 1 : 0;
+    ls = w2 ? 0 : ls;
+    lr += w2;
   };
 
   f32x16 acc[TN][TM];  // [cout sub-tile][pixel sub-tile]; D rows = couts, D cols = pixels
@@ -340,9 +368,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
 #pragma unroll 2
     for (int lrow = rr; lrow < WGM * 32; lrow += RPI) {
       const int row = (lrow >> 5) * WM + 32 * tm + (lrow & 31);  // tile row of pass-local row lrow
-      const int m = m0 + row;
-      if (m < p.M) {
-        const long o = (long)m * p.Cout + col;
+      const int opix = orow[row];
+      if (opix >= 0) {
+        const long o = (long)opix * p.Cout + col;
         float v[EPP];
 #pragma unroll
         for (int h = 0; h < EPP / 4; ++h) {
@@ -438,15 +466,19 @@ const int kTileBN[NTILES] = {128, 64, 32, 64};
 bool valid(const rs_conv_desc* d) {
   if (!d) return false;
   if (d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
-  if (d->kh <= 0 || d->kw <= 0 || d->kh * d->kw > kMaxTaps || d->stride <= 0 || d->pad < 0) return false;
+  if (d->kh <= 0 || d->kw <= 0 || d->kh > kMaxK || d->kw > kMaxK || d->stride <= 0 || d->pad < 0) return false;
   if (d->Cout <= 0 || (d->Cout % 32) != 0) return false;
   if (d->ups < 0 || d->ups > 2 || d->stem) return false;
   if (d->C1 <= 0 || (d->C1 % 32) != 0 || d->C2 < 0 || (d->C2 % 32) != 0) return false;
   return true;
 }
 
-int pick_tile(const rs_conv_desc* d) {
-  const long M = (long)d->N * d->Ho * d->Wo;
+bool phase_ok(const rs_conv_desc* d) {
+  return d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
+}
+
+int pick_tile(const rs_conv_desc* d, bool phase4 = false) {
+  const long M = phase4 ? (long)d->N * d->Hs * d->Ws * 4 : (long)d->N * d->Ho * d->Wo;  // (x4: the phases share the grid)
   const long want = 512;  // >= 2 blocks per CU
   if (d->Cout % 128 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 128) >= want) return T128x128;
   if (d->Cout % 64 == 0) {
@@ -458,7 +490,7 @@ int pick_tile(const rs_conv_desc* d) {
 
 // 128-byte rows (4 k-steps per barrier, 2 blocks per CU) or 64-byte rows (2 k-steps per barrier, 4 blocks per CU)?
 // RS_CONV_ROWB=64|128 overrides (measurement knob).
-int pick_rowb(const rs_conv_desc* d, int es) {
+int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false) {
   static const int forced = [] {
     const char* e = getenv("RS_CONV_ROWB");
     return e ? atoi(e) : 0;
@@ -468,9 +500,9 @@ int pick_rowb(const rs_conv_desc* d, int es) {
   // doubled occupancy (>= 2048 blocks) and the K loop is short (<= 16 chunks of 128 bytes) -- the 1x1 convolutions at
   // 64^2..128^2 gain 25-35 % -- or, for fp32, at any K (the 64-cycle fp32 MFMAs hide the extra barriers); long-K layers
   // with few blocks (layer3/4, dec0/dec1) keep 128-byte rows (+8..20 % there).
-  const int tile = pick_tile(d);
+  const int tile = pick_tile(d, phase4);
   const long blocks = (long)rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[tile]) * (d->Cout / kTileBN[tile]);
-  const long nk128 = (long)d->kh * d->kw * (d->C1 + d->C2) * es / 128;
+  const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
   if (blocks >= 2048 && (nk128 <= 16 || es == 4)) return 64;
   return 128;
 }
@@ -489,8 +521,9 @@ template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
              float* stats = nullptr, const void* bn_y = nullptr, const float* bn_mean = nullptr,
-             const float* bn_invstd = nullptr) {
+             const float* bn_invstd = nullptr, bool phase4 = false) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
+  if (phase4 && (!phase_ok(d) || stats)) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
   constexpr long ES = (long)sizeof(T);
   ConvArgsT<T> a;
@@ -511,24 +544,26 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.Ws = d->Ws;
   a.C1 = d->C1;
   a.C2 = d->C2;
-  a.ups = d->ups;
-  a.Hv = d->ups == 0 ? d->Hs : (d->ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
-  a.Wv = d->ups == 0 ? d->Ws : (d->ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
-  a.kh = d->kh;
-  a.kw = d->kw;
+  a.phase4 = phase4 ? 1 : 0;
+  a.ups = phase4 ? 0 : d->ups;  // phase mode gathers on the source grid itself
+  a.Hv = a.ups == 0 ? d->Hs : (a.ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
+  a.Wv = a.ups == 0 ? d->Ws : (a.ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
+  a.kh = phase4 ? 2 : d->kh;
+  a.kw = phase4 ? 2 : d->kw;
   a.stride = d->stride;
   a.pad = d->pad;
   a.Ho = d->Ho;
   a.Wo = d->Wo;
   a.Cout = d->Cout;
-  const long M = (long)d->N * d->Ho * d->Wo;
-  if (M >= (1L << 31)) return RS_EINVAL;
+  if ((long)d->N * d->Ho * d->Wo >= (1L << 31)) return RS_EINVAL;
+  const long M = phase4 ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo;  // rows per phase
   a.M = (int)M;
   {
-    // 32-bit byte offsets relative to the first image of a tile (<= 128 output pixels: 128/(Ho*Wo) + 2 images)
+    // 32-bit byte offsets relative to the first image of a tile (<= 128 rows: 128/(rows per image) + 2 images)
     const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
     const long img_bytes = (long)d->Hs * d->Ws * cmax * ES;
-    const long span = (128 / ((long)d->Ho * d->Wo) + 2) * img_bytes;
+    const long rows_per_image = phase4 ? (long)d->Hs * d->Ws : (long)d->Ho * d->Wo;
+    const long span = (128 / rows_per_image + 2) * img_bytes;
     if (span >= (1L << 31)) return RS_EINVAL;
     if ((long)d->Cout * d->kh * d->kw * (d->C1 + d->C2) * ES >= (1L << 31)) return RS_EINVAL;
   }
@@ -536,16 +571,16 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   // instead of 2, which is what the short-K layers want -- see pick_rowb)
   const int kc128 = 128 / (int)ES;
   const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
-  const int kc = (can128 && pick_rowb(d, (int)ES) == 128) ? kc128 : kc128 / 2;
+  const int kc = (can128 && pick_rowb(d, (int)ES, phase4) == 128) ? kc128 : kc128 / 2;
   a.cpt = (d->C1 + d->C2) / kc;
-  a.ntaps = d->kh * d->kw;
+  a.ntaps = a.kh * a.kw;
   a.nk = a.ntaps * a.cpt;
   a.Kw = a.nk * kc;
   a.relu = d->relu;
 
-  const int tile = pick_tile(d);
+  const int tile = pick_tile(d, phase4);
   a.ntiles = d->Cout / kTileBN[tile];
-  const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles;
+  const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
   hipStream_t s = (hipStream_t)stream;
   if (kc == kc128) launch<T, 128>(tile, grid, s, a);
   else launch<T, 64>(tile, grid, s, a);
@@ -561,6 +596,52 @@ int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2,
 }
 
 int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+
+// ---- phase form of the decoder convolutions ---------------------------------------------------------------------------
+// fp32 KRSC [Cout][3][3][Cin] -> [4 phases (py, px)][Cout][2][2][Cin] in T: tap (r, s) of phase (py, px) is the sum of the
+// original taps that land on the same source pixel: rows {0},{1,2} for py = 0 and {0,1},{2} for py = 1 (same in x).
+template <typename T>
+__global__ void pack_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  long t = i / Cin;
+  const int s = (int)(t & 1), r = (int)((t >> 1) & 1);
+  t >>= 2;
+  const int co = (int)(t % Cout);
+  const int ph = (int)(t / Cout), py = ph >> 1, px = ph & 1;
+  const int ky0 = py == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), ky1 = py == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+  const int kx0 = px == 0 ? (s == 0 ? 0 : 1) : (s == 0 ? 0 : 2), kx1 = px == 0 ? (s == 0 ? 0 : 2) : (s == 0 ? 1 : 2);
+  float acc = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+  out[i] = (T)acc;
+}
+
+extern "C" int rs_pack_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream) {
+  if (!w_krsc || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
+  const long total = 16L * Cout * Cin;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32)
+    pack_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin, total);
+  else if (dtype == RS_BF16)
+    pack_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin, total);
+  else
+    return RS_EINVAL;
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2,
+                                      const void* weight_phase, const float* scale, const float* shift,
+                                      const void* residual, const void* relu_mask, void* out, rs_stream_t stream) {
+  if (dtype == RS_F32)
+    return conv_fwd<float>(d, src1, src2, weight_phase, scale, shift, residual, relu_mask, out, stream, nullptr, nullptr,
+                           nullptr, nullptr, true);
+  if (dtype == RS_BF16)
+    return conv_fwd<bf16_t>(d, src1, src2, weight_phase, scale, shift, residual, relu_mask, out, stream, nullptr, nullptr,
+                            nullptr, nullptr, true);
+  return RS_EINVAL;
+}
 
 extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;

@@ -203,6 +203,45 @@ def bn_finalize_stats(partial, m, gamma, beta, eps, momentum, running_mean=None,
     return mean, invstd, scale, shift
 
 
+def pack_phase_weight(w_krsc, dtype=torch.float32):
+    """fp32 KRSC [Cout,3,3,Cin] -> [4,Cout,2,2,Cin] in ``dtype``: the four parity-specific 2x2 filters that a 3x3 / pad-1
+    convolution over a nearest-x2 upsampled input collapses to (``rs_pack_phase_weight_dt``)."""
+
+    cout, kh, kw, cin = w_krsc.shape
+    assert kh == 3 and kw == 3
+    out = torch.empty((4, cout, 2, 2, cin), device=w_krsc.device, dtype=dtype)
+    check(_lib.lib().rs_pack_phase_weight_dt(_dev(w_krsc, "w"), _dev(out, "out", dtype), RS_BF16 if dtype == BF16 else RS_F32,
+                                             cout, cin, _stream()), "rs_pack_phase_weight_dt")
+    return out
+
+
+def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual=None, relu=False, relu_mask=None):
+    """DecoderBlock in phase form: relu?(conv3x3(interpolate(cat[src1, src2], x2 nearest), pad 1)) computed as four 2x2
+    convolutions on the source grid (``rs_conv2d_fwd_phase_dt``); ``weight_phase`` from ``pack_phase_weight``."""
+
+    n, hs, ws, c1 = src1.shape
+    c2 = 0 if src2 is None else src2.shape[3]
+    cout = weight_phase.shape[1]
+    assert tuple(weight_phase.shape) == (4, cout, 2, 2, c1 + c2)
+    act = src1.dtype
+    d = ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, int(relu), 0)
+    out = torch.empty((n, 2 * hs, 2 * ws, cout), device=src1.device, dtype=act)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv2d_fwd_phase_dt(
+        ctypes.byref(d), _dt(src1), _dev(src1, "src1", act), _dev(src2, "src2", act), _dev(weight_phase, "weight", act),
+        _dev(scale, "scale"), _dev(shift, "shift"), _dev(residual, "residual", act), _dev(relu_mask, "relu_mask", act),
+        _dev(out, "out", act), _stream())
+    check(rc, "rs_conv2d_fwd_phase_dt")
+    if PROFILE is not None:
+        ev1.record()
+        bf = act == BF16
+        PROFILE.append((conv_tile_name(d, bf).replace("<", "<phase,"), conv_flops(d),
+                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 2 if bf else 4)))
+    return out
+
+
 def conv_tile_name(d, bf16=False):
     lib = _lib.lib()
     if bf16:

@@ -61,6 +61,17 @@ class _Conv(nn.Module):
             self._bf16 = c
         return c[1]
 
+    def phase(self, dtype=torch.float32):
+        """The four parity-specific 2x2 filters of this 3x3 convolution behind a nearest-x2 upsample (DecoderBlock),
+        packed on the device from the fp32 master and cached until the parameter is modified."""
+
+        key = (self.weight.data_ptr(), self.weight._version, dtype)
+        c = getattr(self, "_phase", None)
+        if c is None or c[0] != key:
+            c = (key, ops.pack_phase_weight(self.krsc(), dtype))
+            self._phase = c
+        return c[1]
+
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(self.cin, self.cout, self.k, self.stride, self.padding)
 
@@ -303,8 +314,8 @@ class UNet(nn.Module):
             enc.append(h)
         enc1, enc2, enc3, enc4 = enc
 
-        def up(block, skip, prev=None):
-            return ops.conv2d(skip, block.block.block.krsc(dt), src2=prev, ups=1, pad=1, relu=True)
+        def up(block, skip, prev=None):  # DecoderBlock in phase form: four 2x2 convolutions on the source grid
+            return ops.conv2d_phase(skip, block.block.block.phase(dt), src2=prev, relu=True)
 
         center = up(self.center, ops.maxpool2d(enc4, 2, 2, 0))
         dec0 = up(self.dec0, enc4, center)

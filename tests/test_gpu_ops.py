@@ -87,6 +87,32 @@ def test_conv_upsample_concat(c1, c2, cout, h, w):
     close(got, want)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c1,c2,cout,h,w", [(64, 32, 64, 10, 14), (32, 0, 32, 16, 16), (256, 64, 128, 8, 8), (128, 0, 32, 32, 24),
+                                            (64, 64, 128, 5, 3)])
+def test_conv_phase_form_equals_upsample_conv(c1, c2, cout, h, w, dtype):
+    """rs_conv2d_fwd_phase_dt (four parity 2x2 convolutions with pre-summed taps) == conv3x3(interpolate(cat, x2)) + ReLU
+    (reference unet.py:73,134-137), including borders and the concat split."""
+    from robosat_amd import ops
+
+    n = 2
+    bf = dtype == torch.bfloat16
+    rq = (lambda t: t.to(dtype).float()) if bf else (lambda t: t)
+    a = rq(rnd(n, c1, h, w, seed=8))
+    b = rq(rnd(n, c2, h, w, seed=9)) if c2 else None
+    wt = rnd(cout, c1 + c2, 3, 3, seed=10) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    cat = torch.cat([a, b], 1) if c2 else a
+    want = F.relu(F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1))
+    wp = ops.pack_phase_weight(krsc(wt), dtype)
+    assert tuple(wp.shape) == (4, cout, 2, 2, c1 + c2)
+    # the packed taps are sums of the original ones
+    wsum = wt.sum((2, 3))
+    assert float((wp.float().sum((2, 3)).cpu() - wsum.unsqueeze(0)).abs().max()) <= (5e-2 if bf else 1e-5) * float(wsum.abs().max())
+    got = ops.conv2d_phase(nhwc(a).to(dtype), wp, src2=nhwc(b).to(dtype) if c2 else None, relu=True)
+    assert got.dtype == dtype and tuple(got.shape) == (n, 2 * h, 2 * w, cout)
+    close(nchw(got.float()), want, 2e-2 if bf else 2e-4)
+
+
 @pytest.mark.parametrize("k,pad,hin", [(3, 1, 16), (1, 0, 16), (3, 1, 15)])
 def test_conv_zero_insert_is_stride2_adjoint(k, pad, hin):
     """ups=2 gather == data gradient of a stride-2 convolution (checked against autograd)."""

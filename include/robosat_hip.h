@@ -270,6 +270,15 @@ int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, c
                            const float* scale, const float* shift, const void* residual, const void* relu_mask, void* out,
                            rs_stream_t stream);
 
+/* ... and its data gradient: d loss / d (pre-upsample input) is ONE 4x4 / stride-2 / pad-1 convolution over dz with
+ * pre-summed taps (rs_conv2d_fwd[_bf16] with kh = kw = 4 and these weights, [Cin][4][4][Cout]): the gradient lands at
+ * the source resolution with 4/9 of the multiply-adds and the 2x2 sum of interpolate's backward already inside;
+ * rs_cat_split_bwd_dt then only splits torch.cat's channels, applies the ReLU masks and accumulates (rs_upsample2x_bwd
+ * without the 2x2 sum). */
+int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
+int rs_cat_split_bwd_dt(const void* dcat, void* d1, void* d2, const void* mask1, const void* mask2, int dtype, int N, int H,
+                        int W, int C1, int C2, int accumulate1, rs_stream_t stream);
+
 /* The same fusion for BatchNorm's BACKWARD (conv -> bn -> relu read right to left): the data-gradient convolution that
  * produces g = d loss / d z (rs_conv2d_fwd semantics on `dy` with rs_pack_dgrad_weight weights, optional residual,
  * relu_mask = z) also accumulates, per M tile, sum g and sum g * xhat with xhat = (bn_y - bn_mean) * bn_invstd;

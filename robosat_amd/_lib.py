@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 8
+ABI_VERSION = 9
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -87,6 +87,8 @@ SIGNATURES = {
     "rs_bn_finalize_stats": (c_int, [P, c_long, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rs_pack_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_phase_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P]),
+    "rs_pack_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "rs_cat_split_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_conv2d_dgrad_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),
     "rs_bn_bwd_from_partials_dt": (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, c_long, c_int, P, P]),
     "rs_nchw_to_nhwc4_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -176,10 +176,13 @@ def _backward(net, tape, dlogits, arena):
         """dz = gradient at the block's conv output (ReLU already applied).  Returns (d skip, d prev)."""
         conv = block.block.block
         ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=arena.conv(conv))
-        dup = ops.conv2d(dz, ops.pack_dgrad_weight(conv.krsc(), dz.dtype), pad=1)
+        # phase form: the gradient wrt the pre-upsample tensors is ONE 4x4 / stride-2 convolution over dz (the 2x2 sum of
+        # interpolate's backward is folded into pre-summed taps): 4/9 of the MACs, output already at source resolution
+        dsrc = ops.conv2d(dz, ops.pack_dgrad_phase_weight(conv.krsc(), dz.dtype), stride=2, pad=1,
+                          out_hw=(skip.shape[1], skip.shape[2]))
         c1 = skip.shape[3]
         c2 = 0 if prev is None else prev.shape[3]
-        return ops.upsample2x_bwd(dup, c1, c2, mask1=mask_skip, mask2=mask_prev, out1=skip_grad_out)
+        return ops.cat_split_bwd(dsrc, c1, c2, mask1=mask_skip, mask2=mask_prev, out1=skip_grad_out)
 
     d3, _ = up_bwd(net.dec4, d4, t["dec3"], None, t["dec3"], None)
     del d4

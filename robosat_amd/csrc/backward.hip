@@ -47,7 +47,9 @@ __global__ void maxpool_bwd_kernel(const TY* __restrict__ dy, const uint8_t* __r
 // d/dx of F.interpolate(scale_factor=2, mode="nearest") (unet.py:73) followed by the split of torch.cat
 // (unet.py:134-137): 2x2 sum of the gradient at the upsampled resolution, channels [0,C1) -> d1, [C1,C1+C2) -> d2.
 // mask1/mask2 (optional) are the ReLU outputs the gradients flow into: result zeroed where mask <= 0.
-template <typename T>
+// SUM = false: `dup` is already at the source resolution [N][H][W][C1+C2] (the phase-form data gradient,
+// rs_pack_dgrad_phase_weight_dt): only the torch.cat split, the ReLU masks and the accumulation remain.
+template <typename T, bool SUM>
 __global__ void upsample2x_bwd_kernel(const T* __restrict__ dup, T* __restrict__ d1, T* __restrict__ d2,
                                       const T* __restrict__ mask1, const T* __restrict__ mask2, int H, int W,
                                       int C1, int C2, long total, int accumulate1) {
@@ -56,16 +58,21 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dup, T* __restrict__
   const int Ct = C1 + C2, Q = Ct >> 2;
   const int q = (int)(i % Q);
   long pix = i / Q;  // (n*H + y)*W + x
-  const int x = (int)(pix % W);
-  const long ny = pix / W;  // n*H + y
-  const long W2 = 2L * W;
-  const long base = ((2 * ny) * W2 + 2 * x) * Ct + q * 4;  // row 2*(n*H+y) of the [N*2H][2W] image == n*2H + 2y
-  f32x4 s = rs_ld4(dup + base);
-  const f32x4 b = rs_ld4(dup + base + Ct);
-  const f32x4 c = rs_ld4(dup + base + W2 * Ct);
-  const f32x4 d = rs_ld4(dup + base + W2 * Ct + Ct);
+  f32x4 s;
+  if (SUM) {
+    const int x = (int)(pix % W);
+    const long ny = pix / W;  // n*H + y
+    const long W2 = 2L * W;
+    const long base = ((2 * ny) * W2 + 2 * x) * Ct + q * 4;  // row 2*(n*H+y) of the [N*2H][2W] image == n*2H + 2y
+    s = rs_ld4(dup + base);
+    const f32x4 b = rs_ld4(dup + base + Ct);
+    const f32x4 c = rs_ld4(dup + base + W2 * Ct);
+    const f32x4 d = rs_ld4(dup + base + W2 * Ct + Ct);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) s[e] = (s[e] + b[e]) + (c[e] + d[e]);
+    for (int e = 0; e < 4; ++e) s[e] = (s[e] + b[e]) + (c[e] + d[e]);
+  } else {
+    s = rs_ld4(dup + pix * Ct + q * 4);
+  }
   const int ch = q * 4;
   if (ch < C1) {
     const long o = pix * C1 + ch;
@@ -246,10 +253,10 @@ int launch_maxpool_bwd(const void* dy, const uint8_t* argmax, void* dx, int H, i
   return RS_LAUNCH_RESULT();
 }
 
-template <typename T>
+template <typename T, bool SUM>
 int launch_upsample_bwd(const void* dup, void* d1, void* d2, const void* mask1, const void* mask2, int H, int W, int C1,
                         int C2, long total, int accumulate1, hipStream_t s) {
-  upsample2x_bwd_kernel<T><<<rs_cdiv(total, 256), 256, 0, s>>>(
+  upsample2x_bwd_kernel<T, SUM><<<rs_cdiv(total, 256), 256, 0, s>>>(
       reinterpret_cast<const T*>(dup), reinterpret_cast<T*>(d1), reinterpret_cast<T*>(d2), reinterpret_cast<const T*>(mask1),
       reinterpret_cast<const T*>(mask2), H, W, C1, C2, total, accumulate1);
   return RS_LAUNCH_RESULT();
@@ -282,8 +289,19 @@ extern "C" int rs_upsample2x_bwd_dt(const void* dup, void* d1, void* d2, const v
   if (C2 > 0 && !d2) return RS_EINVAL;
   const long total = (long)N * H * W * ((C1 + C2) / 4);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == RS_F32) return launch_upsample_bwd<float>(dup, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
-  if (dtype == RS_BF16) return launch_upsample_bwd<bf16_t>(dup, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
+  if (dtype == RS_F32) return launch_upsample_bwd<float, true>(dup, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
+  if (dtype == RS_BF16) return launch_upsample_bwd<bf16_t, true>(dup, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_cat_split_bwd_dt(const void* dcat, void* d1, void* d2, const void* mask1, const void* mask2, int dtype,
+                                   int N, int H, int W, int C1, int C2, int accumulate1, rs_stream_t stream) {
+  if (!dcat || !d1 || N <= 0 || H <= 0 || W <= 0 || C1 <= 0 || (C1 & 3) || C2 < 0 || (C2 & 3)) return RS_EINVAL;
+  if (C2 > 0 && !d2) return RS_EINVAL;
+  const long total = (long)N * H * W * ((C1 + C2) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32) return launch_upsample_bwd<float, false>(dcat, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
+  if (dtype == RS_BF16) return launch_upsample_bwd<bf16_t, false>(dcat, d1, d2, mask1, mask2, H, W, C1, C2, total, accumulate1, s);
   return RS_EINVAL;
 }
 

@@ -618,6 +618,39 @@ __global__ void pack_phase_weight_kernel(const float* __restrict__ w, T* __restr
   out[i] = (T)acc;
 }
 
+// fp32 KRSC [Cout][3][3][Cin] -> data-gradient weights of the phase form, [Cin][4][4][Cout] in T: the gradient of
+// DecoderBlock wrt its (pre-upsample) input is a 4x4 / stride-2 / pad-1 convolution over dz,
+//   d_src[u][v][ci] = sum_{ty,tx,co} dz[2u - 1 + ty][2v - 1 + tx][co] * Wd[ci][ty][tx][co],
+// Wd[ty] = sum of the taps ky with ((2u - 1 + ty) + ky - 1) >> 1 == u:  ty 0 -> {2}, 1 -> {1,2}, 2 -> {0,1}, 3 -> {0}.
+template <typename T>
+__global__ void pack_dgrad_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  long t = i / Cout;
+  const int tx = (int)(t & 3), ty = (int)((t >> 2) & 3);
+  const int ci = (int)(t >> 4);
+  const int ky0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), ky1 = ty == 0 ? 2 : (ty == 1 ? 2 : (ty == 2 ? 1 : 0));
+  const int kx0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), kx1 = tx == 0 ? 2 : (tx == 1 ? 2 : (tx == 2 ? 1 : 0));
+  float acc = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+  out[i] = (T)acc;
+}
+
+extern "C" int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream) {
+  if (!w_krsc || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
+  const long total = 16L * Cout * Cin;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32)
+    pack_dgrad_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin, total);
+  else if (dtype == RS_BF16)
+    pack_dgrad_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin, total);
+  else
+    return RS_EINVAL;
+  return RS_LAUNCH_RESULT();
+}
+
 extern "C" int rs_pack_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream) {
   if (!w_krsc || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
   const long total = 16L * Cout * Cin;

@@ -215,6 +215,35 @@ def pack_phase_weight(w_krsc, dtype=torch.float32):
     return out
 
 
+def pack_dgrad_phase_weight(w_krsc, dtype=torch.float32):
+    """fp32 KRSC [Cout,3,3,Cin] -> [Cin,4,4,Cout] in ``dtype``: weights of the 4x4 / stride-2 convolution over dz that is
+    the data gradient of DecoderBlock wrt its pre-upsample input (``rs_pack_dgrad_phase_weight_dt``)."""
+
+    cout, kh, kw, cin = w_krsc.shape
+    assert kh == 3 and kw == 3
+    out = torch.empty((cin, 4, 4, cout), device=w_krsc.device, dtype=dtype)
+    check(_lib.lib().rs_pack_dgrad_phase_weight_dt(_dev(w_krsc, "w"), _dev(out, "out", dtype),
+                                                   RS_BF16 if dtype == BF16 else RS_F32, cout, cin, _stream()),
+          "rs_pack_dgrad_phase_weight_dt")
+    return out
+
+
+def cat_split_bwd(dcat, c1, c2=0, mask1=None, mask2=None, out1=None):
+    """dcat [N,H,W,C1+C2] -> (d1 [N,H,W,C1], d2 [N,H,W,C2] or None): the torch.cat split + ReLU masks; ``out1`` given =>
+    accumulate into it."""
+
+    n, h, w, ct = dcat.shape
+    assert ct == c1 + c2
+    t = dcat.dtype
+    acc = out1 is not None
+    d1 = out1 if acc else torch.empty((n, h, w, c1), device=dcat.device, dtype=t)
+    d2 = torch.empty((n, h, w, c2), device=dcat.device, dtype=t) if c2 else None
+    rc = _lib.lib().rs_cat_split_bwd_dt(_dev(dcat, "dcat", t), _dev(d1, "d1", t), _dev(d2, "d2", t), _dev(mask1, "mask1", t),
+                                        _dev(mask2, "mask2", t), _dt(dcat), n, h, w, c1, c2, int(acc), _stream())
+    check(rc, "rs_cat_split_bwd_dt")
+    return d1, d2
+
+
 def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual=None, relu=False, relu_mask=None):
     """DecoderBlock in phase form: relu?(conv3x3(interpolate(cat[src1, src2], x2 nearest), pad 1)) computed as four 2x2
     convolutions on the source grid (``rs_conv2d_fwd_phase_dt``); ``weight_phase`` from ``pack_phase_weight``."""

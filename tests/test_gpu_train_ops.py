@@ -244,3 +244,33 @@ def test_metrics_match_reference_golden(golden_dir):
     m.add_batch(actual[1:], scores[1:])
     assert [m.tn, m.fn, m.fp, m.tp] == g["counts"].tolist()
     assert np.allclose([m.get_miou(), m.get_fg_iou(), m.get_mcc()], g["scores3"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c1,c2,cout,h,w", [(64, 32, 64, 10, 14), (128, 0, 32, 16, 8), (256, 64, 128, 8, 8), (64, 64, 128, 5, 3)])
+def test_decoder_dgrad_phase_form(c1, c2, cout, h, w, dtype):
+    """d loss / d (skip, prev) of relu-less DecoderBlock conv3x3(interpolate(cat[skip, prev], x2)) == one 4x4 / stride-2
+    convolution over dz with rs_pack_dgrad_phase_weight_dt weights, then the cat split (vs autograd)."""
+    from robosat_amd import ops
+
+    n = 2
+    bf = dtype == torch.bfloat16
+    rq = (lambda t: t.to(dtype).float()) if bf else (lambda t: t)
+    a = rnd(n, c1, h, w, seed=1).requires_grad_(True)
+    b = rnd(n, c2, h, w, seed=2).requires_grad_(True) if c2 else None
+    wt = rnd(cout, c1 + c2, 3, 3, seed=3) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    cat = torch.cat([a, b], 1) if c2 else a
+    y = F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1)
+    dz = rq(rnd(*y.shape, seed=4))
+    y.backward(dz)
+    wd = ops.pack_dgrad_phase_weight(krsc(wt), dtype)
+    assert tuple(wd.shape) == (c1 + c2, 4, 4, cout)
+    dsrc = ops.conv2d(nhwc(dz).to(dtype), wd, stride=2, pad=1, out_hw=(h, w))
+    m1 = rq(rnd(n, c1, h, w, seed=5))
+    base = rq(rnd(n, c1, h, w, seed=6))
+    acc = nhwc(base).to(dtype)
+    d1, d2 = ops.cat_split_bwd(dsrc, c1, c2, mask1=nhwc(m1).to(dtype), out1=acc)
+    tol = 3e-2 if bf else 3e-4
+    close(nchw(d1.float()), base + a.grad * (m1 > 0), tol, "d skip")
+    if c2:
+        close(nchw(d2.float()), b.grad, tol, "d prev")

@@ -179,7 +179,7 @@ def _backward(net, tape, dlogits, arena):
         # phase form: the gradient wrt the pre-upsample tensors is ONE 4x4 / stride-2 convolution over dz (the 2x2 sum of
         # interpolate's backward is folded into pre-summed taps): 4/9 of the MACs, output already at source resolution
         dsrc = ops.conv2d(dz, ops.pack_dgrad_phase_weight(conv.krsc(), dz.dtype), stride=2, pad=1,
-                          out_hw=(skip.shape[1], skip.shape[2]))
+                          out_hw=(skip.shape[1], skip.shape[2]), alg_scale=2.25)
         c1 = skip.shape[3]
         c2 = 0 if prev is None else prev.shape[3]
         return ops.cat_split_bwd(dsrc, c1, c2, mask1=mask_skip, mask2=mask_prev, out1=skip_grad_out)

@@ -142,7 +142,7 @@ __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
 
 constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 data gradient of an upsampled 3x3)
 
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB>
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   // gathers.  Block -> (phase, tile); the problem rows m then enumerate SOURCE pixels (n, a, b) and the output row is
   // (n, 2a + py, 2b + px).
   int py = 0, px = 0;
-  if (p.phase4) {
+  if (PHASE) {
     py = (bid >> 1) & 1;
     px = bid & 1;
     bid >>= 2;
@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const int Hd = p.phase4 ? p.Hs : p.Ho, Wd = p.phase4 ? p.Ws : p.Wo;  // the grid the rows m enumerate
+  const int Hd = PHASE ? p.Hs : p.Ho, Wd = PHASE ? p.Ws : p.Wo;  // the grid the rows m enumerate
   const int HdWd = Hd * Wd;
   const int nfirst = m0 / HdWd;
   const int ush = p.ups ? 1 : 0;
   const int upar = p.ups == 2 ? 1 : 0;
-  const int pad_y = p.phase4 ? 1 - py : p.pad, pad_x = p.phase4 ? 1 - px : p.pad;
+  const int pad_y = PHASE ? 1 - py : p.pad, pad_x = PHASE ? 1 - px : p.pad;
 
   // ---- separable gather table, relative to the tile's first image: source pixel of (row, tap (r, s)) =
   //      taby[r][row] + tabx[s][row] when both are >= 0, else the tap contributes zeros ------------------------------
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
         const int ix = ox * p.stride - pad_x + (t - p.kh);
         if (((unsigned)ix < (unsigned)p.Wv) && ((ix & upar) == 0)) v = ix >> ush;
       } else {
-        v = p.phase4 ? (n * p.Ho + 2 * oy + py) * p.Wo + 2 * ox + px : m;
+        v = PHASE ? (n * p.Ho + 2 * oy + py) * p.Wo + 2 * ox + px : m;
       }
     }
     if (t < p.kh) taby[t * BM + row] = v;
@@ -507,13 +507,13 @@ int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false) {
   return 128;
 }
 
-template <typename T, int ROWB>
+template <typename T, int ROWB, bool PHASE>
 void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
   switch (tile) {
-    case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, ROWB><<<grid, 256, 0, s>>>(a); break;
-    case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, ROWB><<<grid, 256, 0, s>>>(a); break;
-    case T128x32: conv_igemm_dma<T, 128, 32, 4, 1, ROWB><<<grid, 256, 0, s>>>(a); break;
-    default: conv_igemm_dma<T, 64, 64, 2, 2, ROWB><<<grid, 256, 0, s>>>(a); break;
+    case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
+    case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
+    case T128x32: conv_igemm_dma<T, 128, 32, 4, 1, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
+    default: conv_igemm_dma<T, 64, 64, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
   }
 }
 
@@ -582,8 +582,13 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.ntiles = d->Cout / kTileBN[tile];
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
   hipStream_t s = (hipStream_t)stream;
-  if (kc == kc128) launch<T, 128>(tile, grid, s, a);
-  else launch<T, 64>(tile, grid, s, a);
+  if (phase4) {
+    if (kc == kc128) launch<T, 128, true>(tile, grid, s, a);
+    else launch<T, 64, true>(tile, grid, s, a);
+  } else {
+    if (kc == kc128) launch<T, 128, false>(tile, grid, s, a);
+    else launch<T, 64, false>(tile, grid, s, a);
+  }
   return RS_LAUNCH_RESULT();
 }
 

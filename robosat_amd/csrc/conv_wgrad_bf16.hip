@@ -93,7 +93,13 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
 
 // PK = pixels per chunk: 64 (4 k-steps per barrier, 64 KB of LDS for the 128x128 tile: 2 blocks per CU) or 32 (2 k-steps,
 // half the LDS: 4 blocks per CU -- the short reductions of the small layers)
-template <int BMo, int BNo, int WGM, int WGN, int PK>
+// PHASE: the layer is DecoderBlock (3x3 / pad 1 behind the nearest-x2 upsample).  Instead of nine taps over the UPSAMPLED
+// pixels the block reduces one of 16 (parity, source offset) combinations over the SOURCE pixels:
+//   G[(py,px),(r,s)][co][ci] = sum_{n,a,b} dz[n][2a+py][2b+px][co] * src[n][a-(1-py)+r][b-(1-px)+s][ci]
+// (4/9 of the multiply-adds; dz rows are then gathered too: a second table), and combine_phase_wgrad_kernel adds the four
+// G's that make up each filter tap: dW[ky][kx] = sum_{(py,r) : ky in S(py,r)} sum_{(px,s) : kx in S(px,s)} G, with
+// S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2} (the taps that hit the same source pixel).
+template <int BMo, int BNo, int WGM, int WGN, int PK, bool PHASE>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const WgradArgsB p) {
   constexpr int NW = WGM * WGN;          // waves
   constexpr int NS = PK / 16;            // MFMA k-steps per chunk
@@ -109,8 +115,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   constexpr int BUF = ABYTES + BBYTES;
   static_assert(TM >= 1 && TN >= 1 && (IA % NW) == 0 && (IB % NW) == 0, "bad tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 2 * PK * 4];
-  int* tabs = reinterpret_cast<int*>(smem + 2 * BUF);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + (PHASE ? 4 : 2) * PK * 4];
+  int* tabs = reinterpret_cast<int*>(smem + 2 * BUF);  // [2][PK] input-row gather
+  int* taba = tabs + 2 * PK;                            // [2][PK] dz-row gather (PHASE only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -123,8 +130,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   const int tk = bid % p.tiles_k;
   const int split = bid / p.tiles_k;
   const int tap = tk / p.tiles_ci, tci = tk - tap * p.tiles_ci;
-  const int ky = tap / p.kw;
-  const int kx = tap - ky * p.kw;
+  const int ky = PHASE ? ((tap >> 1) & 1) : tap / p.kw;  // PHASE: tap = 4*(2*py+px) + 2*r + s
+  const int kx = PHASE ? (tap & 1) : tap - ky * p.kw;
+  const int py = (tap >> 3) & 1, px = (tap >> 2) & 1;
   const int co0 = tco * BMo;
   const int ci0 = tci * BNo;
 
@@ -140,12 +148,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   const int total_chunks = (p.M + PK - 1) / PK;
   int chunk1 = chunk0 + p.chunks_per_split;
   if (chunk1 > total_chunks) chunk1 = total_chunks;
-  const int HoWo = p.Ho * p.Wo;
+  const int Wd = PHASE ? p.Ws : p.Wo;                   // the pixel grid the reduction index m enumerates
+  const int HoWo = PHASE ? p.Hs * p.Ws : p.Ho * p.Wo;   // (div_howo / div_wo are prepared for that grid)
 
   const int m_first = chunk0 * PK;
   const int n_first = (int)rs_div((unsigned)m_first, p.div_howo);
   const long img = (long)p.Hs * p.Ws * Cs;
-  const __amdgpu_buffer_rsrc_t rsrc_dy = wb_make_rsrc(p.dy + (long)m_first * p.Cout, ((long)p.M - m_first) * p.Cout * 2);
+  const long dimg = (long)p.Ho * p.Wo * p.Cout;
+  const __amdgpu_buffer_rsrc_t rsrc_dy =
+      PHASE ? wb_make_rsrc(p.dy + n_first * dimg, (long)(p.N - n_first) * dimg * 2)
+            : wb_make_rsrc(p.dy + (long)m_first * p.Cout, ((long)p.M - m_first) * p.Cout * 2);
   const __amdgpu_buffer_rsrc_t rsrc_x = wb_make_rsrc(src + n_first * img, (long)(p.N - n_first) * img * 2);
   const int ush = p.ups ? 1 : 0;
   const int upar = p.ups == 2 ? 1 : 0;
@@ -154,18 +166,25 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   auto fill_table = [&](int chunk, int which) __attribute__((always_inline)) {
     if (tid < PK) {
       const int m = chunk * PK + tid;
-      int pix = -1;
+      int pix = -1, pixa = -1;
       if (m < p.M) {
         const int n = (int)rs_div((unsigned)m, p.div_howo);
         const int rem = m - n * HoWo;
         const int oy = (int)rs_div((unsigned)rem, p.div_wo);
-        const int ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride - p.pad + ky;
-        const int ix = ox * p.stride - p.pad + kx;
-        const bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv) && (((iy | ix) & upar) == 0);
-        if (ok) pix = ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+        const int ox = rem - oy * Wd;
+        if (PHASE) {
+          const int iy = oy - (1 - py) + ky, ix = ox - (1 - px) + kx;
+          if (((unsigned)iy < (unsigned)p.Hs) && ((unsigned)ix < (unsigned)p.Ws)) pix = ((n - n_first) * p.Hs + iy) * p.Ws + ix;
+          pixa = ((n - n_first) * p.Ho + 2 * oy + py) * p.Wo + 2 * ox + px;
+        } else {
+          const int iy = oy * p.stride - p.pad + ky;
+          const int ix = ox * p.stride - p.pad + kx;
+          const bool ok = ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv) && (((iy | ix) & upar) == 0);
+          if (ok) pix = ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+        }
       }
       tabs[which * PK + tid] = pix;
+      if (PHASE) taba[which * PK + tid] = pixa;
     }
   };
 
@@ -186,15 +205,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
     const unsigned int L = lds0 + buf * BUF;
     int pix[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j)  // table lookups of all of this wave's input-row instructions first (one LDS round trip)
-      pix[j] = (NW * j >= IA) ? tabs[which * PK + RIB * (wave + NW * j - IA) + ra_b] : 0;
+    for (int j = 0; j < NI; ++j)  // table lookups of all of this wave's gathered-row instructions first (one LDS round trip)
+      pix[j] = (NW * j >= IA) ? tabs[which * PK + RIB * (wave + NW * j - IA) + ra_b]
+                              : (PHASE ? taba[which * PK + RIA * (wave + NW * j) + ra_a] : 0);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int ii = wave + NW * j;  // wave-uniform; IA is a multiple of NW, so the role depends on j alone
       if (NW * j < IA) {
-        const int R = RIA * ii + ra_a;
-        const int m = chunk * PK + R;
-        wb_dma16(rsrc_dy, L + ii * 1024, (m - m_first) * cout2 + cola);  // rows >= M lie past the descriptor: zeros
+        if (PHASE) {
+          wb_dma16(rsrc_dy, L + ii * 1024, pix[j] >= 0 ? pix[j] * cout2 + cola : -1);
+        } else {
+          const int R = RIA * ii + ra_a;
+          const int m = chunk * PK + R;
+          wb_dma16(rsrc_dy, L + ii * 1024, (m - m_first) * cout2 + cola);  // rows >= M lie past the descriptor: zeros
+        }
       } else {
         wb_dma16(rsrc_x, L + ABYTES + (ii - IA) * 1024, pix[j] >= 0 ? pix[j] * cs2 + colb : -1);
       }
@@ -271,9 +295,31 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
 }
 
 struct Plan {
-  int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split, pk;
+  int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split, pk, phase;
   long K;
 };
+
+// G [Cout][16][Cin] (phase form, tap index 4*(2*py+px) + 2*r + s) -> dW [Cout][3][3][Cin]
+__global__ void combine_phase_wgrad_kernel(const float* __restrict__ g, float* __restrict__ dw, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  long t = i / Cin;
+  const int kx = (int)(t % 3), ky = (int)((t / 3) % 3);
+  const long co = t / 9;
+  // (py, r) pairs whose tap set contains ky: ky 0 -> (0,0),(1,0); 1 -> (0,1),(1,0); 2 -> (0,1),(1,1)
+  const int ya[2][2] = {{0, ky == 0 ? 0 : 1}, {1, ky == 2 ? 1 : 0}};
+  const int xa[2][2] = {{0, kx == 0 ? 0 : 1}, {1, kx == 2 ? 1 : 0}};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int tap = 4 * (2 * ya[a][0] + xa[b][0]) + 2 * ya[a][1] + xa[b][1];
+      acc += g[(co * 16 + tap) * Cin + ci];
+    }
+  dw[i] = acc;
+}
 
 enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32 };
 
@@ -289,9 +335,18 @@ bool valid(const rs_conv_desc* d) {
 
 int largest_tile(int c) { return (c % 128 == 0) ? 128 : (c % 64 == 0) ? 64 : 32; }
 
+bool phase_ok(const rs_conv_desc* d) {
+  static const int off = [] {
+    const char* e = getenv("RS_WGRAD_PHASE");
+    return e && atoi(e) == 0;
+  }();
+  return !off && d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
+}
+
 Plan plan(const rs_conv_desc* d) {
   Plan pl;
-  const long M = (long)d->N * d->Ho * d->Wo;
+  pl.phase = phase_ok(d) ? 1 : 0;
+  const long M = pl.phase ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo;
   pl.bmo = largest_tile(d->Cout);
   pl.bno = largest_tile(d->C1);
   if (d->C2 > 0) {
@@ -303,7 +358,7 @@ Plan plan(const rs_conv_desc* d) {
   pl.variant = pl.bmo == 128 ? (pl.bno == 128 ? V128x128 : V128x64)
                : pl.bmo == 64 ? (pl.bno == 128 ? V64x128 : V64x64)
                               : (pl.bno == 128 ? V32x128 : V32x32);
-  pl.taps = d->kh * d->kw;
+  pl.taps = pl.phase ? 16 : d->kh * d->kw;
   pl.tiles_ci = (d->C1 + d->C2) / pl.bno;
   pl.K = (long)pl.taps * (d->C1 + d->C2);
   pl.tiles_co = d->Cout / pl.bmo;
@@ -315,7 +370,7 @@ Plan plan(const rs_conv_desc* d) {
     return e ? atoi(e) : 0;
   }();
   pl.pk = (forced == 32 || forced == 64) ? forced : 64;
-  if (pl.bmo == 32 || pl.bno == 32) pl.pk = 64;
+  if (pl.bmo == 32 || pl.bno == 32 || pl.phase) pl.pk = 64;
   const int PK = pl.pk;
   const long chunks = (M + PK - 1) / PK;
   long s = (1024 + tiles - 1) / tiles;            // aim at >= 1024 blocks ...
@@ -325,11 +380,12 @@ Plan plan(const rs_conv_desc* d) {
   // 32-bit byte offsets inside a split: shrink the splits until dy and the input both fit
   const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
   const long img_bytes = (long)d->Hs * d->Ws * cmax * 2;
-  const long howo = (long)d->Ho * d->Wo;
+  const long howo = pl.phase ? (long)d->Hs * d->Ws : (long)d->Ho * d->Wo;
+  const long dimg_bytes = (long)d->Ho * d->Wo * d->Cout * 2;
   for (;;) {
     pl.chunks_per_split = (int)((chunks + s - 1) / s);
     const long px = ((long)pl.chunks_per_split + 2) * PK;
-    const long span_dy = px * d->Cout * 2;
+    const long span_dy = pl.phase ? (px / howo + 2) * dimg_bytes : px * d->Cout * 2;
     const long span_x = (px / howo + 2) * img_bytes;
     if ((span_dy < (1L << 31) && span_x < (1L << 31)) || pl.chunks_per_split == 1) break;
     s *= 2;
@@ -349,7 +405,7 @@ extern "C" long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d) {
   }
   const Plan pl = plan(d);
   const long n = (long)d->Cout * pl.K;
-  return (pl.splits * n + rs_reduce_scratch_floats(n, pl.splits)) * (long)sizeof(float);
+  return (pl.splits * n + rs_reduce_scratch_floats(n, pl.splits) + (pl.phase ? n : 0)) * (long)sizeof(float);
 }
 
 extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, const rs_bf16* src1, const rs_bf16* src2,
@@ -378,8 +434,8 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   a.C1 = d->C1;
   a.C2 = d->C2;
   a.ups = d->ups;
-  a.div_howo = rs_make_fastdiv((unsigned)(d->Ho * d->Wo));
-  a.div_wo = rs_make_fastdiv((unsigned)d->Wo);
+  a.div_howo = rs_make_fastdiv((unsigned)(pl.phase ? d->Hs * d->Ws : d->Ho * d->Wo));
+  a.div_wo = rs_make_fastdiv((unsigned)(pl.phase ? d->Ws : d->Wo));
   a.Hv = d->ups == 0 ? d->Hs : (d->ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
   a.Wv = d->ups == 0 ? d->Ws : (d->ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
   a.kw = d->kw;
@@ -388,7 +444,7 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   a.Ho = d->Ho;
   a.Wo = d->Wo;
   a.Cout = d->Cout;
-  a.M = (int)((long)d->N * d->Ho * d->Wo);
+  a.M = (int)(pl.phase ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo);
   a.K = (int)pl.K;
   a.tiles_co = pl.tiles_co;
   a.tiles_ci = pl.tiles_ci;
@@ -396,27 +452,44 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   a.chunks_per_split = pl.chunks_per_split;
   const int grid = pl.tiles_co * pl.tiles_k * pl.splits;
   hipStream_t s = (hipStream_t)stream;
-  if (pl.pk == 32) {
+  if (pl.phase) {
     switch (pl.variant) {
-      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
-      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
-      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
-      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 32><<<grid, 256, 0, s>>>(a); break;
+      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+      case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, true><<<grid, 256, 0, s>>>(a); break;
+      case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, true><<<grid, 64, 0, s>>>(a); break;
+      default: return RS_EINVAL;
+    }
+  } else if (pl.pk == 32) {
+    switch (pl.variant) {
+      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
       default: return RS_EINVAL;
     }
   } else {
     switch (pl.variant) {
-      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
-      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
-      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
-      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64><<<grid, 256, 0, s>>>(a); break;
-      case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64><<<grid, 256, 0, s>>>(a); break;
-      case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64><<<grid, 64, 0, s>>>(a); break;
+      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+      case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;
+      case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, false><<<grid, 64, 0, s>>>(a); break;
       default: return RS_EINVAL;
     }
   }
   const int rc = RS_LAUNCH_RESULT();
   if (rc) return rc;
   const long n = (long)d->Cout * pl.K;  // multiple of 4
-  return rs_reduce_splits(a.out, dw, n, pl.splits, a.out + (long)pl.splits * n, stream);
+  float* scratch = a.out + (long)pl.splits * n;
+  if (!pl.phase) return rs_reduce_splits(a.out, dw, n, pl.splits, scratch, stream);
+  float* gbuf = scratch + rs_reduce_scratch_floats(n, pl.splits);  // G [Cout][16][Cin]
+  const int rc2 = rs_reduce_splits(a.out, gbuf, n, pl.splits, scratch, stream);
+  if (rc2) return rc2;
+  const long total = (long)d->Cout * 9 * (d->C1 + d->C2);
+  combine_phase_wgrad_kernel<<<rs_cdiv(total, 256), 256, 0, s>>>(gbuf, dw, d->C1 + d->C2, total);
+  return RS_LAUNCH_RESULT();
 }

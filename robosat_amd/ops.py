@@ -46,6 +46,13 @@ def _stream():
 PROFILE = None
 
 
+def _record(name, flops, shape, ev0, ev1, nbytes, executed=None):
+    """One roofline record: ALGORITHMIC flops / bytes of the launch (reference shapes) and the flops
+    the kernel actually executes (smaller for the phase-form decoder kernels: 4/9)."""
+
+    PROFILE.append((name, flops, shape, ev0, ev1, nbytes, flops if executed is None else executed))
+
+
 def conv_flops(d):
     """Algorithmic FLOPs of one launch: 2*N*Cout*Cin*kh*kw*Ho*Wo on the reference's shapes."""
 
@@ -74,7 +81,7 @@ def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=
 
 
 def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False,
-           stem=0, out_hw=None, out=None, relu_mask=None):
+           stem=0, out_hw=None, out=None, relu_mask=None, alg_scale=1.0):
     """``rs_conv2d_fwd``: out = relu?(conv(gather(src1|src2)) * scale + shift + residual).
 
     ``stem``: 0, or the true filter width (7) when ``weight`` is the packed ``[Cout,kh,8,4]`` stem filter.
@@ -106,8 +113,11 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     check(rc, "rs_conv2d_fwd_bf16" if bf else "rs_conv2d_fwd")
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                        conv_bytes(d, 2 if bf else 4)))
+        name = conv_tile_name(d, bf)
+        if alg_scale != 1.0:  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
+            name = name.replace("<", "<phase,")
+        _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                conv_bytes(d, 2 if bf else 4), conv_flops(d))
     return out
 
 
@@ -134,8 +144,8 @@ def conv2d_bnstats(src1, weight, src2=None, ups=0, stride=1, pad=0):
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                        conv_bytes(d, 2 if bf else 4)))
+        _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                        conv_bytes(d, 2 if bf else 4))
     return out, partial
 
 
@@ -164,8 +174,8 @@ def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0,
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        PROFILE.append((conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                        conv_bytes(d, 2 if bf else 4)))
+        _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                        conv_bytes(d, 2 if bf else 4))
     return out, partial
 
 
@@ -266,8 +276,9 @@ def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        PROFILE.append((conv_tile_name(d, bf).replace("<", "<phase,"), conv_flops(d),
-                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 2 if bf else 4)))
+        _record(conv_tile_name(d, bf).replace("<", "<phase,"), conv_flops(d),
+                (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 2 if bf else 4),
+                conv_flops(d) * 4.0 / 9.0)
     return out
 
 
@@ -318,7 +329,7 @@ def stem_conv_bf16(x4, w_packed, scale=None, shift=None, relu=False):
     if PROFILE is not None:
         ev1.record()
         flops = 2.0 * n * 64 * 3 * 49 * (h // 2) * (w // 2)
-        PROFILE.append(("stem_conv_bf16", flops, (3, 64, 7, 2, 0, h // 2, w // 2), ev0, ev1, 2 * (x4.numel() + out.numel())))
+        _record("stem_conv_bf16", flops, (3, 64, 7, 2, 0, h // 2, w // 2), ev0, ev1, 2 * (x4.numel() + out.numel()))
     return out
 
 
@@ -337,7 +348,7 @@ def stem_conv_wgrad_bf16(dy, x4):
     if PROFILE is not None:
         ev1.record()
         flops = 2.0 * n * 64 * 3 * 49 * (h // 2) * (w // 2)
-        PROFILE.append(("stem_wgrad_bf16", flops, (3, 64, 7, 2, 0, h // 2, w // 2), ev0, ev1, 2 * (x4.numel() + dy.numel())))
+        _record("stem_wgrad_bf16", flops, (3, 64, 7, 2, 0, h // 2, w // 2), ev0, ev1, 2 * (x4.numel() + dy.numel()))
     return dw
 
 
@@ -475,8 +486,8 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         ev1.record()
         es = 2 if bf else 4
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
-        PROFILE.append(("conv_wgrad_bf16" if bf else "conv_wgrad_f32", conv_flops(d),
-                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes))
+        _record("conv_wgrad_bf16" if bf else "conv_wgrad_f32", conv_flops(d),
+                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes)
     return dw
 
 

@@ -171,16 +171,19 @@ def test_wgrad_bf16_thin_upsample(cin, h, w):
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
 
 
-def test_wgrad_bf16_upsample_concat():
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [(2, 128, 64, 64, 12, 10), (1, 256, 0, 128, 9, 7), (3, 64, 64, 256, 5, 16), (2, 256, 64, 128, 16, 16)])
+def test_wgrad_bf16_upsample_concat(n, c1, c2, cout, h, w):
+    """DecoderBlock filter gradient; takes the phase form (16 parity/offset reductions over SOURCE pixels + combine)."""
     from robosat_amd import ops
 
-    n, c1, c2, cout, h, w = 2, 128, 64, 64, 12, 10
-    a, b = q(rnd(n, c1, h, w, seed=4)), q(rnd(n, c2, h, w, seed=5))
+    a = q(rnd(n, c1, h, w, seed=4))
+    b = q(rnd(n, c2, h, w, seed=5)) if c2 else None
     wt = (rnd(cout, c1 + c2, 3, 3, seed=6) * 0.05).requires_grad_(True)
-    y = F.conv2d(F.interpolate(torch.cat([a, b], 1), scale_factor=2, mode="nearest"), wt, padding=1)
+    cat = torch.cat([a, b], 1) if c2 else a
+    y = F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1)
     gy = q(rnd(*y.shape, seed=7))
     y.backward(gy)
-    dw = ops.conv2d_wgrad(nhwc(gy), nhwc(a), 3, 3, src2=nhwc(b), ups=1, pad=1)
+    dw = ops.conv2d_wgrad(nhwc(gy), nhwc(a), 3, 3, src2=nhwc(b) if c2 else None, ups=1, pad=1)
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
 
 

@@ -396,6 +396,15 @@ Plan plan(const rs_conv_desc* d) {
 
 }  // namespace
 
+// Which formulation rs_conv2d_wgrad_bf16 uses for `d` (for the roofline report): 0 tap-per-block, 1 all-taps thin kernel,
+// 2 phase form (executes 4/9 of the algorithmic multiply-adds).
+extern "C" int rs_conv2d_wgrad_bf16_form(const rs_conv_desc* d) {
+  if (!valid(d)) return RS_EINVAL;
+  int tb = 0, ts = 0;
+  if (rs_wgrad_thin_plan(d, &tb, &ts)) return 1;
+  return phase_ok(d) ? 2 : 0;
+}
+
 extern "C" long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
   int tb = 0, tslices = 0;

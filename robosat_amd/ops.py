@@ -486,8 +486,10 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         ev1.record()
         es = 2 if bf else 4
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
-        _record("conv_wgrad_bf16" if bf else "conv_wgrad_f32", conv_flops(d),
-                        (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes)
+        form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d)) if bf else 0
+        name = ("conv_wgrad_bf16", "conv_wgrad_thin_bf16", "conv_wgrad_bf16<phase>")[form] if bf else "conv_wgrad_f32"
+        _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes,
+                conv_flops(d) * (4.0 / 9.0 if form == 2 else 1.0))
     return dw
 
 

@@ -204,6 +204,9 @@ int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, const rs_bf16
                        const float* scale, const float* shift, const rs_bf16* residual, const rs_bf16* relu_mask,
                        rs_bf16* out, rs_stream_t stream);
 int rs_conv2d_tile_bf16(const rs_conv_desc* d);
+/* Tile index (rs_conv2d_tile_name order) and K-chunk row size (64 | 128 bytes) the dispatcher picks for `d` with `es`-byte
+ * activations, direct (phase4 = 0) or phase form: kernel names in reports then map 1:1 to the launched symbols. */
+int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* rowb);
 const char* rs_conv2d_tile_name_bf16(int tile);
 
 /* rs_conv2d_wgrad with bf16 dy / sources; dw is fp32 KRSC (the optimizer's master gradient). */

@@ -69,6 +69,7 @@ SIGNATURES = {
     # bf16 path (activations typed by a dtype code / bf16 entry points)
     "rs_conv2d_fwd_bf16": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     "rs_conv2d_tile_bf16": (c_int, [POINTER(ConvDesc)]),
+    "rs_conv2d_config": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "rs_conv2d_tile_name_bf16": (c_char_p, [c_int]),
     "rs_conv2d_wgrad_bf16_workspace_bytes": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_wgrad_bf16_form": (c_int, [POINTER(ConvDesc)]),

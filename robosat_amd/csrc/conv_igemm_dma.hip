@@ -602,6 +602,17 @@ int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2,
 
 int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
 
+// For the roofline report (kernel names that map 1:1 to the launched symbol): tile index and K-chunk row bytes the
+// dispatcher picks for `d` with activations of `es` bytes, in the direct (phase4 = 0) or phase form.
+extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* rowb) {
+  if (!valid(d) || (es != 2 && es != 4) || (phase4 && !phase_ok(d))) return RS_EINVAL;
+  const int kc128 = 128 / es;
+  const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
+  if (tile) *tile = pick_tile(d, phase4 != 0);
+  if (rowb) *rowb = (can128 && pick_rowb(d, es, phase4 != 0) == 128) ? 128 : 64;
+  return 0;
+}
+
 // ---- phase form of the decoder convolutions ---------------------------------------------------------------------------
 // fp32 KRSC [Cout][3][3][Cin] -> [4 phases (py, px)][Cout][2][2][Cin] in T: tap (r, s) of phase (py, px) is the sum of the
 // original taps that land on the same source pixel: rows {0},{1,2} for py = 0 and {0,1},{2} for py = 1 (same in x).

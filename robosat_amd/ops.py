@@ -115,7 +115,7 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
         ev1.record()
         name = conv_tile_name(d, bf)
         if alg_scale != 1.0:  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
-            name = name.replace("<", "<phase,")
+            name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                 conv_bytes(d, 2 if bf else 4), conv_flops(d))
     return out
@@ -276,17 +276,23 @@ def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        _record(conv_tile_name(d, bf).replace("<", "<phase,"), conv_flops(d),
+        _record(conv_tile_name(d, bf, phase=True), conv_flops(d),
                 (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 2 if bf else 4),
                 conv_flops(d) * 4.0 / 9.0)
     return out
 
 
-def conv_tile_name(d, bf16=False):
+def conv_tile_name(d, bf16=False, phase=False):
+    """Report name of the kernel a convolution launch runs, 1:1 with the launched symbol:
+    ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel)."""
+
     lib = _lib.lib()
-    if bf16:
-        return lib.rs_conv2d_tile_name_bf16(lib.rs_conv2d_tile_bf16(ctypes.byref(d))).decode()
-    return lib.rs_conv2d_tile_name(lib.rs_conv2d_tile(ctypes.byref(d))).decode()
+    if d.stem:
+        return lib.rs_conv2d_tile_name(lib.rs_conv2d_tile(ctypes.byref(d))).decode()
+    tile, rowb = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.rs_conv2d_config(ctypes.byref(d), 2 if bf16 else 4, int(phase), ctypes.byref(tile), ctypes.byref(rowb)), "rs_conv2d_config")
+    base = (lib.rs_conv2d_tile_name_bf16 if bf16 else lib.rs_conv2d_tile_name)(tile.value).decode()
+    return base.replace("<", "<phase," if phase else "<").replace(">", ",r{}>".format(rowb.value))
 
 
 def cast_bf16(t):

@@ -20,10 +20,10 @@ out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
 
 def bench_name(k):
     k = k.replace("(anonymous namespace)::", "")
-    m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, \d+, (true|false)>", k)
+    m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)>", k)
     if m:
-        return "conv_igemm_{}<{}{}x{}>".format("f32" if m.group(1) == "float" else "bf16", "phase," if m.group(4) == "true" else "",
-                                             m.group(2), m.group(3))
+        return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "float" else "bf16",
+                                                  "phase," if m.group(5) == "true" else "", m.group(2), m.group(3), m.group(4))
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), \d+, \d+, 1>", k)
     if m:
         return "conv_igemm_f32<{}x{},stem>".format(m.group(1), m.group(2))

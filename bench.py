@@ -266,8 +266,10 @@ def main():
 
     el, step = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)
     line = None
+    # every rank runs the two untimed roofline passes: a train step contains the gradient all-reduce, so rank 0 alone
+    # would wait for its peers forever
+    roof, layers = roofline(step)
     if rank == 0:
-        roof, layers = roofline(step)
         if args.layers_json:
             with open(args.layers_json, "w") as fp:
                 json.dump(layers, fp, indent=1)
@@ -287,8 +289,8 @@ def main():
     if args.phase == "predict" and not args.no_train_leg:
         tb, ts, tw = args.train_batch, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
         tel, tstep = run_phase(args, "train", "bf16", tb, ts, tw, device, dist, rank)
+        troof, _ = roofline(tstep)
         if rank == 0:
-            troof, _ = roofline(tstep)
             line["train"] = {"value": round(world * tb * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
                              "ms_per_step": round(tel / ts * 1e3, 3), "dtype": "bf16", "scaling": "weak",
                              "config": workload(args, "train", "bf16", tb, world), "roofline": troof}

@@ -55,7 +55,7 @@ struct ConvArgsT {
   const float* bn_invstd;
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
-  int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4;
+  int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4, direct;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -324,6 +324,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     __syncthreads();
   }
 
+  // ---- direct epilogue (p.direct; no BatchNorm statistics): D[i = cout][j = pixel] puts 4 consecutive couts of one pixel
+  //      in registers 4g..4g+3, so a lane can apply the epilogue and store them itself (16 bytes fp32 / 8 bytes bf16; the
+  //      two half-waves fill 32 / 16 contiguous bytes per pixel row and L2 merges the rows across g, tn) -- no LDS round
+  //      trip, no barrier.  Which of the two wins is shape dependent (measured; see pick_direct).
+  if (p.direct) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int opix = orow[wm * WM + 32 * tm + (lane & 31)];
+      if (opix < 0) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = n0 + wn * WN + 32 * tn + 8 * g + 4 * hh;
+          const long o = (long)opix * p.Cout + c0;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[tn][tm][4 * g + e];
+            v[e] = a * (p.scale ? p.scale[c0 + e] : 1.f) + (p.shift ? p.shift[c0 + e] : 0.f);
+          }
+          if (p.res) {
+            const f32x4 r = rs_ld4(p.res + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (p.mask) {
+            const f32x4 z = rs_ld4(p.mask + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
+          }
+          rs_st4(p.out + o, v);
+        }
+    }
+    return;
+  }
+
   // ---- epilogue: registers -> LDS [pixel][cout] fp32 -> one 16-byte piece of couts per thread, row-wise stores.
   //      TM passes of WGM*32 rows each (pass t = sub-tile tm = t of every wave) keep the staging tile at
   //      WGM*32 x (BN+4) floats: the LDS footprint, hence the blocks per CU, is set by the pipeline buffers alone.
@@ -545,6 +587,13 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.C1 = d->C1;
   a.C2 = d->C2;
   a.phase4 = phase4 ? 1 : 0;
+  {
+    static const int forced = [] {  // RS_CONV_DIRECT=0|1 overrides (measurement knob)
+      const char* e = getenv("RS_CONV_DIRECT");
+      return e ? atoi(e) : -1;
+    }();
+    a.direct = (forced >= 0 ? forced != 0 : false) && !stats;
+  }
   a.ups = phase4 ? 0 : d->ups;  // phase mode gathers on the source grid itself
   a.Hv = a.ups == 0 ? d->Hs : (a.ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
   a.Wv = a.ups == 0 ? d->Ws : (a.ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);

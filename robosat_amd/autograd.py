@@ -18,6 +18,21 @@ import torch
 from . import ops
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for the weight-gradient kernels: a layer's wgrad and dgrad both only read dy, so
+    the wgrad (and its split reduction) runs beside the dgrad -> BatchNorm chain that is the backward's critical path and
+    fills the CUs the short encoder kernels leave idle."""
+
+    s = _SIDE.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE[device] = s
+    return s
+
+
 class GradArena:
     """All parameter gradients of one backward pass live in ONE flat fp32 buffer, carved sequentially in the order
     the backward produces them (head, decoder, layer4 ... stem).  The kernels write straight into their slice, so a
@@ -28,6 +43,8 @@ class GradArena:
     def __init__(self, params, device, reducer=None):
         total = sum((p.numel() + 3) // 4 * 4 for p in params if p.requires_grad)
         self.flat = torch.empty(total, device=device, dtype=torch.float32)
+        self.side = _side_stream(device)
+        self.flat.record_stream(self.side)  # written by the wgrad kernels on the side stream
         self.off = 0
         self.sent = 0
         self.reducer = reducer
@@ -53,12 +70,30 @@ class GradArena:
         self.grads[w] = v.permute(0, 3, 1, 2)
         return v
 
+    def wgrad(self, fn, *tensors):
+        """Run ``fn`` (weight-gradient launches reading ``tensors``) on the side stream, after everything enqueued so far."""
+
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)  # the caching allocator must not recycle them under the side stream
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
     def flush(self):
         if self.reducer is not None and self.off > self.sent:
+            self.join()  # the bucket's weight gradients are complete
             self.reducer.reduce_async(self.flat[self.sent:self.off])
             self.sent = self.off
 
     def finish(self):
+        self.join()
         self.flush()
         if self.reducer is not None:
             self.reducer.wait()
@@ -168,14 +203,16 @@ def _backward(net, tape, dlogits, arena):
                                      db=arena.take(net.final.bias, (net.num_classes,)))
 
     c5 = net.dec5.block
-    ops.conv2d_wgrad(d5, t["dec4"], 3, 3, pad=1, out=arena.conv(c5))
+    w5 = arena.conv(c5)
+    arena.wgrad(lambda: ops.conv2d_wgrad(d5, t["dec4"], 3, 3, pad=1, out=w5), d5, t["dec4"])
     d4 = ops.conv2d(d5, ops.pack_dgrad_weight(c5.krsc(), d5.dtype), pad=1, relu_mask=t["dec4"])
     del d5
 
     def up_bwd(block, dz, skip, prev, mask_skip, mask_prev, skip_grad_out=None):
         """dz = gradient at the block's conv output (ReLU already applied).  Returns (d skip, d prev)."""
         conv = block.block.block
-        ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=arena.conv(conv))
+        wo = arena.conv(conv)
+        arena.wgrad(lambda: ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=wo), dz, skip, prev)
         # phase form: the gradient wrt the pre-upsample tensors is ONE 4x4 / stride-2 convolution over dz (the 2x2 sum of
         # interpolate's backward is folded into pre-summed taps): 4/9 of the MACs, output already at source resolution
         dsrc = ops.conv2d(dz, ops.pack_dgrad_phase_weight(conv.krsc(), dz.dtype), stride=2, pad=1,
@@ -227,24 +264,28 @@ def _backward(net, tape, dlogits, arena):
                                                  **bn_grads(blk.bn3))
             gm = g
         del g
-        ops.conv2d_wgrad(dy3, rec["z2"], 1, 1, out=arena.conv(blk.conv3))
+        w3 = arena.conv(blk.conv3)
+        arena.wgrad(lambda: ops.conv2d_wgrad(dy3, rec["z2"], 1, 1, out=w3), dy3, rec["z2"])
         g2, p2 = dgrad_into_bn(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]), rec["y2"], rec["st2"], rec["z2"])
         del dy3
         dy2, _, _ = ops.bn_bwd_from_partials(g2, rec["y2"], rec["st2"][0], rec["st2"][1], blk.bn2.weight.detach(), p2,
                                              **bn_grads(blk.bn2))
         del g2
-        ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=arena.conv(blk.conv2))
+        w2 = arena.conv(blk.conv2)
+        arena.wgrad(lambda: ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=w2), dy2, rec["z1"])
         g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"])
         del dy2
         dy1, _, _ = ops.bn_bwd_from_partials(g1, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), p1,
                                              **bn_grads(blk.bn1))
         del g1
-        ops.conv2d_wgrad(dy1, h, 1, 1, out=arena.conv(blk.conv1))
+        w1 = arena.conv(blk.conv1)
+        arena.wgrad(lambda: ops.conv2d_wgrad(dy1, h, 1, 1, out=w1), dy1, h)
         extra = skip_grad.get(id(blk))
         if blk.downsample is not None:
             dconv, dbn = blk.downsample[0], blk.downsample[1]
             dyd, _, _ = ops.bn_bwd(gm, None, rec["yd"], rec["std"][0], rec["std"][1], dbn.weight.detach(), **bn_grads(dbn))
-            ops.conv2d_wgrad(dyd, h, 1, 1, stride=blk.stride, out=arena.conv(dconv))
+            wdn = arena.conv(dconv)
+            arena.wgrad(lambda: ops.conv2d_wgrad(dyd, h, 1, 1, stride=blk.stride, out=wdn), dyd, h)
             res = _dgrad(dyd, dconv, hw_in, residual=extra)
             del dyd
         else:

@@ -436,14 +436,16 @@ _WORKSPACE = {}
 
 
 def _workspace(nbytes, device):
-    """A per-device scratch buffer, grown on demand.  All kernels run on one stream, so successive users serialise."""
+    """A scratch buffer per (device, stream), grown on demand: users on one stream serialise; the weight-gradient side
+    stream of the backward pass (robosat_amd.autograd) gets its own."""
 
     if nbytes < 0:
         raise ValueError("workspace query failed (RS_EINVAL)")
-    ws = _WORKSPACE.get(device)
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
-        _WORKSPACE[device] = ws
+        _WORKSPACE[key] = ws
     return ctypes.c_void_p(ws.data_ptr())
 
 

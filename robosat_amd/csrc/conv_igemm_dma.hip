@@ -688,29 +688,38 @@ __global__ void pack_phase_weight_kernel(const float* __restrict__ w, T* __restr
 //   d_src[u][v][ci] = sum_{ty,tx,co} dz[2u - 1 + ty][2v - 1 + tx][co] * Wd[ci][ty][tx][co],
 // Wd[ty] = sum of the taps ky with ((2u - 1 + ty) + ky - 1) >> 1 == u:  ty 0 -> {2}, 1 -> {1,2}, 2 -> {0,1}, 3 -> {0}.
 template <typename T>
-__global__ void pack_dgrad_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int co = (int)(i % Cout);
-  long t = i / Cout;
-  const int tx = (int)(t & 3), ty = (int)((t >> 2) & 3);
-  const int ci = (int)(t >> 4);
-  const int ky0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), ky1 = ty == 0 ? 2 : (ty == 1 ? 2 : (ty == 2 ? 1 : 0));
-  const int kx0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), kx1 = tx == 0 ? 2 : (tx == 1 ? 2 : (tx == 2 ? 1 : 0));
-  float acc = 0.f;
-  for (int ky = ky0; ky <= ky1; ++ky)
-    for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
-  out[i] = (T)acc;
+__global__ __launch_bounds__(256) void pack_dgrad_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout,
+                                                                      int Cin) {
+  // block = 32 cins x 32 couts, all taps: reads coalesced along ci (the KRSC inner dimension), LDS transpose, writes
+  // coalesced along co (the inner dimension of [Cin][4][4][Cout])
+  __shared__ float tile[9][32][33];  // [tap][co][ci]
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int e = ty; e < 9 * 32; e += 8) {
+    const int k = e / 32, co = e - k * 32;
+    tile[k][co][tx] = (co0 + co < Cout && ci0 + tx < Cin) ? w[((long)(co0 + co) * 9 + k) * Cin + ci0 + tx] : 0.f;
+  }
+  __syncthreads();
+  for (int e = ty; e < 16 * 32; e += 8) {
+    const int t = e / 32, ci = e - t * 32;  // thread writes out[ci0+ci][t][co0+tx]
+    const int ty4 = t >> 2, tx4 = t & 3;
+    const int ky0 = ty4 == 0 ? 2 : (ty4 == 1 ? 1 : 0), ky1 = ty4 == 0 ? 2 : (ty4 == 1 ? 2 : (ty4 == 2 ? 1 : 0));
+    const int kx0 = tx4 == 0 ? 2 : (tx4 == 1 ? 1 : 0), kx1 = tx4 == 0 ? 2 : (tx4 == 1 ? 2 : (tx4 == 2 ? 1 : 0));
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += tile[ky * 3 + kx][tx][ci];
+    if (ci0 + ci < Cin && co0 + tx < Cout) out[((long)(ci0 + ci) * 16 + t) * Cout + co0 + tx] = (T)acc;
+  }
 }
 
 extern "C" int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream) {
   if (!w_krsc || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
-  const long total = 16L * Cout * Cin;
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(rs_cdiv(Cin, 32), rs_cdiv(Cout, 32));
   if (dtype == RS_F32)
-    pack_dgrad_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin, total);
+    pack_dgrad_phase_weight_kernel<float><<<grid, 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin);
   else if (dtype == RS_BF16)
-    pack_dgrad_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin, total);
+    pack_dgrad_phase_weight_kernel<bf16_t><<<grid, 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin);
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();

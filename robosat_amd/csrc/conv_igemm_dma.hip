@@ -135,6 +135,10 @@ __device__ __forceinline__ void rb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int 
 }
 
 __device__ __forceinline__ void rb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void rb_dma_wait_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
   return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
@@ -142,8 +146,9 @@ __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
 
 constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 data gradient of an upsampled 3x3)
 
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE>
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int NBUF = 2>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
+  static_assert(NBUF == 2 || NBUF == 3, "2 or 3 pipeline buffers");
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
   constexpr int NW = 4;
@@ -159,11 +164,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   constexpr int KS = CPR / 2;         // k-steps per chunk (two pieces each: lanes 0-31 / 32-63)
   constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline buffer
   constexpr int LDO = BN + 4;         // epilogue staging row (floats)
-  constexpr int PIPE = 2 * BUF, STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
+  constexpr int PIPE = NBUF * BUF, STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
   constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
   constexpr int TABN = (2 * kMaxK + 1) * BM;  // separable gather table (tap row | tap column) x tile row + output rows
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
   static_assert((IA % NW) == 0 && IB >= 1 && (BM % RI) == 0 && (BN % RI) == 0, "DMA instruction split");
+  static_assert(NBUF == 2 || ((IA + IB) % NW) == 0, "counted vmcnt waits need the same DMA count in every wave");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAINB + TABN * 4];
   int* taby = reinterpret_cast<int*>(smem + MAINB);  // [kh][BM]: ((n - nfirst)*Hs + iy) * Ws, or -1
@@ -305,14 +311,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
       for (int tn = 0; tn < TN; ++tn) mma16(acc[tn][tm], b[tn], a[tm], T());
   };
 
-  // ---- main loop: chunk k+1 streams HBM -> LDS (other buffer) by DMA while the MFMAs of chunk k run; one barrier per
-  //      chunk, each wave having waited for its own DMA instructions first.
-  issue_dma(0);
-  rb_dma_wait();
-  __syncthreads();
+  // ---- main loop: the chunks k+1 .. k+NBUF-1 stream HBM -> LDS by DMA while the MFMAs of chunk k run; one barrier per
+  //      chunk.  Each wave first waits for ITS OWN DMA instructions of chunk k with a COUNTED s_waitcnt (loads complete in
+  //      order: allowing NI*(chunks still in flight) outstanding == chunk k has landed), the barrier publishes everybody's,
+  //      and only then the buffer freed by chunk k-1 is refilled.  With three buffers a chunk has two iterations to land:
+  //      the short-K encoder layers, whose iteration is one DMA round trip and 8 MFMAs long, run ~1.5x faster per block.
+  constexpr int AHEAD = NBUF - 1;
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j)
+    if (j < p.nk) issue_dma(j);
   for (int kc = 0; kc < p.nk; ++kc) {
-    const unsigned char* L = smem + (kc & 1) * BUF;
-    if (kc + 1 < p.nk) issue_dma((kc + 1) & 1);  // (uniform branch) nothing to fetch behind the last chunk
+    if (NBUF == 3 && kc + 1 < p.nk) rb_dma_wait_n<NI>();  // chunk kc+1 may stay in flight
+    else rb_dma_wait();
+    __syncthreads();
+    if (kc + AHEAD < p.nk) issue_dma((kc + AHEAD) % NBUF);  // (uniform) the buffer chunk kc-1 was read from
+    const unsigned char* L = smem + (kc % NBUF) * BUF;
     u32x4 fa[2][TM], fb[2][TN];
     read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
@@ -320,9 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
       if (s + 1 < KS) read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
       mma_frag(fa[s & 1], fb[s & 1]);
     }
-    rb_dma_wait();
-    __syncthreads();
   }
+  __syncthreads();  // every wave is done with the pipeline buffers: the epilogue stages through them
 
   // ---- direct epilogue (p.direct; no BatchNorm statistics): D[i = cout][j = pixel] puts 4 consecutive couts of one pixel
   //      in registers 4g..4g+3, so a lane can apply the epilogue and store them itself (16 bytes fp32 / 8 bytes bf16; the
@@ -551,6 +563,22 @@ int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false) {
 
 template <typename T, int ROWB, bool PHASE>
 void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
+  // RS_CONV_NBUF=3 (measurement knob): three pipeline buffers with counted vmcnt waits for the 64-byte-row kernels (two
+  // chunks in flight per block, but 3 instead of 4 blocks per CU).  Measured per layer on both paths: a wash to slightly
+  // slower (fp32 predict 14.48 -> 14.79 ms of convolutions, bf16 train 17.5 -> 18.0) -- occupancy hides the DMA round trip
+  // better than depth here -- so two buffers stay the default.
+  static const int nbuf3 = [] {
+    const char* e = getenv("RS_CONV_NBUF");
+    return e && atoi(e) == 3;
+  }();
+  if (ROWB == 64 && nbuf3 && tile != T128x32) {
+    switch (tile) {
+      case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, 64, PHASE, 3><<<grid, 256, 0, s>>>(a); break;
+      case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, 64, PHASE, 3><<<grid, 256, 0, s>>>(a); break;
+      default: conv_igemm_dma<T, 64, 64, 2, 2, 64, PHASE, 3><<<grid, 256, 0, s>>>(a); break;
+    }
+    return;
+  }
   switch (tile) {
     case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
     case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;

@@ -263,6 +263,13 @@ def main():
         td.init_process_group(backend="nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if dist:
+        # Create the communicator now and push whatever RCCL wrote through C stdio (it prints a version banner on first
+        # use) out of the buffer, so that the JSON line below stays the LAST line of stdout.
+        import ctypes
+
+        td.barrier(device_ids=[local])
+        ctypes.CDLL(None).fflush(None)
 
     el, step = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)
     line = None
@@ -300,10 +307,14 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds, args.phase, args.loss)
-        print(json.dumps(line), flush=True)
     if dist:
+        import ctypes
+
         td.barrier()
         td.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)  # anything RCCL still holds in C stdio goes out BEFORE the JSON line
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -280,6 +280,11 @@ int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, c
  * rs_cat_split_bwd_dt then only splits torch.cat's channels, applies the ReLU masks and accumulates (rs_upsample2x_bwd
  * without the 2x2 sum). */
 int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
+/* rs_conv2d_fwd with torch.cat's backward fused into the store: output channels [0, csplit) -> out1 (row stride csplit,
+ * zeroed where mask1 <= 0 if mask1 != NULL), [csplit, Cout) -> out2 (row stride Cout - csplit, mask2); csplit must be a
+ * multiple of the tile's cout width (64 | 128 for these layers). */
+int rs_conv2d_fwd_split_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* weight, void* out1, const void* mask1,
+                           void* out2, const void* mask2, int csplit, rs_stream_t stream);
 int rs_cat_split_bwd_dt(const void* dcat, void* d1, void* d2, const void* mask1, const void* mask2, int dtype, int N, int H,
                         int W, int C1, int C2, int accumulate1, rs_stream_t stream);
 

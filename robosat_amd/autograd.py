@@ -215,11 +215,16 @@ def _backward(net, tape, dlogits, arena):
         arena.wgrad(lambda: ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=wo), dz, skip, prev)
         # phase form: the gradient wrt the pre-upsample tensors is ONE 4x4 / stride-2 convolution over dz (the 2x2 sum of
         # interpolate's backward is folded into pre-summed taps): 4/9 of the MACs, output already at source resolution
-        dsrc = ops.conv2d(dz, ops.pack_dgrad_phase_weight(conv.krsc(), dz.dtype), stride=2, pad=1,
-                          out_hw=(skip.shape[1], skip.shape[2]), alg_scale=2.25)
+        wd = ops.pack_dgrad_phase_weight(conv.krsc(), dz.dtype)
+        hw = (skip.shape[1], skip.shape[2])
         c1 = skip.shape[3]
-        c2 = 0 if prev is None else prev.shape[3]
-        return ops.cat_split_bwd(dsrc, c1, c2, mask1=mask_skip, mask2=mask_prev, out1=skip_grad_out)
+        if prev is None and skip_grad_out is None:  # single source: the ReLU mask rides in the epilogue, nothing to split
+            return ops.conv2d(dz, wd, stride=2, pad=1, out_hw=hw, relu_mask=mask_skip, alg_scale=2.25), None
+        if prev is not None and skip_grad_out is None and c1 % 128 == 0:  # torch.cat's backward fused into the store (two destinations)
+            return ops.conv2d_split(dz, wd, c1, stride=2, pad=1, out_hw=hw, mask1=mask_skip, mask2=mask_prev, alg_scale=2.25)
+        dsrc = ops.conv2d(dz, wd, stride=2, pad=1, out_hw=hw, alg_scale=2.25)
+        return ops.cat_split_bwd(dsrc, c1, 0 if prev is None else prev.shape[3], mask1=mask_skip, mask2=mask_prev,
+                                 out1=skip_grad_out)
 
     d3, _ = up_bwd(net.dec4, d4, t["dec3"], None, t["dec3"], None)
     del d4

@@ -53,6 +53,11 @@ struct ConvArgsT {
   const T* bn_y;
   const float* bn_mean;
   const float* bn_invstd;
+  // optional second destination (the torch.cat split of a decoder data gradient): couts [0, csplit) go to `out` (row
+  // stride csplit, `mask`), couts [csplit, Cout) to `out2` (row stride Cout - csplit, `mask2`); csplit % BN == 0
+  T* out2;
+  const T* mask2;
+  int csplit;
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4, direct;
@@ -392,6 +397,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     sc[e] = p.scale ? p.scale[col + e] : 1.f;
     sh[e] = p.shift ? p.shift[col + e] : 0.f;
   }
+  T* outp = p.out;  // destination of this block's couts (block-uniform: a tile never straddles csplit)
+  const T* maskp = p.mask;
+  int ostride = p.Cout, ocol = col;
+  if (p.out2) {
+    if (n0 >= p.csplit) {
+      outp = p.out2;
+      maskp = p.mask2;
+      ostride = p.Cout - p.csplit;
+      ocol = col - p.csplit;
+    } else {
+      ostride = p.csplit;
+    }
+  }
   float st0[EPP], st1[EPP];  // BatchNorm statistics of this thread's rows (only when p.stats)
   float bmu[EPP], bis[EPP];
 #pragma unroll
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
       const int row = (lrow >> 5) * WM + 32 * tm + (lrow & 31);  // tile row of pass-local row lrow
       const int opix = orow[row];
       if (opix >= 0) {
-        const long o = (long)opix * p.Cout + col;
+        const long o = (long)opix * ostride + ocol;
         float v[EPP];
 #pragma unroll
         for (int h = 0; h < EPP / 4; ++h) {
@@ -442,13 +460,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
 #pragma unroll
           for (int e = 0; e < EPP; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.mask) {
+        if (maskp) {
           float z[EPP];
-          Piece<T>::load(p.mask + o, z);
+          Piece<T>::load(maskp + o, z);
 #pragma unroll
           for (int e = 0; e < EPP; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
         }
-        Piece<T>::store(p.out + o, v);
+        Piece<T>::store(outp + o, v);
         if (p.stats) {
           float w[EPP];
           Piece<T>::round(v, w);  // statistics of the values as stored (bf16-rounded on the bf16 path)
@@ -591,8 +609,10 @@ template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
              float* stats = nullptr, const void* bn_y = nullptr, const float* bn_mean = nullptr,
-             const float* bn_invstd = nullptr, bool phase4 = false) {
+             const float* bn_invstd = nullptr, bool phase4 = false, void* out2 = nullptr, const void* mask2 = nullptr,
+             int csplit = 0) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
+  if (out2 && (csplit <= 0 || csplit >= d->Cout || residual || stats)) return RS_EINVAL;
   if (phase4 && (!phase_ok(d) || stats)) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
   constexpr long ES = (long)sizeof(T);
@@ -609,6 +629,9 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.bn_y = reinterpret_cast<const T*>(bn_y);
   a.bn_mean = bn_mean;
   a.bn_invstd = bn_invstd;
+  a.out2 = reinterpret_cast<T*>(out2);
+  a.mask2 = reinterpret_cast<const T*>(mask2);
+  a.csplit = csplit;
   a.N = d->N;
   a.Hs = d->Hs;
   a.Ws = d->Ws;
@@ -656,6 +679,8 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.relu = d->relu;
 
   const int tile = pick_tile(d, phase4);
+  if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
+  a.direct = a.direct && !out2;
   a.ntiles = d->Cout / kTileBN[tile];
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
   hipStream_t s = (hipStream_t)stream;
@@ -764,6 +789,20 @@ extern "C" int rs_pack_phase_weight_dt(const float* w_krsc, void* out, int dtype
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();
+}
+
+// rs_conv2d_fwd with the torch.cat split of a decoder data gradient fused into the store: output channels [0, csplit) ->
+// out1 [N][Ho][Wo][csplit] (zeroed where mask1 <= 0 if given), [csplit, Cout) -> out2 [N][Ho][Wo][Cout-csplit] (mask2).
+extern "C" int rs_conv2d_fwd_split_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* weight, void* out1,
+                                      const void* mask1, void* out2, const void* mask2, int csplit, rs_stream_t stream) {
+  if (!out2 || (d && d->C2 != 0)) return RS_EINVAL;
+  if (dtype == RS_F32)
+    return conv_fwd<float>(d, src1, nullptr, weight, nullptr, nullptr, nullptr, mask1, out1, stream, nullptr, nullptr, nullptr,
+                           nullptr, false, out2, mask2, csplit);
+  if (dtype == RS_BF16)
+    return conv_fwd<bf16_t>(d, src1, nullptr, weight, nullptr, nullptr, nullptr, mask1, out1, stream, nullptr, nullptr,
+                            nullptr, nullptr, false, out2, mask2, csplit);
+  return RS_EINVAL;
 }
 
 extern "C" int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2,

@@ -238,6 +238,33 @@ def pack_dgrad_phase_weight(w_krsc, dtype=torch.float32):
     return out
 
 
+def conv2d_split(src, weight, c1, stride=1, pad=0, out_hw=None, mask1=None, mask2=None, alg_scale=1.0):
+    """``rs_conv2d_fwd_split_dt``: one convolution whose output channels [0, c1) and [c1, Cout) land in two tensors (the
+    backward of torch.cat fused into the store), each with its optional ReLU mask.  Returns (out1, out2)."""
+
+    d = conv_desc(src, weight, None, 0, stride, pad, False, 0, out_hw)
+    act = src.dtype
+    c2 = d.Cout - c1
+    out1 = torch.empty((d.N, d.Ho, d.Wo, c1), device=src.device, dtype=act)
+    out2 = torch.empty((d.N, d.Ho, d.Wo, c2), device=src.device, dtype=act)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv2d_fwd_split_dt(ctypes.byref(d), _dt(src), _dev(src, "src", act), _dev(weight, "weight", act),
+                                           _dev(out1, "out1", act), _dev(mask1, "mask1", act), _dev(out2, "out2", act),
+                                           _dev(mask2, "mask2", act), c1, _stream())
+    check(rc, "rs_conv2d_fwd_split_dt")
+    if PROFILE is not None:
+        ev1.record()
+        bf = act == BF16
+        name = conv_tile_name(d, bf)
+        if alg_scale != 1.0:
+            name = name.replace("<", "<dgrad4x4,")
+        _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                conv_bytes(d, 2 if bf else 4), conv_flops(d))
+    return out1, out2
+
+
 def cat_split_bwd(dcat, c1, c2=0, mask1=None, mask2=None, out1=None):
     """dcat [N,H,W,C1+C2] -> (d1 [N,H,W,C1], d2 [N,H,W,C2] or None): the torch.cat split + ReLU masks; ``out1`` given =>
     accumulate into it."""

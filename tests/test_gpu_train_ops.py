@@ -274,3 +274,12 @@ def test_decoder_dgrad_phase_form(c1, c2, cout, h, w, dtype):
     close(nchw(d1.float()), base + a.grad * (m1 > 0), tol, "d skip")
     if c2:
         close(nchw(d2.float()), b.grad, tol, "d prev")
+        if c1 % 64 == 0 and cout % 32 == 0:  # the same split fused into the convolution's store
+            m2 = rq(rnd(n, c2, h, w, seed=7))
+            try:
+                e1, e2 = ops.conv2d_split(nhwc(dz).to(dtype), wd, c1, stride=2, pad=1, out_hw=(h, w), mask1=nhwc(m1).to(dtype),
+                                          mask2=nhwc(m2).to(dtype))
+            except ValueError:
+                return  # csplit not a multiple of the tile's cout width for this shape
+            close(nchw(e1.float()), a.grad * (m1 > 0), tol, "fused d skip")
+            close(nchw(e2.float()), b.grad * (m2 > 0), tol, "fused d prev")

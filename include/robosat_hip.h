@@ -280,6 +280,9 @@ int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, c
  * rs_cat_split_bwd_dt then only splits torch.cat's channels, applies the ReLU masks and accumulates (rs_upsample2x_bwd
  * without the 2x2 sum). */
 int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
+/* The same weights from the already transposed, tap-flipped fp32 weights of rs_pack_dgrad_weight ([Cin][3][3][Cout]):
+ * both sides contiguous along Cout (the one-step pack reads with a 9*Cin stride). */
+int rs_combine_dgrad_phase_weight_dt(const float* w_dgrad, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
 /* rs_conv2d_fwd with torch.cat's backward fused into the store: output channels [0, csplit) -> out1 (row stride csplit,
  * zeroed where mask1 <= 0 if mask1 != NULL), [csplit, Cout) -> out2 (row stride Cout - csplit, mask2); csplit must be a
  * multiple of the tile's cout width (64 | 128 for these layers). */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 10
+ABI_VERSION = 11
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "rs_pack_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_phase_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P]),
     "rs_pack_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "rs_combine_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_split_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, c_int, P]),
     "rs_cat_split_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_conv2d_dgrad_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),

@@ -13,6 +13,8 @@ Backward structure (no tensor is ever upsampled or concatenated in memory, in ei
     ``torch.cat`` split + the ReLU masks into one pass.
 """
 
+import os
+
 import torch
 
 from . import ops
@@ -26,6 +28,8 @@ def _side_stream(device):
     the wgrad (and its split reduction) runs beside the dgrad -> BatchNorm chain that is the backward's critical path and
     fills the CUs the short encoder kernels leave idle."""
 
+    if os.environ.get("ROBOSAT_WGRAD_STREAM", "1") == "0":  # measurement knob: serial backward (clean per-kernel timings)
+        return torch.cuda.current_stream(device)
     s = _SIDE.get(device)
     if s is None:
         s = torch.cuda.Stream(device=device)

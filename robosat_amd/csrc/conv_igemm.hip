@@ -296,11 +296,11 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
   out[idx] = v;
 }
 
-enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM, NTILES };
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM, T256x128, NTILES };
 const char* const kTileNames[NTILES] = {"conv_igemm_f32<128x128>", "conv_igemm_f32<128x64>", "conv_igemm_f32<128x32>",
-                                        "conv_igemm_f32<64x64>", "conv_igemm_f32<128x64,stem>"};
-const int kTileBM[NTILES] = {128, 128, 128, 64, 128};
-const int kTileBN[NTILES] = {128, 64, 32, 64, 64};
+                                        "conv_igemm_f32<64x64>", "conv_igemm_f32<128x64,stem>", "conv_igemm_f32<256x128>"};
+const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256};
+const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128};
 
 bool valid(const rs_conv_desc* d) {
   if (!d) return false;

@@ -32,6 +32,8 @@
 //            ReLU / ReLU-mask, one 16-byte bf16x8 store.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -116,7 +118,8 @@ __device__ __forceinline__ void mma16(f32x16& acc, const u32x4 a, const u32x4 b,
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_make_rsrc(const void* base, long bytes) {
-  const unsigned int n = bytes > 0xFFFFFFFEL ? 0xFFFFFFFEu : (unsigned int)(bytes < 0 ? 0 : bytes);
+  // (clipped below kDmaOOB: every offset the kernels form is < 2^31, and the out-of-range sentinel must stay out of range)
+  const unsigned int n = bytes > 0xFFFE0000L ? 0xFFFE0000u : (unsigned int)(bytes < 0 ? 0 : bytes);
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
 }
 
@@ -139,6 +142,23 @@ __device__ __forceinline__ void rb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int 
       : "memory");
 }
 
+// The same with a wave-uniform byte offset `soff` added to the address (the SOFFSET operand): the per-lane offsets of a
+// (tap, source) stay in registers and the K loop advances through the channels with one SGPR.  kDmaOOB + soff is out of
+// range for every rsrc rb_make_rsrc builds (zeros land in the LDS): the per-lane offset of a padding / past-the-end row.
+// m0 is declared clobbered rather than saved and restored (two SALU per piece, eight pieces per chunk per wave): the
+// compiler itself only touches m0 for M0-operand LDS builtins and dynamically indexed register arrays, and this file has
+// neither (every register array is indexed by unrolled constants) -- check `grep m0` of the ISA after touching the kernel.
+constexpr int kDmaOOB = (int)0xFFFF0000u;
+__device__ __forceinline__ void rb_dma16s(__amdgpu_buffer_rsrc_t r, unsigned int lds_dst, int voff, int soff) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %2, %3 offen lds"
+      :
+      : "v"(voff), "s"(lds_dst), "s"(r), "s"(soff)
+      : "memory", "m0");
+}
+
 __device__ __forceinline__ void rb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void rb_dma_wait_n() {
@@ -151,12 +171,15 @@ __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
 
 constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 data gradient of an upsampled 3x3)
 
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int NBUF = 2>
-__global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
-  static_assert(NBUF == 2 || NBUF == 3, "2 or 3 pipeline buffers");
-  static_assert(WGM * WGN == 4, "4 waves per block");
+// DBG (measurement builds only, RS_CONV_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = MFMAs on
+// the first chunk's fragments only (no LDS reads in the loop): the three legs of the main loop, timed apart.
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int NBUF = 2, int DBG = 0>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_igemm_dma(const ConvArgsT<T> p) {
+  static_assert(NBUF >= 2 && NBUF <= 4, "2..4 pipeline buffers");
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
   static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
-  constexpr int NW = 4;
+  constexpr int NW = WGM * WGN;  // waves; the 8-wave blocks (256- and 512-row tiles) run one per CU
+  constexpr int NT = 64 * NW;
   constexpr int ES = (int)sizeof(T);  // element size
   constexpr int EPP = 16 / ES;        // elements per 16-byte piece
   constexpr int KC = ROWB / ES;       // channels per chunk
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
 
   // ---- separable gather table, relative to the tile's first image: source pixel of (row, tap (r, s)) =
   //      taby[r][row] + tabx[s][row] when both are >= 0, else the tap contributes zeros ------------------------------
-  for (int e = tid; e < (p.kh + p.kw + 1) * BM; e += 256) {
+  for (int e = tid; e < (p.kh + p.kw + 1) * BM; e += NT) {
     const int t = e / BM, row = e - t * BM;
     const int m = m0 + row;
     int v = -1;
@@ -247,35 +270,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   const int fsw = ROWB == 128 ? ((4 * (wave & 1) + (ra >> 1)) & 7) : ((ra >> 2) & 3);  // f(RI*ii + ra): ii = wave (mod 2)
   const int gp = pp ^ fsw;
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane(rb_lds_addr(smem));
-  int wrow[NI];  // byte offset of this lane's piece in weight row (n0 + RI*jj + ra), chunk 0
+  constexpr int NIA = IA / NW;  // this wave's pieces j < NIA copy pixel rows, the others weight rows
+  int wrow[NI];                 // byte offset of this lane's piece in weight row (n0 + RI*jj + ra), chunk 0
 #pragma unroll
   for (int j = 0; j < NI; ++j) wrow[j] = ((n0 + RI * (wave + NW * j - IA) + ra) * p.Kw + gp * EPP) * ES;
   __syncthreads();
 
-  int lr = 0, ls = 0, lc = 0, lk = 0;  // next chunk to fetch: tap row / tap column / channel chunk / linear index
-  auto issue_dma = [&](int buf) __attribute__((always_inline)) {
-    const unsigned int L = lds0 + buf * BUF;
+  // Per-lane byte offsets of the pixel pieces for the (tap, source) being fetched, chunk 0 of it; kDmaOOB for a padding
+  // row.  Rebuilt from the gather tables only when the tap or the concat source changes -- the chunks in between differ
+  // by the wave-uniform channel offset alone, which rides in the DMA's SOFFSET.
+  int pbase[NIA];
+  auto load_tap = [&](int (&dst)[NIA], int r, int s_, bool first) __attribute__((always_inline)) {
+    const int cs2 = (first ? p.C1 : p.C2) * ES;
+#pragma unroll
+    for (int j = 0; j < NIA; ++j) {
+      const int row = RI * (wave + NW * j) + ra;
+      const int y = taby[r * BM + row], x = tabx[s_ * BM + row];
+      dst[j] = (y | x) < 0 ? kDmaOOB : (y + x) * cs2 + gp * 16;
+    }
+  };
+  // state of the chunk being fetched (wave-uniform): tap row / column, channel chunk, linear index; and what its pieces
+  // need: destination buffer, source descriptor, channel byte offset within the source, weight byte offset.
+  // (K order = the weights' memory order: taps outer, channel chunks inner.  Channel chunks outer / taps inner was tried
+  // for the phase form -- same fabric traffic per launch (FETCH_SIZE), same time -- and dropped: its summation order
+  // depends on the chunk size, which depends on the batch, and predictions must not.)
+  int lr = 0, ls = 0, lc = 0, lk = 0;
+  unsigned int fL = lds0;
+  __amdgpu_buffer_rsrc_t frs = rsrc1;
+  int fsa = 0, fsb = 0;
+  auto begin_chunk = [&](int buf) __attribute__((always_inline)) {
     const int c0 = lc * KC;
     const bool first = c0 < p.C1;
-    const __amdgpu_buffer_rsrc_t rs = first ? rsrc1 : rsrc2;
-    const int cs2 = (first ? p.C1 : p.C2) * ES;
-    const int cb = ((first ? c0 : c0 - p.C1) + gp * EPP) * ES;
-    int pix[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int row = RI * (wave + NW * j) + ra;
-      const int y = (NW * j < IA) ? taby[lr * BM + row] : 0, x = (NW * j < IA) ? tabx[ls * BM + row] : 0;
-      pix[j] = (y | x) < 0 ? -1 : y + x;
-    }
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int ii = wave + NW * j;  // wave-uniform; IA % 4 == 0, so the role depends on j alone
-      if (NW * j < IA) {
-        rb_dma16(rs, L + ii * 1024, pix[j] >= 0 ? pix[j] * cs2 + cb : -1);
-      } else if ((IB % NW) == 0 || ii < IA + IB) {
-        rb_dma16(rsrcw, L + ii * 1024, wrow[j] + lk * ROWB);
-      }
-    }
+    if (lc == 0 || c0 == p.C1) load_tap(pbase, lr, ls, first);  // (uniform) new tap, or the second concat source begins
+    fL = lds0 + buf * BUF;
+    frs = first ? rsrc1 : rsrc2;
+    fsa = (first ? c0 : c0 - p.C1) * ES;
+    fsb = lk * ROWB;
     ++lk;  // advance to the following chunk
     ++lc;
     const int w1 = (lc == p.cpt) ? 1 : 0;
@@ -284,6 +314,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     const int w2 = (ls == p.kw) ? 1 : 0;
     ls = w2 ? 0 : ls;
     lr += w2;
+  };
+  auto issue_piece = [&](int j) __attribute__((always_inline)) {  // j: compile-time after unrolling
+    const int ii = wave + NW * j;  // wave-uniform; IA % NW == 0, so the role depends on j alone
+    if (j < NIA) {
+      rb_dma16s(frs, fL + ii * 1024, pbase[j], fsa);
+    } else if ((IB % NW) == 0 || ii < IA + IB) {
+      rb_dma16s(rsrcw, fL + ii * 1024, wrow[j], fsb);
+    }
   };
 
   f32x16 acc[TN][TM];  // [cout sub-tile][pixel sub-tile]; D rows = couts, D cols = pixels
@@ -309,13 +347,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(L + bbase + 32 * tn * ROWB + foff[s]);
   };
-  auto mma_frag = [&](const u32x4 (&a)[TM], const u32x4 (&b)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) mma16(acc[tn][tm], b[tn], a[tm], T());
-  };
-
   // ---- main loop: the chunks k+1 .. k+NBUF-1 stream HBM -> LDS by DMA while the MFMAs of chunk k run; one barrier per
   //      chunk.  Each wave first waits for ITS OWN DMA instructions of chunk k with a COUNTED s_waitcnt (loads complete in
   //      order: allowing NI*(chunks still in flight) outstanding == chunk k has landed), the barrier publishes everybody's,
@@ -324,21 +355,61 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   constexpr int AHEAD = NBUF - 1;
 #pragma unroll
   for (int j = 0; j < AHEAD; ++j)
-    if (j < p.nk) issue_dma(j);
-  for (int kc = 0; kc < p.nk; ++kc) {
-    if (NBUF == 3 && kc + 1 < p.nk) rb_dma_wait_n<NI>();  // chunk kc+1 may stay in flight
-    else rb_dma_wait();
+    if (j < p.nk) {
+      begin_chunk(j);
+#pragma unroll
+      for (int q = 0; q < NI; ++q) issue_piece(q);
+    }
+  // The pieces of chunk kc+AHEAD are issued BETWEEN the MFMAs of chunk kc (one piece every PSTEP MFMAs from the start
+  // of the chunk): an LDS-DMA instruction costs the issuing wave 60-180 cycles, which a burst at the top of the chunk
+  // would add to the critical path of every wave of the block at once.
+  constexpr int NMMA = KS * TM * TN;
+  constexpr int PSTEP = NMMA / (2 * NI) >= 1 ? NMMA / (2 * NI) : 1;  // front-loaded: the tail of the chunk covers the latency
+  constexpr int PIN = (NMMA + PSTEP - 1) / PSTEP < NI ? (NMMA + PSTEP - 1) / PSTEP : NI;  // pieces placed between MFMAs
+  // One chunk: wait for it, publish it, then its MFMAs -- with the pieces of chunk kc+AHEAD in between when FETCH.  Two
+  // loops (steady state with FETCH, then the last AHEAD chunks without) rather than a branch per piece: a diamond inside
+  // one loop made hipcc keep the 64 accumulator registers of the two arms apart (64 v_mov per chunk).
+  auto chunk = [&](int kc, auto fetch_tag) __attribute__((always_inline)) {
+    constexpr bool FETCH = decltype(fetch_tag)::value;
+    {  // chunks kc+1 .. kc+NBUF-2 may stay in flight (fewer at the tail of the loop)
+      const int fly = p.nk - 1 - kc;
+      if (NBUF >= 4 && fly >= 2) rb_dma_wait_n<2 * NI>();
+      else if (NBUF >= 3 && fly >= 1) rb_dma_wait_n<NI>();
+      else rb_dma_wait();
+    }
     __syncthreads();
-    if (kc + AHEAD < p.nk) issue_dma((kc + AHEAD) % NBUF);  // (uniform) the buffer chunk kc-1 was read from
-    const unsigned char* L = smem + (kc % NBUF) * BUF;
+    if (FETCH) begin_chunk((kc + AHEAD) % NBUF);  // refills the buffer chunk kc-1 was read from
+    if (DBG & 2) {
+      if (FETCH) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) issue_piece(q);
+      }
+      return;
+    }
+    const unsigned char* L = smem + ((DBG & 4) ? 0 : (kc % NBUF)) * BUF;
     u32x4 fa[2][TM], fb[2][TN];
     read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-      mma_frag(fa[s & 1], fb[s & 1]);
+      if (s + 1 < KS && !(DBG & 4)) read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int q = (s * TM + tm) * TN + tn;  // MFMA index within the chunk (compile-time after unrolling)
+          if (FETCH && q % PSTEP == 0 && q / PSTEP < PIN) issue_piece(q / PSTEP);
+          mma16(acc[tn][tm], fb[(DBG & 4) ? 0 : (s & 1)][tn], fa[(DBG & 4) ? 0 : (s & 1)][tm], T());
+        }
     }
-  }
+    if (FETCH) {
+#pragma unroll
+      for (int q = PIN; q < NI; ++q) issue_piece(q);  // (tiles with fewer MFMAs per chunk than pieces)
+    }
+  };
+  const int nfetch = (DBG & 1) ? 0 : (p.nk - AHEAD > 0 ? p.nk - AHEAD : 0);
+  int kc = 0;
+  for (; kc < nfetch; ++kc) chunk(kc, std::true_type());
+  for (; kc < p.nk; ++kc) chunk(kc, std::false_type());
   __syncthreads();  // every wave is done with the pipeline buffers: the epilogue stages through them
 
   // ---- direct epilogue (p.direct; no BatchNorm statistics): D[i = cout][j = pixel] puts 4 consecutive couts of one pixel
@@ -356,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c0 = n0 + wn * WN + 32 * tn + 8 * g + 4 * hh;
+          if (c0 >= p.Cout) continue;  // ragged last N tile
           const long o = (long)opix * p.Cout + c0;
           f32x4 v;
 #pragma unroll
@@ -388,14 +460,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
   //      WGM*32 x (BN+4) floats: the LDS footprint, hence the blocks per CU, is set by the pipeline buffers alone.
   float* lds = reinterpret_cast<float*>(smem);
   constexpr int TPR = BN / EPP;              // threads per row
-  constexpr int RPI = 256 / TPR;             // rows per iteration
+  constexpr int RPI = NT / TPR;              // rows per iteration
   const int cc = tid % TPR, rr = tid / TPR;
   const int col = n0 + cc * EPP;
+  const bool cvalid = col < p.Cout;  // false only in a ragged last N tile (Cout % EPP == 0: a piece never straddles)
   float sc[EPP], sh[EPP];
 #pragma unroll
   for (int e = 0; e < EPP; ++e) {
-    sc[e] = p.scale ? p.scale[col + e] : 1.f;
-    sh[e] = p.shift ? p.shift[col + e] : 0.f;
+    sc[e] = (p.scale && cvalid) ? p.scale[col + e] : 1.f;
+    sh[e] = (p.shift && cvalid) ? p.shift[col + e] : 0.f;
   }
   T* outp = p.out;  // destination of this block's couts (block-uniform: a tile never straddles csplit)
   const T* maskp = p.mask;
@@ -415,8 +488,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
 #pragma unroll
   for (int e = 0; e < EPP; ++e) {
     st0[e] = st1[e] = 0.f;
-    bmu[e] = p.bn_y ? p.bn_mean[col + e] : 0.f;
-    bis[e] = p.bn_y ? p.bn_invstd[col + e] : 0.f;
+    bmu[e] = (p.bn_y && cvalid) ? p.bn_mean[col + e] : 0.f;
+    bis[e] = (p.bn_y && cvalid) ? p.bn_invstd[col + e] : 0.f;
   }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -441,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
     for (int lrow = rr; lrow < WGM * 32; lrow += RPI) {
       const int row = (lrow >> 5) * WM + 32 * tm + (lrow & 31);  // tile row of pass-local row lrow
       const int opix = orow[row];
-      if (opix >= 0) {
+      if (opix >= 0 && cvalid) {
         const long o = (long)opix * ostride + ocol;
         float v[EPP];
 #pragma unroll
@@ -505,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma(const ConvArgsT<T> p) {
       float a = 0.f;
 #pragma unroll 4
       for (int l = 0; l < RPI; ++l) a += r[l * BN + c];
-      p.stats[((long)mt * 2 + (tid < BN ? 0 : 1)) * p.Cout + n0 + c] = a;
+      if (n0 + c < p.Cout) p.stats[((long)mt * 2 + (tid < BN ? 0 : 1)) * p.Cout + n0 + c] = a;
     }
   }
 }
@@ -529,11 +602,14 @@ __global__ void pack_dgrad_weight_bf16_kernel(const float* __restrict__ w, bf16_
   }
 }
 
-enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, NTILES };
+// (index 4 is the fp32 stem kernel of conv_igemm.hip: the two files share the index space of rs_conv2d_tile_name)
+// T256x256 / T512x128: 8-wave blocks, one per CU, bf16 only (see pick_tile)
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, T512x128, NTILES };
 const char* const kTileNamesBf16[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
-                                            "conv_igemm_bf16<64x64>"};
-const int kTileBM[NTILES] = {128, 128, 128, 64};
-const int kTileBN[NTILES] = {128, 64, 32, 64};
+                                            "conv_igemm_bf16<64x64>", "", "conv_igemm_bf16<256x128>",
+                                            "conv_igemm_bf16<256x256>", "conv_igemm_bf16<512x128>"};
+const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 512};
+const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 128};
 
 bool valid(const rs_conv_desc* d) {
   if (!d) return false;
@@ -549,10 +625,43 @@ bool phase_ok(const rs_conv_desc* d) {
   return d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
 }
 
-int pick_tile(const rs_conv_desc* d, bool phase4 = false) {
+int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats = false) {
   const long M = phase4 ? (long)d->N * d->Hs * d->Ws * 4 : (long)d->N * d->Ho * d->Wo;  // (x4: the phases share the grid)
   const long want = 512;  // >= 2 blocks per CU
+  static const int forced_tile = [] {  // RS_CONV_TILE=0..3 (128x128, 128x64, 128x32, 64x64): measurement knob
+    const char* e = getenv("RS_CONV_TILE");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced_tile >= 0 && forced_tile < NTILES && forced_tile != TSTEM_RESERVED && d->Cout % kTileBN[forced_tile] == 0 &&
+      (forced_tile < T256x256 || (es == 2 && !stats)))
+    return forced_tile;
+  // 8-wave tiles (bf16, no fused statistics; one block per CU): half the LDS-DMA bytes per MFMA of the 128x128 tile,
+  // which is what bounds that tile (~23 B/clk/CU of DMA = ~900 TFLOP/s at 64 flop/B).  Measured per layer (bs 32):
+  // 256x256 +21 % on 256->256 3x3 at 64^2 (512 blocks, 1071 vs 882 TFLOP/s) but -30 % with 128 blocks; 512x128 +3..6 % on
+  // the N = 128 layers (within run-to-run noise: off by default).  On the whole bf16 train step either is a wash
+  // (29.3 ms with and without): few launches qualify.  RS_CONV_BIG = bit 0: 256x256, bit 1: 512x128 (A/B knob).
+  static const int big = [] {  // bit 0: 256x256, bit 1: 512x128
+    const char* e = getenv("RS_CONV_BIG");
+    return e ? atoi(e) : 1;
+  }();
+  if (big && es == 2 && !stats) {
+    const long mrows = phase4 ? (long)d->N * d->Hs * d->Ws : M;  // rows per launch grid slice (each phase tiles its own)
+    const long nph = phase4 ? 4 : 1;
+    if ((big & 1) && d->Cout % 256 == 0 && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= 384) return T256x256;
+    const bool n128 = d->Cout % 128 == 0 || (d->Cout > 128 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5);
+    if ((big & 2) && n128 && rs_cdiv(mrows, 512) * rs_cdiv(d->Cout, 128) * nph >= 512) return T512x128;
+  }
   if (d->Cout % 128 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 128) >= want) return T128x128;
+  // ragged last N tile (weight rows past Cout read as zeros through the buffer bound, the epilogue skips their columns):
+  // worth it when <= 1/5 of the MFMAs are padding -- Cout = 320, the data gradient of the 256 + 64 concat, runs the
+  // 128x128 tile's 2x higher MFMA : LDS-read ratio instead of five 128x64 tiles.  RS_CONV_RAGGED=0 disables (A/B knob).
+  static const bool ragged = [] {
+    const char* e = getenv("RS_CONV_RAGGED");
+    return !e || atoi(e) != 0;
+  }();
+  if (ragged && d->Cout > 128 && d->Cout % 128 != 0 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5 &&
+      (long)rs_cdiv(M, 128) * rs_cdiv(d->Cout, 128) >= want)
+    return T128x128;
   if (d->Cout % 64 == 0) {
     if ((long)rs_cdiv(M, 128) * (d->Cout / 64) >= want) return T128x64;
     return T64x64;
@@ -562,18 +671,19 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false) {
 
 // 128-byte rows (4 k-steps per barrier, 2 blocks per CU) or 64-byte rows (2 k-steps per barrier, 4 blocks per CU)?
 // RS_CONV_ROWB=64|128 overrides (measurement knob).
-int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false) {
+int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false, bool stats = false) {
   static const int forced = [] {
     const char* e = getenv("RS_CONV_ROWB");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 64 || forced == 128) return forced;
   // Measured on both paths (bs-32 bf16 train, bs-16 fp32 predict, per-layer A/B): 64-byte rows win when the grid can use the
   // doubled occupancy (>= 2048 blocks) and the K loop is short (<= 16 chunks of 128 bytes) -- the 1x1 convolutions at
   // 64^2..128^2 gain 25-35 % -- or, for fp32, at any K (the 64-cycle fp32 MFMAs hide the extra barriers); long-K layers
   // with few blocks (layer3/4, dec0/dec1) keep 128-byte rows (+8..20 % there).
-  const int tile = pick_tile(d, phase4);
-  const long blocks = (long)rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[tile]) * (d->Cout / kTileBN[tile]);
+  const int tile = pick_tile(d, phase4, es, stats);
+  if (tile == T512x128) return 64;  // (512 + 128) rows x 128 bytes x 2 buffers would not fit the LDS
+  if (forced == 64 || forced == 128) return forced;
+  const long blocks = (long)rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[tile]) * rs_cdiv(d->Cout, kTileBN[tile]);
   const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
   if (blocks >= 2048 && (nk128 <= 16 || es == 4)) return 64;
   return 128;
@@ -581,6 +691,29 @@ int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false) {
 
 template <typename T, int ROWB, bool PHASE>
 void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
+  if constexpr (sizeof(T) == 2) {
+    if (tile == T256x256 || tile == T512x128) {  // 8 waves, 1 block per CU; RS_CONV_NBUF overrides the pipeline depth
+      static const int nb = [] {
+        const char* e = getenv("RS_CONV_NBUF");
+        return e ? atoi(e) : 0;
+      }();
+      if (tile == T256x256) {
+        if constexpr (ROWB == 128) {
+          conv_igemm_dma<T, 256, 256, 2, 4, 128, PHASE, 2><<<grid, 512, 0, s>>>(a);
+        } else {
+          if (nb == 2) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 2><<<grid, 512, 0, s>>>(a);
+          else if (nb == 3) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 3><<<grid, 512, 0, s>>>(a);
+          else conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 4><<<grid, 512, 0, s>>>(a);
+        }
+      } else {
+        if constexpr (ROWB == 64) {
+          if (nb == 2) conv_igemm_dma<T, 512, 128, 4, 2, 64, PHASE, 2><<<grid, 512, 0, s>>>(a);
+          else conv_igemm_dma<T, 512, 128, 4, 2, 64, PHASE, 3><<<grid, 512, 0, s>>>(a);
+        }
+      }
+      return;
+    }
+  }
   // RS_CONV_NBUF=3 (measurement knob): three pipeline buffers with counted vmcnt waits for the 64-byte-row kernels (two
   // chunks in flight per block, but 3 instead of 4 blocks per CU).  Measured per layer on both paths: a wash to slightly
   // slower (fp32 predict 14.48 -> 14.79 ms of convolutions, bf16 train 17.5 -> 18.0) -- occupancy hides the DMA round trip
@@ -597,10 +730,26 @@ void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
     }
     return;
   }
+  if constexpr (sizeof(T) == 2 && !PHASE) {
+    static const int dbg = [] {
+      const char* e = getenv("RS_CONV_DBG");
+      return e ? atoi(e) : 0;
+    }();
+    if (dbg && tile == T128x128) {
+      switch (dbg) {
+        case 1: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 1><<<grid, 256, 0, s>>>(a); return;
+        case 2: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 2><<<grid, 256, 0, s>>>(a); return;
+        case 4: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 4><<<grid, 256, 0, s>>>(a); return;
+        case 5: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 5><<<grid, 256, 0, s>>>(a); return;
+        default: break;
+      }
+    }
+  }
   switch (tile) {
     case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
     case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
     case T128x32: conv_igemm_dma<T, 128, 32, 4, 1, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
+    case T256x128: conv_igemm_dma<T, 256, 128, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
     default: conv_igemm_dma<T, 64, 64, 2, 2, ROWB, PHASE><<<grid, 256, 0, s>>>(a); break;
   }
 }
@@ -659,11 +808,11 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   const long M = phase4 ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo;  // rows per phase
   a.M = (int)M;
   {
-    // 32-bit byte offsets relative to the first image of a tile (<= 128 rows: 128/(rows per image) + 2 images)
+    // 32-bit byte offsets relative to the first image of a tile (<= 512 rows: 512/(rows per image) + 2 images)
     const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
     const long img_bytes = (long)d->Hs * d->Ws * cmax * ES;
     const long rows_per_image = phase4 ? (long)d->Hs * d->Ws : (long)d->Ho * d->Wo;
-    const long span = (128 / rows_per_image + 2) * img_bytes;
+    const long span = (512 / rows_per_image + 2) * img_bytes;
     if (span >= (1L << 31)) return RS_EINVAL;
     if ((long)d->Cout * d->kh * d->kw * (d->C1 + d->C2) * ES >= (1L << 31)) return RS_EINVAL;
   }
@@ -671,17 +820,17 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   // instead of 2, which is what the short-K layers want -- see pick_rowb)
   const int kc128 = 128 / (int)ES;
   const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
-  const int kc = (can128 && pick_rowb(d, (int)ES, phase4) == 128) ? kc128 : kc128 / 2;
+  const int kc = (can128 && pick_rowb(d, (int)ES, phase4, stats != nullptr) == 128) ? kc128 : kc128 / 2;
   a.cpt = (d->C1 + d->C2) / kc;
   a.ntaps = a.kh * a.kw;
   a.nk = a.ntaps * a.cpt;
   a.Kw = a.nk * kc;
   a.relu = d->relu;
 
-  const int tile = pick_tile(d, phase4);
+  const int tile = pick_tile(d, phase4, (int)ES, stats != nullptr);
   if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
   a.direct = a.direct && !out2;
-  a.ntiles = d->Cout / kTileBN[tile];
+  a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
   hipStream_t s = (hipStream_t)stream;
   if (phase4) {
@@ -710,7 +859,7 @@ extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* 
   if (!valid(d) || (es != 2 && es != 4) || (phase4 && !phase_ok(d))) return RS_EINVAL;
   const int kc128 = 128 / es;
   const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
-  if (tile) *tile = pick_tile(d, phase4 != 0);
+  if (tile) *tile = pick_tile(d, phase4 != 0, es);
   if (rowb) *rowb = (can128 && pick_rowb(d, es, phase4 != 0) == 128) ? 128 : 64;
   return 0;
 }
@@ -741,38 +890,61 @@ __global__ void pack_phase_weight_kernel(const float* __restrict__ w, T* __restr
 //   d_src[u][v][ci] = sum_{ty,tx,co} dz[2u - 1 + ty][2v - 1 + tx][co] * Wd[ci][ty][tx][co],
 // Wd[ty] = sum of the taps ky with ((2u - 1 + ty) + ky - 1) >> 1 == u:  ty 0 -> {2}, 1 -> {1,2}, 2 -> {0,1}, 3 -> {0}.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_dgrad_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout,
-                                                                      int Cin) {
-  // block = 32 cins x 32 couts, all taps: reads coalesced along ci (the KRSC inner dimension), LDS transpose, writes
-  // coalesced along co (the inner dimension of [Cin][4][4][Cout])
-  __shared__ float tile[9][32][33];  // [tap][co][ci]
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int e = ty; e < 9 * 32; e += 8) {
-    const int k = e / 32, co = e - k * 32;
-    tile[k][co][tx] = (co0 + co < Cout && ci0 + tx < Cin) ? w[((long)(co0 + co) * 9 + k) * Cin + ci0 + tx] : 0.f;
-  }
-  __syncthreads();
-  for (int e = ty; e < 16 * 32; e += 8) {
-    const int t = e / 32, ci = e - t * 32;  // thread writes out[ci0+ci][t][co0+tx]
-    const int ty4 = t >> 2, tx4 = t & 3;
-    const int ky0 = ty4 == 0 ? 2 : (ty4 == 1 ? 1 : 0), ky1 = ty4 == 0 ? 2 : (ty4 == 1 ? 2 : (ty4 == 2 ? 1 : 0));
-    const int kx0 = tx4 == 0 ? 2 : (tx4 == 1 ? 1 : 0), kx1 = tx4 == 0 ? 2 : (tx4 == 1 ? 2 : (tx4 == 2 ? 1 : 0));
-    float acc = 0.f;
-    for (int ky = ky0; ky <= ky1; ++ky)
-      for (int kx = kx0; kx <= kx1; ++kx) acc += tile[ky * 3 + kx][tx][ci];
-    if (ci0 + ci < Cin && co0 + tx < Cout) out[((long)(ci0 + ci) * 16 + t) * Cout + co0 + tx] = (T)acc;
-  }
+__global__ void pack_dgrad_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  long t = i / Cout;
+  const int tx = (int)(t & 3), ty = (int)((t >> 2) & 3);
+  const int ci = (int)(t >> 4);
+  const int ky0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), ky1 = ty == 0 ? 2 : (ty == 1 ? 2 : (ty == 2 ? 1 : 0));
+  const int kx0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), kx1 = tx == 0 ? 2 : (tx == 1 ? 2 : (tx == 2 ? 1 : 0));
+  float acc = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+  out[i] = (T)acc;
+}
+
+// Same result from the ALREADY TRANSPOSED weights wt [Cin][3][3][Cout] with flipped taps (rs_pack_dgrad_weight): reads and
+// writes are both contiguous along Cout, which the one-step kernel above cannot offer (its reads stride by 9*Cin).
+template <typename T>
+__global__ void combine_dgrad_phase_weight_kernel(const float* __restrict__ wt, T* __restrict__ out, int Cout, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  long t = i / Cout;
+  const int tx = (int)(t & 3), ty = (int)((t >> 2) & 3);
+  const long ci = t >> 4;
+  const int ky0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), ky1 = ty == 0 ? 2 : (ty == 1 ? 2 : (ty == 2 ? 1 : 0));
+  const int kx0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), kx1 = tx == 0 ? 2 : (tx == 1 ? 2 : (tx == 2 ? 1 : 0));
+  float acc = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) acc += wt[(ci * 9 + (8 - (ky * 3 + kx))) * Cout + co];  // tap-flipped layout
+  out[i] = (T)acc;
+}
+
+extern "C" int rs_combine_dgrad_phase_weight_dt(const float* w_dgrad, void* out, int dtype, int Cout, int Cin,
+                                                rs_stream_t stream) {
+  if (!w_dgrad || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
+  const long total = 16L * Cout * Cin;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32)
+    combine_dgrad_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_dgrad, reinterpret_cast<float*>(out), Cout, total);
+  else if (dtype == RS_BF16)
+    combine_dgrad_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_dgrad, reinterpret_cast<bf16_t*>(out), Cout, total);
+  else
+    return RS_EINVAL;
+  return RS_LAUNCH_RESULT();
 }
 
 extern "C" int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream) {
   if (!w_krsc || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
+  const long total = 16L * Cout * Cin;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(rs_cdiv(Cin, 32), rs_cdiv(Cout, 32));
   if (dtype == RS_F32)
-    pack_dgrad_phase_weight_kernel<float><<<grid, 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin);
+    pack_dgrad_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin, total);
   else if (dtype == RS_BF16)
-    pack_dgrad_phase_weight_kernel<bf16_t><<<grid, 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin);
+    pack_dgrad_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin, total);
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();
@@ -844,7 +1016,7 @@ extern "C" int rs_conv2d_fwd_bnstats_dt(const rs_conv_desc* d, int dtype, const 
   return RS_EINVAL;
 }
 
-extern "C" int rs_conv2d_tile_bf16(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+extern "C" int rs_conv2d_tile_bf16(const rs_conv_desc* d) { return valid(d) ? pick_tile(d, false, 2) : RS_EINVAL; }
 
 extern "C" const char* rs_conv2d_tile_name_bf16(int tile) {
   return (tile >= 0 && tile < NTILES) ? kTileNamesBf16[tile] : "";

@@ -232,9 +232,11 @@ def pack_dgrad_phase_weight(w_krsc, dtype=torch.float32):
     cout, kh, kw, cin = w_krsc.shape
     assert kh == 3 and kw == 3
     out = torch.empty((cin, 4, 4, cout), device=w_krsc.device, dtype=dtype)
-    check(_lib.lib().rs_pack_dgrad_phase_weight_dt(_dev(w_krsc, "w"), _dev(out, "out", dtype),
-                                                   RS_BF16 if dtype == BF16 else RS_F32, cout, cin, _stream()),
-          "rs_pack_dgrad_phase_weight_dt")
+    # two coalesced steps: LDS-tiled transpose to [Cin,3,3,Cout] (rs_pack_dgrad_weight), then the tap sums along Cout
+    wt = pack_dgrad_weight(w_krsc, torch.float32)
+    check(_lib.lib().rs_combine_dgrad_phase_weight_dt(_dev(wt, "wt"), _dev(out, "out", dtype),
+                                                      RS_BF16 if dtype == BF16 else RS_F32, cout, cin, _stream()),
+          "rs_combine_dgrad_phase_weight_dt")
     return out
 
 

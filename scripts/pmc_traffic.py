@@ -20,7 +20,7 @@ out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
 
 def bench_name(k):
     k = k.replace("(anonymous namespace)::", "")
-    m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, \d+)?>", k)
+    m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, \d+)*>", k)
     if m:
         return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "float" else "bf16",
                                                   "phase," if m.group(5) == "true" else "", m.group(2), m.group(3), m.group(4))

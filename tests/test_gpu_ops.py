@@ -47,6 +47,7 @@ CASES = [
     ("1x1_c256", 2, 64, 20, 12, 256, 1, 1, 0),
     ("1x1_s2", 2, 128, 20, 12, 256, 1, 2, 0),
     ("3x3_c96in", 1, 96, 9, 33, 160, 3, 1, 1),  # Cout 160 -> 128x32 tiles
+    ("3x3_c320_ragged", 1, 32, 256, 256, 320, 3, 1, 1),  # 128x128 with a ragged third N tile
 ]
 
 

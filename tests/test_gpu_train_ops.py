@@ -247,7 +247,8 @@ def test_metrics_match_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("c1,c2,cout,h,w", [(64, 32, 64, 10, 14), (128, 0, 32, 16, 8), (256, 64, 128, 8, 8), (64, 64, 128, 5, 3)])
+@pytest.mark.parametrize("c1,c2,cout,h,w", [(64, 32, 64, 10, 14), (128, 0, 32, 16, 8), (256, 64, 128, 8, 8), (64, 64, 128, 5, 3),
+                                            (256, 64, 32, 128, 128)])  # last: 320 couts -> ragged third 128-wide N tile
 def test_decoder_dgrad_phase_form(c1, c2, cout, h, w, dtype):
     """d loss / d (skip, prev) of relu-less DecoderBlock conv3x3(interpolate(cat[skip, prev], x2)) == one 4x4 / stride-2
     convolution over dz with rs_pack_dgrad_phase_weight_dt weights, then the cat split (vs autograd)."""

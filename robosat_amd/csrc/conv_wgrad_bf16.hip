@@ -27,6 +27,8 @@
 //   split-P: partial tiles -> workspace [split][Cout][K], summed by reduce.hip: deterministic, no atomics.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -55,17 +57,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wb_make_rsrc(const void* base,
 // (the OTHER pipeline buffer) is disjoint from the operand reads that follow and drains the queue (s_waitcnt vmcnt(0))
 // before the first ds_read of every chunk, serialising copy and MFMA.  As asm the copy is invisible to its counters, so
 // the kernel waits itself: wb_dma_wait() ahead of the barrier that publishes the buffer.
+// m0 is named as a clobber rather than saved/restored around every piece (see the note at rb_dma16s in
+// conv_igemm_dma.hip: nothing else in this file makes the compiler use m0).
 __device__ __forceinline__ void wb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int lds_dst, int voff) {
-  unsigned int keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+      "s_mov_b32 m0, %1\n\t"
       "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "buffer_load_dwordx4 %0, %2, 0 offen lds"
+      :
       : "v"(voff), "s"(lds_dst), "s"(r)
-      : "memory");
+      : "memory", "m0");
 }
 
 __device__ __forceinline__ void wb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -201,11 +202,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   const int cout2 = p.Cout * 2, cs2 = Cs * 2;
 
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane(wb_lds_addr(smem));
-  auto issue_dma = [&](int chunk, int buf, int which) __attribute__((always_inline)) {
-    const unsigned int L = lds0 + buf * BUF;
+  // Per chunk: first the byte offsets of all of this wave's pieces (one LDS round trip for the gather tables), then the
+  // pieces themselves -- in the steady state BETWEEN the MFMAs of the previous chunk (an LDS-DMA instruction costs its
+  // wave 60-180 cycles of issue; a burst at the top of the chunk puts that on every wave's critical path at once).
+  int voff[NI];
+  unsigned int fL = lds0;
+  auto prepare_dma = [&](int chunk, int buf, int which) __attribute__((always_inline)) {
+    fL = lds0 + buf * BUF;
     int pix[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j)  // table lookups of all of this wave's gathered-row instructions first (one LDS round trip)
+    for (int j = 0; j < NI; ++j)
       pix[j] = (NW * j >= IA) ? tabs[which * PK + RIB * (wave + NW * j - IA) + ra_b]
                               : (PHASE ? taba[which * PK + RIA * (wave + NW * j) + ra_a] : 0);
 #pragma unroll
@@ -213,16 +219,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
       const int ii = wave + NW * j;  // wave-uniform; IA is a multiple of NW, so the role depends on j alone
       if (NW * j < IA) {
         if (PHASE) {
-          wb_dma16(rsrc_dy, L + ii * 1024, pix[j] >= 0 ? pix[j] * cout2 + cola : -1);
+          voff[j] = pix[j] >= 0 ? pix[j] * cout2 + cola : -1;
         } else {
-          const int R = RIA * ii + ra_a;
-          const int m = chunk * PK + R;
-          wb_dma16(rsrc_dy, L + ii * 1024, (m - m_first) * cout2 + cola);  // rows >= M lie past the descriptor: zeros
+          const int m = chunk * PK + RIA * ii + ra_a;
+          voff[j] = (m - m_first) * cout2 + cola;  // rows >= M lie past the descriptor: zeros
         }
       } else {
-        wb_dma16(rsrc_x, L + ABYTES + (ii - IA) * 1024, pix[j] >= 0 ? pix[j] * cs2 + colb : -1);
+        voff[j] = pix[j] >= 0 ? pix[j] * cs2 + colb : -1;
       }
     }
+  };
+  auto issue_piece = [&](int j) __attribute__((always_inline)) {
+    const int ii = wave + NW * j;
+    if (NW * j < IA) wb_dma16(rsrc_dy, fL + ii * 1024, voff[j]);
+    else wb_dma16(rsrc_x, fL + ABYTES + (ii - IA) * 1024, voff[j]);
   };
 
   f32x16 acc[TM][TN];
@@ -245,37 +255,54 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) boff[tn] = ABYTES + (8 * (g >> 1) + jr) * ROWB_ + (((wn * TN + tn) ^ rsw_b) * 64) + chb;
 
+  constexpr int NMMA = NS * TM * TN;
+  constexpr int PSTEP = NMMA / (2 * NI) >= 1 ? NMMA / (2 * NI) : 1;  // front-loaded: the chunk's tail covers the latency
+  constexpr int PIN = (NMMA + PSTEP - 1) / PSTEP < NI ? (NMMA + PSTEP - 1) / PSTEP : NI;
+  auto chunk_mma = [&](const unsigned char* L, auto fetch_tag) __attribute__((always_inline)) {
+    constexpr bool FETCH = decltype(fetch_tag)::value;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        fa[tm] = wb_tr_read8(L + aoff[tm] + (16 * s) * ROWA, L + aoff[tm] + (16 * s + 4) * ROWA);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        fb[tn] = wb_tr_read8(L + boff[tn] + (16 * s) * ROWB_, L + boff[tn] + (16 * s + 4) * ROWB_);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int q = (s * TM + tm) * TN + tn;  // MFMA index within the chunk (compile-time after unrolling)
+          if (FETCH && q % PSTEP == 0 && q / PSTEP < PIN) issue_piece(q / PSTEP);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (FETCH) {
+#pragma unroll
+      for (int q = PIN; q < NI; ++q) issue_piece(q);
+    }
+  };
   if (chunk0 < chunk1) {
     fill_table(chunk0, 0);
     fill_table(chunk0 + 1, 1);
     __syncthreads();
-    issue_dma(chunk0, 0, 0);
+    prepare_dma(chunk0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) issue_piece(q);
     wb_dma_wait();
     __syncthreads();
-    for (int c = chunk0; c < chunk1; ++c) {
+    int c = chunk0;
+    for (; c + 1 < chunk1; ++c) {  // steady state: chunk c+1 streams into the other buffer between chunk c's MFMAs
       const int it = c - chunk0;
-      const unsigned char* L = smem + (it & 1) * BUF;
-      // chunk c+1 -> the other buffer (its last readers passed the barrier that ended iteration it-1)
-      if (c + 1 < chunk1) issue_dma(c + 1, (it + 1) & 1, (it + 1) & 1);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        bf16x8 fa[TM], fb[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          fa[tm] = wb_tr_read8(L + aoff[tm] + (16 * s) * ROWA, L + aoff[tm] + (16 * s + 4) * ROWA);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          fb[tn] = wb_tr_read8(L + boff[tn] + (16 * s) * ROWB_, L + boff[tn] + (16 * s + 4) * ROWB_);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
-      }
+      // (the other buffer's last readers passed the barrier that ended iteration it-1)
+      prepare_dma(c + 1, (it + 1) & 1, (it + 1) & 1);
+      chunk_mma(smem + (it & 1) * BUF, std::true_type());
       fill_table(c + 2, it & 1);
       wb_dma_wait();  // this wave's share of chunk c+1 has landed; the barrier publishes everybody's
       __syncthreads();
     }
+    chunk_mma(smem + ((c - chunk0) & 1) * BUF, std::false_type());
   }
 
   // D[i][j]: i = cout (tile-local) = (r&3) + 8*(r>>2) + 4*(lane>>5), j = cin (tile-local) = lane&31

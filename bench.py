@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: dense bf16 (v_mfma_f32_32x32x16_bf16); never the 2:1-sparsity figure
+HBM_PEAK_GBS = 8000.0  # same guide: HBM3E ~8 TB/s
 
 
 def kernel_peak(name):
@@ -77,12 +78,22 @@ def roofline(step):
 
     from robosat_amd import ops
 
-    step()
-    torch.cuda.synchronize()
-    ops.PROFILE = []
-    step()
-    torch.cuda.synchronize()
-    recs, ops.PROFILE = ops.PROFILE, None
+    # per-launch timings must not overlap each other: the train step's weight-gradient side stream is switched off for the
+    # profiled pass (the TIMED steps of run_phase keep it)
+    keep = os.environ.get("ROBOSAT_WGRAD_STREAM")
+    os.environ["ROBOSAT_WGRAD_STREAM"] = "0"
+    try:
+        step()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+    finally:
+        if keep is None:
+            del os.environ["ROBOSAT_WGRAD_STREAM"]
+        else:
+            os.environ["ROBOSAT_WGRAD_STREAM"] = keep
     per_kernel, layers = {}, []
     for name, flops, shape, e0, e1, nbytes, executed in recs:
         ms = e0.elapsed_time(e1)
@@ -101,23 +112,36 @@ def roofline(step):
     # time-weighted peak of the launches (fp32 and bf16 kernels coexist in the bf16 path: the stem stays fp32)
     ideal_ms = sum(v[4] / kernel_peak(n) / 1e9 for n, v in per_kernel.items())  # on EXECUTED flops
     total_exe = sum(v[4] for v in per_kernel.values())
-    achieved = flops / ms / 1e9
     peak = kernel_peak(dom)
-    out = {
-        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom), "launches": launches,
-        # `achieved` counts ALGORITHMIC flops (2*N*Cout*Cin*k*k*Ho*Wo on the reference's shapes).  The phase-form decoder
-        # kernels execute 4/9 of them (conv3x3 over a nearest-x2 upsample = four 2x2 convolutions with pre-summed taps), so
-        # their algorithmic rate can exceed the MFMA peak; `executed` is what the matrix cores actually do.
+    # which roof binds the dominant kernel: its EXECUTED flops at the dense MFMA peak of its dtype, or its algorithmic bytes
+    # (every tensor once) at HBM_PEAK -- whichever takes longer
+    t_mfma, t_hbm = exe_flops / peak / 1e9, alg_bytes / HBM_PEAK_GBS / 1e6
+    out = {"bound": "mfma" if t_mfma >= t_hbm else "hbm", "kernel": dom}
+    if t_mfma >= t_hbm:
+        achieved = flops / ms / 1e9
+        out.update({"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4)})
+    else:
+        achieved = alg_bytes / ms / 1e6
+        out.update({"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)})
+    out.update({
+        "traffic": pmc_traffic(dom), "launches": launches,
+        # `achieved` (mfma) counts ALGORITHMIC flops (2*N*Cout*Cin*k*k*Ho*Wo on the reference's shapes).  The phase-form
+        # decoder kernels execute 4/9 of them (conv3x3 over a nearest-x2 upsample = four 2x2 convolutions with pre-summed
+        # taps), so their algorithmic rate can exceed the MFMA peak; `executed` is what the matrix cores actually do.
         "executed": {"tflops": round(exe_flops / ms / 1e9, 2), "frac": round(exe_flops / ms / 1e9 / peak, 4)},
+        "hbm": {"algorithmic_gbs": round(alg_bytes / ms / 1e6, 1), "frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)},
         "avg_launch_ms": round(ms / launches, 4), "gflop_per_launch": round(flops / launches / 1e9, 3),
         "algorithmic_bytes_per_launch": round(alg_bytes / launches),
         "all_convs": {"tflops": round(total_fl / total_ms / 1e9, 2), "executed_tflops": round(total_exe / total_ms / 1e9, 2),
                       "executed_frac": round(ideal_ms / total_ms, 4), "ms": round(total_ms, 3), "gflop": round(total_fl / 1e9, 2),
-                      "executed_gflop": round(total_exe / 1e9, 2)},
+                      "executed_gflop": round(total_exe / 1e9, 2),
+                      # the launches' roofline times (max of the MFMA and the HBM time of each) over their measured times
+                      "roofline_frac": round(sum(max(v[4] / kernel_peak(n) / 1e9, v[3] / HBM_PEAK_GBS / 1e6)
+                                                 for n, v in per_kernel.items()) / total_ms, 4)},
         "per_kernel": {n: {"tflops": round(v[0] / v[1] / 1e9, 2), "executed_tflops": round(v[4] / v[1] / 1e9, 2),
-                           "ms": round(v[1], 3), "launches": v[2]} for n, v in per_kernel.items()},
-    }
+                           "gbs": round(v[3] / v[1] / 1e6, 1), "ms": round(v[1], 3), "launches": v[2]}
+                       for n, v in per_kernel.items()},
+    })
     return out, layers
 
 
@@ -294,7 +318,7 @@ def main():
     # The metric is "train+predict": the headline `value` above is the predict leg (BASELINE configs[1]); the train leg
     # (configs[2]: bf16, bs 32 per GPU, fwd + Lovasz + bwd + RCCL gradient all-reduce + Adam) rides in the same line.
     if args.phase == "predict" and not args.no_train_leg:
-        tb, ts, tw = args.train_batch, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+        tb, ts, tw = args.train_batch, max(1, min(args.steps, 10)), max(3, min(args.warmup, 5))
         tel, tstep = run_phase(args, "train", "bf16", tb, ts, tw, device, dist, rank)
         troof, _ = roofline(tstep)
         if rank == 0:

@@ -647,7 +647,9 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats
   if (big && es == 2 && !stats) {
     const long mrows = phase4 ? (long)d->N * d->Hs * d->Ws : M;  // rows per launch grid slice (each phase tiles its own)
     const long nph = phase4 ? 4 : 1;
-    if ((big & 1) && d->Cout % 256 == 0 && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= 384) return T256x256;
+    const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
+    // (short-K launches are DMA-latency / HBM bound: there the 256-row tile ties the 128x128 one at best)
+    if ((big & 1) && d->Cout % 256 == 0 && nk128 >= 32 && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= 384) return T256x256;
     const bool n128 = d->Cout % 128 == 0 || (d->Cout > 128 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5);
     if ((big & 2) && n128 && rs_cdiv(mrows, 512) * rs_cdiv(d->Cout, 128) * nph >= 512) return T512x128;
   }
@@ -676,16 +678,22 @@ int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false, bool stats = f
     const char* e = getenv("RS_CONV_ROWB");
     return e ? atoi(e) : 0;
   }();
-  // Measured on both paths (bs-32 bf16 train, bs-16 fp32 predict, per-layer A/B): 64-byte rows win when the grid can use the
-  // doubled occupancy (>= 2048 blocks) and the K loop is short (<= 16 chunks of 128 bytes) -- the 1x1 convolutions at
-  // 64^2..128^2 gain 25-35 % -- or, for fp32, at any K (the 64-cycle fp32 MFMAs hide the extra barriers); long-K layers
-  // with few blocks (layer3/4, dec0/dec1) keep 128-byte rows (+8..20 % there).
+  // Measured per layer with both row sizes forced, on both paths (bs-32 bf16 train, bs-16 fp32 predict; after the DMA
+  // pieces moved between the MFMAs).  64-byte rows = half the LDS per block, twice the blocks per CU, a barrier every 2
+  // k-steps: they win on short K loops (the 1x1 convolutions of the encoder: 25-37 % at nk128 <= 8, where a block is
+  // mostly DMA round trip + epilogue and co-resident blocks are what overlaps them) and on mid-K layers with a large grid;
+  // 128-byte rows win on long K (20-40 % on layer3/4's 3x3 and the decoder's phase / 4x4 forms in bf16).  fp32: the
+  // 64-cycle MFMAs hide the extra barriers, 64-byte rows tie or win up to nk128 = 16 and whenever the grid is large.
   const int tile = pick_tile(d, phase4, es, stats);
   if (tile == T512x128) return 64;  // (512 + 128) rows x 128 bytes x 2 buffers would not fit the LDS
   if (forced == 64 || forced == 128) return forced;
   const long blocks = (long)rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[tile]) * rs_cdiv(d->Cout, kTileBN[tile]);
   const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
-  if (blocks >= 2048 && (nk128 <= 16 || es == 4)) return 64;
+  if (es == 4) return (nk128 <= 16 || blocks >= 2048) ? 64 : 128;
+  if (tile == T256x256) return nk128 <= 8 ? 64 : 128;
+  if (kTileBN[tile] <= 64) return nk128 <= 4 ? 64 : 128;
+  if (phase4 || d->kh == 4) return 128;
+  if (nk128 <= 8 || (blocks >= 2048 && nk128 <= 24)) return 64;
   return 128;
 }
 

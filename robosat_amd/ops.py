@@ -60,12 +60,13 @@ def conv_flops(d):
     return 2.0 * d.N * d.Cout * cin * d.kh * d.kw * d.Ho * d.Wo
 
 
-def conv_bytes(d, esize):
+def conv_bytes(d, esize, epilogue_tensors=0):
     """Algorithmic HBM bytes of one launch: every tensor once -- the PRE-upsample sources, the
-    weights, the output."""
+    weights, the output, and the ``epilogue_tensors`` output-shaped operands the fused epilogue reads (residual, ReLU
+    mask, the BatchNorm input of the fused backward statistics)."""
 
     cin = 4 if d.stem else d.C1 + d.C2
-    return esize * (d.N * d.Hs * d.Ws * cin + d.Cout * d.kh * d.kw * cin + d.N * d.Ho * d.Wo * d.Cout)
+    return esize * (d.N * d.Hs * d.Ws * cin + d.Cout * d.kh * d.kw * cin + (1 + epilogue_tensors) * d.N * d.Ho * d.Wo * d.Cout)
 
 
 def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=0, out_hw=None):
@@ -117,7 +118,7 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
         if alg_scale != 1.0:  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                conv_bytes(d, 2 if bf else 4), conv_flops(d))
+                conv_bytes(d, 2 if bf else 4, (residual is not None) + (relu_mask is not None)), conv_flops(d))
     return out
 
 
@@ -175,7 +176,7 @@ def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0,
         ev1.record()
         bf = act == BF16
         _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                        conv_bytes(d, 2 if bf else 4))
+                        conv_bytes(d, 2 if bf else 4, 1 + (residual is not None) + (relu_mask is not None)))
     return out, partial
 
 
@@ -263,7 +264,8 @@ def conv2d_split(src, weight, c1, stride=1, pad=0, out_hw=None, mask1=None, mask
         if alg_scale != 1.0:
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                conv_bytes(d, 2 if bf else 4), conv_flops(d))
+                conv_bytes(d, 2 if bf else 4, ((mask1 is not None) * c1 + (mask2 is not None) * (d.Cout - c1)) / d.Cout),
+                conv_flops(d))
     return out1, out2
 
 
@@ -306,8 +308,8 @@ def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual
         ev1.record()
         bf = act == BF16
         _record(conv_tile_name(d, bf, phase=True), conv_flops(d),
-                (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 2 if bf else 4),
-                conv_flops(d) * 4.0 / 9.0)
+                (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                conv_bytes(d, 2 if bf else 4, (residual is not None) + (relu_mask is not None)), conv_flops(d) * 4.0 / 9.0)
     return out
 
 

@@ -17,6 +17,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/predict_pmc_$C -o p -- $B --steps 1 --warmup 1 > $OUT/predict_pmc_$C.log 2>&1; echo "exit $?"
   echo "== pmc $C: train fp32 bs8 (calibration)"
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/trainf32_pmc_$C -o p -- $B --phase train --batch 8 --steps 1 --warmup 1 > $OUT/trainf32_pmc_$C.log 2>&1; echo "exit $?"
+  echo "== pmc $C: train bf16 bs32"
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/trainbf16_pmc_$C -o p -- $B --phase train --dtype bf16 --batch 32 --steps 1 --warmup 1 > $OUT/trainbf16_pmc_$C.log 2>&1; echo "exit $?"
 done
 cd $REPO
 # keep the merge small: per-dispatch traces are large

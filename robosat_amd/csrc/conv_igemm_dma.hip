@@ -159,6 +159,10 @@ __device__ __forceinline__ void rb_dma16s(__amdgpu_buffer_rsrc_t r, unsigned int
       : "memory", "m0");
 }
 
+// A bare s_barrier that hipcc may not move LDS accesses across (the builtin is IntrNoMem) and that carries no fence: a
+// fence would drain the LDS-DMAs in flight (they count on vmcnt).
+__device__ __forceinline__ void rb_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void rb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void rb_dma_wait_n() {
@@ -173,8 +177,11 @@ constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 dat
 
 // DBG (measurement builds only, RS_CONV_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = MFMAs on
 // the first chunk's fragments only (no LDS reads in the loop): the three legs of the main loop, timed apart.
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int NBUF = 2, int DBG = 0>
+// STAG (8 waves, 64-byte rows, 4 buffers): the two wave groups {0-3} / {4-7} -- one wave of each per SIMD -- run half a chunk
+// apart, so one group's MFMAs cover the other's barrier, fragment reads and DMA issue (see the schedule at the loop).
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int NBUF = 2, int DBG = 0, bool STAG = false>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_igemm_dma(const ConvArgsT<T> p) {
+  static_assert(!STAG || (WGM * WGN == 8 && ROWB == 64 && NBUF == 4 && DBG == 0), "staggered schedule: 8 waves, 2 k-steps per chunk, 4 buffers");
   static_assert(NBUF >= 2 && NBUF <= 4, "2..4 pipeline buffers");
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
   static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_i
   //      order: allowing NI*(chunks still in flight) outstanding == chunk k has landed), the barrier publishes everybody's,
   //      and only then the buffer freed by chunk k-1 is refilled.  With three buffers a chunk has two iterations to land:
   //      the short-K encoder layers, whose iteration is one DMA round trip and 8 MFMAs long, run ~1.5x faster per block.
-  constexpr int AHEAD = NBUF - 1;
+  constexpr int AHEAD = STAG ? NBUF - 2 : NBUF - 1;
 #pragma unroll
   for (int j = 0; j < AHEAD; ++j)
     if (j < p.nk) {
@@ -407,16 +414,83 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_i
     }
   };
   const int nfetch = (DBG & 1) ? 0 : (p.nk - AHEAD > 0 ? p.nk - AHEAD : 0);
-  int kc = 0;
-  for (; kc < nfetch; ++kc) chunk(kc, std::true_type());
-  for (; kc < p.nk; ++kc) chunk(kc, std::false_type());
+  if constexpr (STAG) {
+    // Global barrier sequence: group A executes S_0 M_0 S_1 M_1 ... S_{n-1} M_{n-1} E, group B executes X S_0 M_0 ...
+    // M_{n-1}: B's S_c is A's M_c, B's M_c is A's S_{c+1} -- B runs one k-step (half a chunk) behind A.  Per chunk c each
+    // group: S_c, k-step 0, M_c, k-step 1.  Chunk c+2 is fetched (4 buffers) by A during its k-step 0 of c and by B during
+    // its k-step 1 of c: both after the last reader of that buffer's previous chunk c-2 (B's k-step 1, which ends at B's
+    // S_{c-1} = A's M_{c-1}).  A chunk is read only after a barrier that every wave reached AFTER waiting for its own
+    // pieces of it: A waits for chunk c ahead of S_c, B for chunk c+1 ahead of its M_c (= A's S_{c+1}).
+    auto kstep = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN], auto fetch_tag) __attribute__((always_inline)) {
+      constexpr bool FETCH = decltype(fetch_tag)::value;
+      constexpr int NM = TM * TN;
+      constexpr int PS = NM / NI >= 1 ? NM / NI : 1;
+      if (p.direct & 2) __builtin_amdgcn_s_setprio(1);  // (experiment: RS_CONV_STAG=2) favour the group that is in its MFMAs
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int q = tm * TN + tn;
+          if (FETCH && q % PS == 0 && q / PS < NI) issue_piece(q / PS);
+          mma16(acc[tn][tm], fb[tn], fa[tm], T());
+        }
+      if (FETCH) {
+#pragma unroll
+        for (int q = (NM + PS - 1) / PS; q < NI; ++q) issue_piece(q);
+      }
+      if (p.direct & 2) __builtin_amdgcn_s_setprio(0);
+    };
+    const int grp = wave >> 2;  // (wave-uniform)
+    if (grp == 0) {
+      auto chunk_a = [&](int kc, auto fetch_tag) __attribute__((always_inline)) {
+        if (kc + 1 < p.nk) rb_dma_wait_n<NI>();  // chunk kc landed (own pieces); kc+1's may still fly
+        else rb_dma_wait();
+        rb_barrier();  // S_kc
+        if (decltype(fetch_tag)::value) begin_chunk((kc + AHEAD) % NBUF);
+        const unsigned char* L = smem + (kc % NBUF) * BUF;
+        u32x4 fa[2][TM], fb[2][TN];
+        read_frag(L, 0, fa[0], fb[0]);
+        read_frag(L, 1, fa[1], fb[1]);
+        kstep(fa[0], fb[0], fetch_tag);
+        rb_barrier();  // M_kc
+        kstep(fa[1], fb[1], std::false_type());
+      };
+      int kc = 0;
+      for (; kc < nfetch; ++kc) chunk_a(kc, std::true_type());
+      for (; kc < p.nk; ++kc) chunk_a(kc, std::false_type());
+      rb_barrier();  // E (pairs with B's M_{n-1})
+    } else {
+      if (p.nk > 1) rb_dma_wait_n<NI>();  // chunk 0 landed before X = A's S_0
+      else rb_dma_wait();
+      rb_barrier();  // X
+      auto chunk_b = [&](int kc, auto fetch_tag) __attribute__((always_inline)) {
+        rb_barrier();  // S_kc
+        const unsigned char* L = smem + (kc % NBUF) * BUF;
+        u32x4 fa[2][TM], fb[2][TN];
+        read_frag(L, 0, fa[0], fb[0]);
+        read_frag(L, 1, fa[1], fb[1]);
+        kstep(fa[0], fb[0], std::false_type());
+        rb_dma_wait();  // own pieces of chunk kc+1 (everything this wave has issued so far) before A reads it
+        rb_barrier();  // M_kc
+        if (decltype(fetch_tag)::value) begin_chunk((kc + AHEAD) % NBUF);
+        kstep(fa[1], fb[1], fetch_tag);
+      };
+      int kc = 0;
+      for (; kc < nfetch; ++kc) chunk_b(kc, std::true_type());
+      for (; kc < p.nk; ++kc) chunk_b(kc, std::false_type());
+    }
+  } else {
+    int kc = 0;
+    for (; kc < nfetch; ++kc) chunk(kc, std::true_type());
+    for (; kc < p.nk; ++kc) chunk(kc, std::false_type());
+  }
   __syncthreads();  // every wave is done with the pipeline buffers: the epilogue stages through them
 
   // ---- direct epilogue (p.direct; no BatchNorm statistics): D[i = cout][j = pixel] puts 4 consecutive couts of one pixel
   //      in registers 4g..4g+3, so a lane can apply the epilogue and store them itself (16 bytes fp32 / 8 bytes bf16; the
   //      two half-waves fill 32 / 16 contiguous bytes per pixel row and L2 merges the rows across g, tn) -- no LDS round
   //      trip, no barrier.  Which of the two wins is shape dependent (measured; see pick_direct).
-  if (p.direct) {
+  if (p.direct & 1) {
     const int hh = lane >> 5;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -709,7 +783,16 @@ void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
         if constexpr (ROWB == 128) {
           conv_igemm_dma<T, 256, 256, 2, 4, 128, PHASE, 2><<<grid, 512, 0, s>>>(a);
         } else {
-          if (nb == 2) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 2><<<grid, 512, 0, s>>>(a);
+          static const int stag = [] {
+            const char* e = getenv("RS_CONV_STAG");
+            return e ? atoi(e) : 0;
+          }();
+          if (stag) {
+            ConvArgsT<T> b = a;
+            b.direct = stag == 2 ? 2 : 0;  // (bit 1 = s_setprio around the MFMA clusters; the direct epilogue is off here)
+            conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 4, 0, true><<<grid, 512, 0, s>>>(b);
+          }
+          else if (nb == 2) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 2><<<grid, 512, 0, s>>>(a);
           else if (nb == 3) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 3><<<grid, 512, 0, s>>>(a);
           else conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 4><<<grid, 512, 0, s>>>(a);
         }

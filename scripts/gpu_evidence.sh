@@ -13,7 +13,7 @@ timeout 600 python bench.py --phase train --dtype bf16 --batch 32 --steps 10 --w
 tail -1 $OUT/bench_train.log > $OUT/bench_train_bf16_bs32.json; cut -c1-400 $OUT/bench_train_bf16_bs32.json
 # the non-headline configurations (one line each)
 {
-  for A in "--dtype bf16 --no-train-leg --steps 20" "--phase train --batch 8 --steps 5 --warmup 2" "--size 1024 --batch 8 --no-train-leg --steps 10" "--phase train --dtype bf16 --batch 32 --classes 4 --steps 10"; do
+  for A in "--dtype bf16 --no-train-leg --steps 20" "--phase train --batch 8 --steps 5 --warmup 2" "--size 1024 --batch 8 --no-train-leg --steps 10" "--phase train --dtype bf16 --batch 32 --classes 4 --steps 10" "--size 576 --batch 16 --no-train-leg --steps 10"; do
     timeout 600 python bench.py --no-cpu-baseline $A 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], '->', d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['dtype'], '|', d['config']['workload'])" "$A"
   done
 } > $OUT/bench_others.txt 2>&1

@@ -15,13 +15,9 @@ import re
 import sys
 from collections import defaultdict
 
-root = sys.argv[1]
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
-
-
 def bench_name(k):
     k = k.replace("(anonymous namespace)::", "")
-    m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, \d+)*>", k)
+    m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, (?:\d+|true|false))*>", k)
     if m:
         return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "float" else "bf16",
                                                   "phase," if m.group(5) == "true" else "", m.group(2), m.group(3), m.group(4))
@@ -46,7 +42,7 @@ def bench_name(k):
     return m.group(1) if m else k[:40]
 
 
-def collect(tag, counter):
+def collect(root, tag, counter):
     acc = defaultdict(lambda: [0.0, 0])
     path = "{}/{}_pmc_{}/p_counter_collection.csv".format(root, tag, counter)
     if not os.path.exists(path):
@@ -61,17 +57,21 @@ def collect(tag, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
-result, lines = {}, []
-for tag in ("predict", "trainbf16", "trainf32"):
-    f, w = collect(tag, "FETCH_SIZE"), collect(tag, "WRITE_SIZE")
-    lines.append("== {} (per launch, averaged over the launches of a kernel; MB = 1e6 bytes)".format(tag))
-    for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, (0, 0))[0] + w.get(k, (0, 0))[0]) * max(f.get(k, (0, 1))[1], 1)):
-        rd = 2.0 * f.get(k, (0, 0))[0] * 1024
-        wr = w.get(k, (0, 0))[0] * 1024
-        n = (f.get(k) or w.get(k))[1]
-        lines.append("{:42s} launches {:4d}  read {:9.2f} MB  write {:9.2f} MB  total {:9.2f} MB".format(k, n, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
-        if tag == "predict" or k not in result:
-            result[k] = round(rd + wr)
-with open(out, "w") as fp:
-    json.dump(result, fp, indent=1, sort_keys=True)
-print("\n".join(lines))
+
+if __name__ == "__main__":
+    root = sys.argv[1]
+    out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
+    result, lines = {}, []
+    for tag in ("predict", "trainbf16", "trainf32"):
+        f, w = collect(root, tag, "FETCH_SIZE"), collect(root, tag, "WRITE_SIZE")
+        lines.append("== {} (per launch, averaged over the launches of a kernel; MB = 1e6 bytes)".format(tag))
+        for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, (0, 0))[0] + w.get(k, (0, 0))[0]) * max(f.get(k, (0, 1))[1], 1)):
+            rd = 2.0 * f.get(k, (0, 0))[0] * 1024
+            wr = w.get(k, (0, 0))[0] * 1024
+            n = (f.get(k) or w.get(k))[1]
+            lines.append("{:42s} launches {:4d}  read {:9.2f} MB  write {:9.2f} MB  total {:9.2f} MB".format(k, n, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+            if tag == "predict" or k not in result:
+                result[k] = round(rd + wr)
+    with open(out, "w") as fp:
+        json.dump(result, fp, indent=1, sort_keys=True)
+    print("\n".join(lines))

@@ -280,6 +280,19 @@ int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, c
  * rs_cat_split_bwd_dt then only splits torch.cat's channels, applies the ReLU masks and accumulates (rs_upsample2x_bwd
  * without the 2x2 sum). */
 int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
+/* bf16 compute copies of MANY convolution weights in one launch -- what rs_cast_f32_to_bf16 + rs_pack_dgrad_weight_bf16
+ * produce per tensor, bit for bit (the per-step re-cast of the fp32 master weights after Adam.step, robosat/tools/
+ * train.py:188; the reference has no counterpart: it computes in fp32).  `items_dev` is a DEVICE array of n items ordered
+ * by tile_begin; item i covers tiles [tile_begin_i, tile_begin_i + taps * ceil(Cin/32) * ceil(Cout/32)); total_tiles = their
+ * sum.  cast / dgrad may be NULL. */
+typedef struct rs_wprep_item {
+  const float* w; /* fp32 KRSC [Cout][taps][Cin] */
+  rs_bf16* cast;  /* bf16 KRSC copy, or NULL */
+  rs_bf16* dgrad; /* bf16 [Cin][taps, flipped][Cout] (the layout of rs_pack_dgrad_weight_bf16), or NULL */
+  int Cout, taps, Cin;
+  int tile_begin;
+} rs_wprep_item;
+int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int total_tiles, rs_stream_t stream);
 /* The same weights from the already transposed, tap-flipped fp32 weights of rs_pack_dgrad_weight ([Cin][3][3][Cout]):
  * both sides contiguous along Cout (the one-step pack reads with a 9*Cin stride). */
 int rs_combine_dgrad_phase_weight_dt(const float* w_dgrad, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);

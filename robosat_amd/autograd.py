@@ -139,6 +139,8 @@ def _forward(net, x, tape):
     r = net.resnet
     t = tape.t
     dt = net.compute_dtype  # fp32 or bf16 activations (the image is cast on upload)
+    if dt == torch.bfloat16:
+        net.prep_bf16_weights()  # one launch: bf16 casts + data-gradient layouts of the encoder weights for this step
     x4 = ops.nchw_to_nhwc4(x, dt)
     t["x4"] = x4
     if dt == torch.bfloat16:
@@ -187,7 +189,7 @@ def _forward(net, x, tape):
 def _dgrad(dy, conv, out_hw, residual=None, relu_mask=None):
     """Data gradient of ``conv`` (a parameter holder with .k/.stride/.padding) evaluated at dy (fp32 or bf16)."""
 
-    wd = ops.pack_dgrad_weight(conv.krsc(), dy.dtype)
+    wd = conv.dgrad_weight(dy.dtype)
     return ops.conv2d(dy, wd, ups=2 if conv.stride == 2 else 0, pad=conv.k - 1 - conv.padding, out_hw=out_hw,
                       residual=residual, relu_mask=relu_mask)
 
@@ -209,7 +211,7 @@ def _backward(net, tape, dlogits, arena):
     c5 = net.dec5.block
     w5 = arena.conv(c5)
     arena.wgrad(lambda: ops.conv2d_wgrad(d5, t["dec4"], 3, 3, pad=1, out=w5), d5, t["dec4"])
-    d4 = ops.conv2d(d5, ops.pack_dgrad_weight(c5.krsc(), d5.dtype), pad=1, relu_mask=t["dec4"])
+    d4 = ops.conv2d(d5, c5.dgrad_weight(d5.dtype), pad=1, relu_mask=t["dec4"])
     del d5
 
     def up_bwd(block, dz, skip, prev, mask_skip, mask_prev, skip_grad_out=None):
@@ -255,7 +257,7 @@ def _backward(net, tape, dlogits, arena):
     def dgrad_into_bn(dy, conv, out_hw, y, st, z, residual=None):
         """Gradient at the OUTPUT of a BatchNorm+ReLU (z) from the convolution that consumed z, with the ReLU mask and
         BatchNorm's two backward reductions done in the convolution's epilogue: returns (g, partial)."""
-        wd = ops.pack_dgrad_weight(conv.krsc(), dy.dtype)
+        wd = conv.dgrad_weight(dy.dtype)
         return ops.conv2d_dgrad_bnstats(dy, wd, out_hw, y, st[0], st[1], ups=2 if conv.stride == 2 else 0,
                                         pad=conv.k - 1 - conv.padding, residual=residual, relu_mask=z)
 

@@ -676,6 +676,53 @@ __global__ void pack_dgrad_weight_bf16_kernel(const float* __restrict__ w, bf16_
   }
 }
 
+// The same for MANY weight tensors in one launch (the bf16 compute copies of a whole network after an optimizer step):
+// block -> (item, 32x32 tile); one read of the fp32 tile feeds both the bf16 KRSC copy and the transposed, tap-flipped
+// data-gradient copy.
+__global__ __launch_bounds__(256) void weight_prep_bf16_kernel(const rs_wprep_item* __restrict__ items, int n) {
+  __shared__ float tile[32][33];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n - 1;  // last item with tile_begin <= bid (block-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile_begin <= bid) lo = mid;
+    else hi = mid - 1;
+  }
+  const rs_wprep_item it = items[lo];
+  int t = bid - it.tile_begin;
+  const int tci = (it.Cin + 31) / 32, tco = (it.Cout + 31) / 32;
+  const int ci0 = (t % tci) * 32;
+  t /= tci;
+  const int co0 = (t % tco) * 32;
+  const int tap = t / tco;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  bf16_t* cast = reinterpret_cast<bf16_t*>(it.cast);
+  bf16_t* dgrad = reinterpret_cast<bf16_t*>(it.dgrad);
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < it.Cout && ci < it.Cin) {
+      const long i = ((long)co * it.taps + tap) * it.Cin + ci;
+      v = it.w[i];
+      if (cast) cast[i] = (bf16_t)v;
+    }
+    tile[r][tx] = v;
+  }
+  if (!dgrad) return;  // (block-uniform)
+  __syncthreads();
+  const int ftap = it.taps - 1 - tap;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < it.Cin && co < it.Cout) dgrad[((long)ci * it.taps + ftap) * it.Cout + co] = (bf16_t)tile[tx][r];
+  }
+}
+
+extern "C" int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int total_tiles, rs_stream_t stream) {
+  if (!items_dev || n <= 0 || total_tiles <= 0) return RS_EINVAL;
+  weight_prep_bf16_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(items_dev, n);
+  return RS_LAUNCH_RESULT();
+}
+
 // (index 4 is the fp32 stem kernel of conv_igemm.hip: the two files share the index space of rs_conv2d_tile_name)
 // T256x256 / T512x128: 8-wave blocks, one per CU, bf16 only (see pick_tile)
 enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, T512x128, NTILES };

@@ -334,6 +334,40 @@ def cast_bf16(t):
     return out
 
 
+class _WPrepItem(ctypes.Structure):  # rs_wprep_item (include/robosat_hip.h)
+    _fields_ = [("w", ctypes.c_void_p), ("cast", ctypes.c_void_p), ("dgrad", ctypes.c_void_p), ("Cout", ctypes.c_int),
+                ("taps", ctypes.c_int), ("Cin", ctypes.c_int), ("tile_begin", ctypes.c_int)]
+
+
+class WeightPrep:
+    """One launch (``rs_weight_prep_bf16``) that refreshes the bf16 compute copies of a fixed set of fp32 KRSC weights:
+    the bf16 KRSC cast and the transposed, tap-flipped data-gradient layout of each -- bit-identical to ``cast_bf16`` /
+    ``pack_dgrad_weight(w, bfloat16)`` per tensor.  The destination buffers and the device-side item table are allocated
+    once; ``run()`` is what a training step calls after the optimizer moved the master weights."""
+
+    def __init__(self, weights_krsc, want_dgrad=True):
+        assert weights_krsc and all(w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 for w in weights_krsc)
+        dev = weights_krsc[0].device
+        self.weights = list(weights_krsc)
+        self.cast = [torch.empty(w.shape, device=dev, dtype=BF16) for w in self.weights]
+        self.dgrad = [torch.empty((w.shape[3], w.shape[1], w.shape[2], w.shape[0]), device=dev, dtype=BF16) if want_dgrad else None
+                      for w in self.weights]
+        items = (_WPrepItem * len(self.weights))()
+        tiles = 0
+        for i, w in enumerate(self.weights):
+            cout, kh, kw, cin = w.shape
+            items[i] = _WPrepItem(_dev(w, "w").value, _dev(self.cast[i], "cast", BF16).value,
+                                  _dev(self.dgrad[i], "dgrad", BF16).value if want_dgrad else None, cout, kh * kw, cin, tiles)
+            tiles += kh * kw * ((cin + 31) // 32) * ((cout + 31) // 32)
+        self.tiles = tiles
+        self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        self.ptrs = tuple(w.data_ptr() for w in self.weights)
+
+    def run(self):
+        check(_lib.lib().rs_weight_prep_bf16(_dev(self.table, "items", torch.uint8), len(self.weights), self.tiles, _stream()),
+              "rs_weight_prep_bf16")
+
+
 def pack_stem_weight(w_krsc, dtype=torch.float32):
     """fp32 [Cout,kh,kw<=8,Cin<=4] -> [Cout,kh,8,4] (zero padded) in ``dtype``."""
 

@@ -61,6 +61,15 @@ class _Conv(nn.Module):
             self._bf16 = c
         return c[1]
 
+    def dgrad_weight(self, dtype=torch.float32):
+        """Data-gradient weights [Cin,kh,kw,Cout], taps flipped, in ``dtype``: the copy ``UNet.prep_bf16_weights`` made for
+        the current parameter version if there is one, else packed now (``rs_pack_dgrad_weight[_bf16]``)."""
+
+        c = getattr(self, "_dgrad", None)
+        if dtype == torch.bfloat16 and c is not None and c[0] == (self.weight.data_ptr(), self.weight._version):
+            return c[1]
+        return ops.pack_dgrad_weight(self.krsc(), dtype)
+
     def phase(self, dtype=torch.float32):
         """The four parity-specific 2x2 filters of this 3x3 convolution behind a nearest-x2 upsample (DecoderBlock),
         packed on the device from the fp32 master and cached until the parameter is modified."""
@@ -237,6 +246,31 @@ class UNet(nn.Module):
     def _blocks(self):
         r = self.resnet
         return [list(r.layer1), list(r.layer2), list(r.layer3), list(r.layer4)]
+
+    def prep_bf16_weights(self):
+        """Refresh, in ONE launch, the bf16 compute copies (KRSC cast + data-gradient layout) of the convolutions that
+        use them in a bf16 training step -- the 52 encoder convolutions and dec5 -- if any master weight changed since
+        the last refresh (i.e. once per optimizer step).  ``_Conv.krsc(bf16)`` / ``_Conv.dgrad_weight(bf16)`` then hit
+        these copies; without this call they cast / pack per tensor as before (105 small launches per step)."""
+
+        convs = []
+        for layer in self._blocks():
+            for blk in layer:
+                convs += [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
+        convs.append(self.dec5.block)
+        keys = [(c.weight.data_ptr(), c.weight._version) for c in convs]
+        st = getattr(self, "_wprep", None)
+        if st is not None and st[1] == keys:
+            return
+        ws = [c.krsc() for c in convs]
+        if st is None or st[0].ptrs != tuple(w.data_ptr() for w in ws):  # first use, or the parameters moved (.to(), load)
+            st = [ops.WeightPrep(ws), None]
+        st[0].run()
+        st[1] = keys
+        self._wprep = st
+        for c, k, cast, dg in zip(convs, keys, st[0].cast, st[0].dgrad):
+            c._bf16 = (k, cast)
+            c._dgrad = (k, dg)
 
     # -- forward ------------------------------------------------------------------------------------------------
 

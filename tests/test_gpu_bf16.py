@@ -449,3 +449,30 @@ def test_unet_bf16_train_step_vs_oracle(loss_name):
         if name.endswith("running_mean") or name.endswith("running_var"):
             want = rb[name]
             assert float((b.cpu() - want).abs().max()) <= 1e-2 * max(1.0, float(want.abs().max())), name
+
+def test_weight_prep_multi_tensor_is_bit_identical():
+    """rs_weight_prep_bf16 (one launch for many weights) == rs_cast_f32_to_bf16 + rs_pack_dgrad_weight_bf16 per tensor, and
+    UNet.prep_bf16_weights() re-runs exactly when a master weight changes."""
+    from robosat_amd import ops
+    from robosat_amd.unet import UNet
+
+    shapes = [(64, 1, 1, 64), (64, 3, 3, 64), (256, 1, 1, 64), (96, 3, 3, 40), (33, 1, 1, 70), (512, 3, 3, 512)]
+    ws = [rnd(*s, seed=40 + i).to(DEV) for i, s in enumerate(shapes)]
+    prep = ops.WeightPrep(ws)
+    prep.run()
+    for w, c, d in zip(ws, prep.cast, prep.dgrad):
+        assert torch.equal(c, ops.cast_bf16(w))
+        assert torch.equal(d, ops.pack_dgrad_weight(w, torch.bfloat16))
+
+    net = UNet(2, pretrained=False, compute_dtype=torch.bfloat16).to(DEV)
+    net.prep_bf16_weights()
+    c = net.resnet.layer2[1].conv2
+    first = c.krsc(torch.bfloat16)
+    assert first is net._wprep[0].cast[net._wprep[0].ptrs.index(c.krsc().data_ptr())]
+    assert torch.equal(first, ops.cast_bf16(c.krsc())) and torch.equal(c.dgrad_weight(torch.bfloat16), ops.pack_dgrad_weight(c.krsc(), torch.bfloat16))
+    with torch.no_grad():
+        c.weight.mul_(1.5)  # what an optimizer step does: in place, version bump
+    assert c.krsc(torch.bfloat16) is not first or not torch.equal(c.krsc(torch.bfloat16), first)  # stale copy is not served
+    net.prep_bf16_weights()
+    assert torch.equal(c.krsc(torch.bfloat16), ops.cast_bf16(c.krsc()))
+    assert torch.equal(c.dgrad_weight(torch.bfloat16), ops.pack_dgrad_weight(c.krsc(), torch.bfloat16))

@@ -76,3 +76,32 @@ def test_no_cpu_fallback():
     net = UNet(2, pretrained=False).eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 64, 64))
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """The ctypes mirrors of the two structs that cross the C ABI (rs_conv_desc, rs_wprep_item) have the size and field
+    offsets gcc gives the declarations in include/robosat_hip.h (the header must also compile as plain C)."""
+    import ctypes
+    import subprocess
+
+    from robosat_amd import _lib, ops
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"rs_conv_desc": _lib.ConvDesc, "rs_wprep_item": ops._WPrepItem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "robosat_hip.h"', "int main(void) {"]
+    for cname, mirror in structs.items():
+        lines.append('  printf("{0} size %zu\\n", sizeof({0}));'.format(cname))
+        for fname, _ in mirror._fields_:
+            lines.append('  printf("{0} {1} %zu\\n", offsetof({0}, {1}));'.format(cname, fname))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, field, value = line.split()
+        got[(cname, field)] = int(value)
+    for cname, mirror in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert got[(cname, fname)] == getattr(mirror, fname).offset, (cname, fname)

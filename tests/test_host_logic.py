@@ -105,3 +105,40 @@ def test_struct_layouts_match_the_c_header(tmp_path):
         assert got[(cname, "size")] == ctypes.sizeof(mirror), cname
         for fname, _ in mirror._fields_:
             assert got[(cname, fname)] == getattr(mirror, fname).offset, (cname, fname)
+
+def test_dispatcher_choices_for_the_benchmark_layers():
+    """rs_conv2d_config is pure host logic: pin the (tile, K-chunk row bytes) the dispatcher picks for representative
+    layers of the two benchmark configurations, i.e. the measured heuristics of pick_tile / pick_rowb.
+    A deliberate re-tune changes this table together with the measurement that justifies it."""
+    from robosat_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("librobosat_hip.so not built (run __graft_entry__.build())")
+    lib = _lib.lib()
+
+    def cfg(n, hs, ws, c1, c2, ups, k, stride, pad, ho, wo, cout, es, phase=0):
+        d = _lib.ConvDesc(n, hs, ws, c1, c2, ups, k, k, stride, pad, ho, wo, cout, 0, 0)
+        tile, rowb = ctypes.c_int(0), ctypes.c_int(0)
+        assert lib.rs_conv2d_config(ctypes.byref(d), es, phase, ctypes.byref(tile), ctypes.byref(rowb)) == 0
+        name = (lib.rs_conv2d_tile_name_bf16 if es == 2 else lib.rs_conv2d_tile_name)(tile.value).decode()
+        return name[name.index("<") + 1:-1], rowb.value
+
+    fp32 = [  # predict bs 16, fp32 (es 4)
+        ((16, 128, 128, 64, 0, 0, 1, 1, 0, 128, 128, 256, 4), ("128x128", 64)),      # layer1 conv3: short K
+        ((16, 32, 32, 256, 0, 0, 1, 1, 0, 32, 32, 1024, 4), ("128x128", 64)),        # layer3 conv3: nk128 = 8
+        ((16, 32, 32, 1024, 0, 0, 1, 1, 0, 32, 32, 256, 4), ("128x64", 128)),        # layer3 conv1: long K, small grid
+        ((16, 16, 16, 512, 0, 0, 3, 1, 1, 16, 16, 512, 4), ("64x64", 128)),          # layer4 conv2
+        ((16, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 4, 1), ("128x128", 64)), # dec3, phase form: large grid
+        ((16, 16, 16, 2048, 256, 1, 3, 1, 1, 32, 32, 256, 4, 1), ("128x64", 128)),   # dec0, phase form
+    ]
+    bf16 = [  # train bs 32, bf16 (es 2)
+        ((32, 128, 128, 64, 0, 0, 1, 1, 0, 128, 128, 256, 2), ("128x128", 64)),      # short K: occupancy
+        ((32, 32, 32, 1024, 0, 0, 1, 1, 0, 32, 32, 256, 2), ("128x128", 128)),       # nk128 = 16, 512 blocks
+        ((32, 128, 128, 64, 0, 0, 3, 1, 1, 128, 128, 64, 2), ("128x64", 128)),       # layer1 conv2
+        ((32, 32, 32, 1024, 256, 1, 3, 1, 1, 64, 64, 256, 2, 1), ("256x256", 128)),  # dec1, phase form: 8-wave tile
+        ((32, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 2, 1), ("128x128", 128)),# dec3, phase form
+        ((32, 256, 256, 128, 0, 0, 4, 2, 1, 128, 128, 320, 2), ("128x128", 128)),    # dec3 data gradient: ragged N (320)
+        ((32, 16, 16, 2048, 256, 1, 3, 1, 1, 32, 32, 256, 2, 1), ("128x128", 128)),  # dec0: too few blocks for 256x256
+    ]
+    for args, want in fp32 + bf16:
+        assert cfg(*args) == want, (args, cfg(*args), want)

@@ -1,4 +1,6 @@
-"""Datasets over slippy-map tile directories (reference ``robosat/datasets.py``), feeding batches to the GPU path."""
+"""Datasets over slippy-map tile directories: the class surface of the reference's ``robosat/datasets.py``
+(``SlippyMapTiles``, ``SlippyMapTilesConcatenation``, ``BufferedSlippyMapDirectory``), feeding batches to the GPU path.
+Parity with the reference's own classes on the same directory: ``tests/test_feeders.py``."""
 
 import torch
 import torch.utils.data
@@ -7,67 +9,71 @@ from PIL import Image
 from .tiles import buffer_tile_image, tiles_from_slippy_map
 
 
-class SlippyMapTiles(torch.utils.data.Dataset):
-    """One ``z/x/y.*`` directory; items are ``(image, tile)`` in sorted tile order."""
+class _TileDirectory(torch.utils.data.Dataset):
+    """A ``z/x/y.*`` directory listed once into ``self.tiles = [(tile, path), ...]``."""
 
-    def __init__(self, root, transform=None):
+    def __init__(self, root, ordered):
         super().__init__()
-        self.transform = transform
-        self.tiles = sorted(tiles_from_slippy_map(root), key=lambda entry: entry[0])
+        listing = tiles_from_slippy_map(root)
+        self.tiles = sorted(listing, key=lambda entry: entry[0]) if ordered else list(listing)
 
     def __len__(self):
         return len(self.tiles)
 
+
+class SlippyMapTiles(_TileDirectory):
+    """Items are ``(image, tile)`` in sorted tile order (``datasets.py:16-39``)."""
+
+    def __init__(self, root, transform=None):
+        super().__init__(root, ordered=True)
+        self.transform = transform
+
     def __getitem__(self, i):
         tile, path = self.tiles[i]
         image = Image.open(path)
-        if self.transform is not None:
-            image = self.transform(image)
-        return image, tile
+        return (image if self.transform is None else self.transform(image)), tile
 
 
 class SlippyMapTilesConcatenation(torch.utils.data.Dataset):
     """Several image directories (concatenated on the channel axis) plus one label directory; items are
-    ``(images [sum C,H,W], mask [H,W], tiles)`` after the joint transform."""
+    ``(images [sum C,H,W], mask [H,W], tiles)`` after the joint transform (``datasets.py:44-78``)."""
 
     def __init__(self, inputs, target, joint_transform=None):
         super().__init__()
         self.joint_transform = joint_transform
-        self.inputs = [SlippyMapTiles(inp) for inp in inputs]
+        self.inputs = [SlippyMapTiles(directory) for directory in inputs]  # transforms are joint: applied in __getitem__
         self.target = SlippyMapTiles(target)
-        assert len({len(ds) for ds in self.inputs}) == 1, "same number of tiles in all images"
-        assert len(self.target) == len(self.inputs[0]), "same number of tiles in images and label"
+        counts = {len(ds) for ds in self.inputs}
+        assert len(counts) == 1, "same number of tiles in all images"
+        assert counts == {len(self.target)}, "same number of tiles in images and label"
 
     def __len__(self):
         return len(self.target)
 
     def __getitem__(self, i):
-        pairs = [ds[i] for ds in self.inputs]
-        images, tiles = [p[0] for p in pairs], [p[1] for p in pairs]
+        images, tiles = zip(*(ds[i] for ds in self.inputs))
         mask, mask_tile = self.target[i]
         assert len(set(tiles)) == 1, "all images are for the same tile"
         assert tiles[0] == mask_tile, "image tile is the same as label tile"
+        images = list(images)
         if self.joint_transform is not None:
             images, mask = self.joint_transform(images, mask)
-        return torch.cat(images, dim=0), mask, tiles
+        return torch.cat(images, dim=0), mask, list(tiles)
 
 
-class BufferedSlippyMapDirectory(torch.utils.data.Dataset):
-    """Tiles composited with an ``overlap`` border from their neighbours; ``unbuffer`` crops predictions back."""
+class BufferedSlippyMapDirectory(_TileDirectory):
+    """Tiles composited with an ``overlap``-pixel border from their neighbours (``datasets.py:83-136``); ``unbuffer``
+    crops a prediction back to the tile.  The tile -> path map is built once (the reference rebuilds it per item)."""
 
     def __init__(self, root, transform=None, size=512, overlap=32):
-        super().__init__()
         assert overlap >= 0
         assert size >= 256
+        super().__init__(root, ordered=False)
         self.transform, self.size, self.overlap = transform, size, overlap
-        self.tiles = list(tiles_from_slippy_map(root))
-        self._store = dict(self.tiles)  # built once (the reference rebuilds this mapping for every item)
-
-    def __len__(self):
-        return len(self.tiles)
+        self._store = dict(self.tiles)
 
     def __getitem__(self, i):
-        tile, _ = self.tiles[i]
+        tile = self.tiles[i][0]
         image = buffer_tile_image(tile, self._store, overlap=self.overlap, tile_size=self.size)
         if self.transform is not None:
             image = self.transform(image)
@@ -75,5 +81,4 @@ class BufferedSlippyMapDirectory(torch.utils.data.Dataset):
 
     def unbuffer(self, probs):
         o = self.overlap
-        _, h, w = probs.shape
-        return probs[:, o:h - o, o:w - o]
+        return probs[:, o:probs.shape[1] - o, o:probs.shape[2] - o]

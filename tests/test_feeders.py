@@ -1,0 +1,93 @@
+"""Feeders against the UNMODIFIED reference, on the CPU: the slippy-map datasets, the joint
+transform chain of ``rs train`` and the buffered tiles of ``rs predict`` hand the model the same tensors the reference's
+own classes do on the same directory.  Needs /root/reference (dev container); skipped where it is absent."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refshim
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refshim.available(), reason="reference tree not present")
+
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]  # train.py:246, predict.py:71
+
+
+def _reference_modules():
+    """The reference's own datasets / transforms modules.  Resize, CenterCrop, Normalize and ToTensor are torchvision's in
+    the reference (train.py:14, transforms.py:14): here the refshim stand-ins, so for those four the comparison only says
+    both sides follow torchvision's semantics -- the datasets, the joint/random transforms, ConvertImageMode, MaskToTensor
+    and the tile buffering are the reference's own code."""
+    import types
+
+    refshim.load_reference()  # installs the stand-ins and puts the reference on sys.path
+    import robosat.datasets as rd  # noqa: E402  (the reference's own files)
+    import robosat.transforms as rt  # noqa: E402
+    import torchvision.transforms as tvt  # noqa: E402  (stand-in)
+
+    ns = types.SimpleNamespace(**{k: getattr(rt, k) for k in dir(rt) if not k.startswith("_")})
+    ns.Resize, ns.CenterCrop, ns.Normalize, ns.Compose = tvt.Resize, tvt.CenterCrop, tvt.Normalize, tvt.Compose
+    return rd, ns
+
+
+def _chain(t):
+    """The training transform of train.py:248-260 (the random flips/rotations draw from `random`)."""
+    return t.JointCompose([
+        t.JointTransform(t.ConvertImageMode("RGB"), t.ConvertImageMode("P")),
+        t.JointTransform(t.Resize((96, 96), 2), t.Resize((96, 96), 0)),  # bilinear / nearest (PIL codes)
+        t.JointTransform(t.CenterCrop((64, 64)), t.CenterCrop((64, 64))),
+        t.JointRandomHorizontalFlip(0.5),
+        t.JointRandomRotation(0.5, 90),
+        t.JointRandomRotation(0.5, 90),
+        t.JointRandomRotation(0.5, 90),
+        t.JointTransform(t.ImageToTensor(), t.MaskToTensor()),
+        t.JointTransform(t.Normalize(mean=MEAN, std=STD), None),
+    ])
+
+
+def test_training_dataset_items_match_reference(tmp_path):
+    rd, rt = _reference_modules()
+    from robosat_amd import datasets as md, transforms as mt
+
+    root = synth.make_dataset(str(tmp_path / "ds"), n_train=6, n_val=2, size=128, seed=11)
+    img, lab = os.path.join(root, "training", "images"), os.path.join(root, "training", "labels")
+    ours = md.SlippyMapTilesConcatenation([img], lab, _chain(mt))
+    ref = rd.SlippyMapTilesConcatenation([img], lab, _chain(rt))
+    assert len(ours) == len(ref) == 6
+    for i in range(len(ref)):
+        random.seed(100 + i)
+        a_img, a_mask, a_tiles = ours[i]
+        random.seed(100 + i)
+        b_img, b_mask, b_tiles = ref[i]
+        assert [tuple(t) for t in a_tiles] == [tuple(t) for t in b_tiles]
+        assert a_img.dtype == b_img.dtype == torch.float32 and a_mask.dtype == b_mask.dtype == torch.int64
+        assert torch.equal(a_img, b_img) and torch.equal(a_mask, b_mask), i
+
+
+def test_buffered_predict_tiles_match_reference(tmp_path):
+    rd, rt = _reference_modules()
+    from robosat_amd import datasets as md, transforms as mt
+
+    root = synth.make_dataset(str(tmp_path / "ds"), n_train=8, n_val=0, size=256, seed=12)
+    img = os.path.join(root, "training", "images")
+
+    def chain(t):  # predict.py:73
+        return t.Compose([t.ConvertImageMode("RGB"), t.ImageToTensor(), t.Normalize(mean=MEAN, std=STD)])
+
+    ours = md.BufferedSlippyMapDirectory(img, transform=chain(mt), size=256, overlap=32)
+    ref = rd.BufferedSlippyMapDirectory(img, transform=chain(rt), size=256, overlap=32)
+    assert len(ours) == len(ref) == 8
+    got = {tuple(t.tolist()): im for im, t in (ours[i] for i in range(len(ours)))}
+    for i in range(len(ref)):
+        b_img, b_tile = ref[i]
+        a_img = got[tuple(b_tile.tolist())]
+        assert a_img.shape == (3, 320, 320)
+        assert torch.equal(a_img, b_img), b_tile
+    probs = np.random.default_rng(0).random((2, 320, 320)).astype(np.float32)
+    assert np.array_equal(ours.unbuffer(probs), ref.unbuffer(probs)) and ours.unbuffer(probs).shape == (2, 256, 256)

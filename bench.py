@@ -232,6 +232,9 @@ def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
                 "Lovasz": lambda: losses.LovaszLoss2d()}[args.loss]().to(device)
         opt = torch.optim.Adam(net.parameters(), lr=1e-4)
         if dist:
+            from robosat_amd import parallel
+
+            parallel.broadcast_module(net)  # (the replicas are seeded identically; this is what `rs train` does)
             net.grad_reducer = GradReducer()  # bucketed RCCL all-reduce overlapped with the backward kernels
 
         def step():
@@ -276,15 +279,22 @@ def workload(args, phase, dtype, batch, world):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from robosat_amd import launch, parallel
+
+    if not launch.under_launcher() and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU), exactly what the driver's
+        # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` provides from outside
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    world, rank, local = launch.dist_env()
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus {} but the launcher started {} rank(s); reporting n_gpus = {}".format(args.gpus, world, world),
+              file=sys.stderr)
     dist = world > 1
     if dist:
         import torch.distributed as td
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+        parallel.init_process_group(world, rank)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if dist:
@@ -292,7 +302,10 @@ def main():
         # use) out of the buffer, so that the JSON line below stays the LAST line of stdout.
         import ctypes
 
-        td.barrier(device_ids=[local])
+        if td.get_backend() == "nccl":
+            td.barrier(device_ids=[local])
+        else:
+            td.barrier()
         ctypes.CDLL(None).fflush(None)
 
     el, step = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)

@@ -12,8 +12,58 @@ are what keeps all 7 links busy; per-tensor collectives (168 of them) would be l
 BatchNorm statistics stay per-rank (unsynchronised), exactly like the per-replica statistics of ``DataParallel``.
 """
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(world, rank, backend=None):
+    """Join the job's process group: RCCL ("nccl") on the MI355X; ``ROBOSAT_DIST_BACKEND=gloo`` selects gloo (the
+    world-size-2 tests that run two ranks on ONE GPU -- RCCL refuses two ranks per device; gloo reduces device tensors
+    through host memory)."""
+
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = backend or os.environ.get("ROBOSAT_DIST_BACKEND", "nccl")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+
+def broadcast_module(module, src=0):
+    """Every parameter and buffer of ``module`` := rank ``src``'s.  ``DataParallel`` re-broadcasts the parameters of
+    device 0 on every forward (reference tools/train.py:69,180); with one replica per process the replicas only have
+    to START identical -- the averaged gradients then keep them identical -- so this runs once after construction /
+    checkpoint load.  Tensors travel in one flat buffer per dtype (a handful of collectives, not 329)."""
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
+    _broadcast_flat(tensors, src)
+
+
+def broadcast_bn_buffers(module, src=0):
+    """BatchNorm running statistics := rank ``src``'s.  The reference's replicas update private copies that are thrown
+    away; only device 0's survive.  Called before validation / checkpointing so that the logged
+    validation numbers are those of the model rank 0 saves."""
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    _broadcast_flat([b.data for b in module.buffers()], src)
+
+
+def _broadcast_flat(tensors, src):
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, ts in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))  # (.copy_ keeps each tensor's memory format, e.g. KRSC weights)
+            off += n
 
 
 class GradReducer:
@@ -47,12 +97,13 @@ class GradReducer:
 
 
 def shard_indices(num_items, batch_size, rank, world, epoch_order=None, drop_last=True):
-    """The slice of an epoch's sample order that ``rank`` processes.
+    """The slice of an epoch's sample order that ``rank`` processes; ``batch_size`` = samples per rank per step.
 
     The global order (``epoch_order``: a permutation for the shuffled training loader, ``range`` for validation --
     reference tools/train.py:273-274) is cut into global batches of ``batch_size * world`` samples with the reference's
     ``drop_last=True`` semantics; each rank takes its contiguous ``batch_size`` share of every global batch, which is
-    how ``DataParallel`` splits a batch along dim 0 (tools/train.py:69)."""
+    how ``DataParallel`` splits a batch along dim 0 (tools/train.py:69).  ``rs train`` passes
+    ``[common] batch_size / world`` here: the TOML batch size stays the GLOBAL batch, as in the reference."""
 
     order = list(range(num_items)) if epoch_order is None else list(epoch_order)
     gb = batch_size * world

@@ -1,7 +1,9 @@
 """``rs predict``: same flags and output files as the reference (``robosat/tools/predict.py``) -- one mode-P PNG per
 tile holding the 8-bit quantised foreground probability with the continuous pink palette -- computed by the
-MI355X-native model with the softmax fused into the last kernel.  With several processes (torchrun) the batches are
-dealt round-robin to the ranks; there is no collective."""
+MI355X-native model with the softmax fused into the last kernel.  A plain ``rs predict`` uses every visible GPU like
+the reference's ``DataParallel`` (tools/predict.py:63): it re-executes itself once per GPU (``robosat_amd.launch``);
+the batches are dealt round-robin to the ranks by the batch sampler (each rank decodes only its own tiles) and there is
+no collective."""
 
 import argparse
 import os
@@ -13,6 +15,7 @@ from PIL import Image
 from torch.utils.data import DataLoader
 from tqdm import tqdm
 
+from robosat_amd import launch
 from robosat_amd.colors import continuous_palette_for_color
 from robosat_amd.config import load_config
 from robosat_amd.datasets import BufferedSlippyMapDirectory
@@ -51,6 +54,23 @@ def quantize(foreground):
     return np.digitize(foreground, np.linspace(0, 1, 256)).astype(np.uint8)
 
 
+class RankBatchSampler:
+    """The reference's sequential batches (DataLoader(batch_size=B), predict.py:78), of which rank r takes every
+    ``world``-th: each rank loads and composites only its own tiles."""
+
+    def __init__(self, num_items, batch_size, rank=0, world=1):
+        self.n, self.bs, self.rank, self.world = num_items, batch_size, rank, world
+
+    def __iter__(self):
+        for i, start in enumerate(range(0, self.n, self.bs)):
+            if i % self.world == self.rank:
+                yield list(range(start, min(start + self.bs, self.n)))
+
+    def __len__(self):
+        nb = (self.n + self.bs - 1) // self.bs
+        return (nb - self.rank + self.world - 1) // self.world
+
+
 def main(args):
     model = load_config(args.model)
     dataset = load_config(args.dataset)
@@ -60,7 +80,12 @@ def main(args):
     if not torch.cuda.is_available():
         sys.exit("Error: CUDA requested but not available")
 
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if not launch.under_launcher():
+        gpus = int(os.environ.get("ROBOSAT_GPUS", torch.cuda.device_count()))
+        if gpus > 1:
+            launch.relaunch_per_gpu(gpus, module="robosat_amd.tools")
+    world, rank, local = launch.dist_env()
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -85,12 +110,11 @@ def main(args):
     directory = BufferedSlippyMapDirectory(args.tiles, transform=transform, size=args.tile_size, overlap=args.overlap)
     assert len(directory) > 0, "at least one tile in dataset"
 
-    loader = DataLoader(directory, batch_size=args.batch_size, num_workers=args.workers, pin_memory=True)
+    loader = DataLoader(directory, num_workers=args.workers, pin_memory=True,
+                        batch_sampler=RankBatchSampler(len(directory), args.batch_size, rank, world))
     palette = continuous_palette_for_color("pink", 256)
 
-    for i, (images, tiles) in enumerate(tqdm(loader, desc="Eval", unit="batch", ascii=True, disable=rank != 0)):
-        if i % world != rank:
-            continue
+    for images, tiles in tqdm(loader, desc="Eval", unit="batch", ascii=True, disable=rank != 0):
         if host_pipeline:
             probs = net.predict_probs(images.to(device, non_blocking=True)).cpu().numpy()
             quantized = []

@@ -2,9 +2,13 @@
 (``robosat/tools/train.py``), driving the MI355X-native model, losses and metrics.
 
 Differences by design:
-  * data parallelism is one process per GPU with an RCCL gradient all-reduce (launch with ``torchrun`` or let
-    WORLD_SIZE/RANK/LOCAL_RANK be set); a single process uses one GPU.  The checkpoint keeps the ``module.`` key prefix
-    the reference's ``DataParallel`` wrapper produces, so files are interchangeable; only rank 0 writes.
+  * data parallelism is one process per GPU with an RCCL gradient all-reduce.  A plain ``rs train`` uses every visible
+    GPU like the reference's ``DataParallel`` (tools/train.py:69): it re-executes itself once per GPU
+    (``robosat_amd.launch``); under ``torchrun`` the given ranks are used as they are.  ``[common] batch_size`` stays the
+    GLOBAL batch, split contiguously over the ranks as ``DataParallel`` scatters dim 0.  All replicas start from rank 0's
+    parameters (broadcast once), BatchNorm statistics stay per replica and rank 0's are the ones validated and saved --
+    what survives of the reference's replicas.  The checkpoint keeps the ``module.`` key prefix the reference's
+    ``DataParallel`` wrapper produces, so files are interchangeable; only rank 0 writes.
   * the per-step ``loss.item()`` and the 4 host syncs per sample of ``Metrics.add`` are gone: loss and confusion
     counts accumulate on the device and are read once per epoch.
 """
@@ -21,7 +25,7 @@ from torch.optim import Adam
 from torch.utils.data import DataLoader
 from tqdm import tqdm
 
-from robosat_amd import parallel
+from robosat_amd import launch, parallel
 from robosat_amd.config import load_config
 from robosat_amd.datasets import SlippyMapTilesConcatenation
 from robosat_amd.log import Log
@@ -59,10 +63,9 @@ def add_parser(subparser):
 
 
 def _dist_env():
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    world, rank, local = launch.dist_env()
+    if world > 1:
+        parallel.init_process_group(world, rank)
     return world, rank, local
 
 
@@ -75,7 +78,18 @@ def main(args):
     if not torch.cuda.is_available():
         sys.exit("Error: CUDA requested but not available")
 
+    batch_size = model["common"]["batch_size"]
+    if not launch.under_launcher():
+        # the reference uses every visible GPU (DataParallel, tools/train.py:69): one process per GPU here
+        gpus = int(os.environ.get("ROBOSAT_GPUS", torch.cuda.device_count()))
+        nranks = launch.ranks_for_batch(batch_size, gpus)
+        if nranks > 1:
+            launch.relaunch_per_gpu(nranks, module="robosat_amd.tools")
+
     world, rank, local = _dist_env()
+    if batch_size % world != 0:
+        sys.exit("Error: [common] batch_size {} is not divisible by the {} ranks it is split over".format(batch_size, world))
+    local = local % max(1, torch.cuda.device_count())  # (several ranks may share a device in the gloo tests)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     master = rank == 0
@@ -85,7 +99,8 @@ def main(args):
     num_classes = len(dataset["common"]["classes"])
     # [model] compute_dtype = "bf16" (extension key; default "fp32" = the parity path) selects the bf16 MFMA kernels
     compute_dtype = model.get("model", {}).get("compute_dtype", "fp32")
-    net = Replica(UNet(num_classes, compute_dtype=compute_dtype)).to(device)
+    in_channels = int(model.get("model", {}).get("in_channels", 3))  # extension key: 4 = RGB + IR (BASELINE configs[4])
+    net = Replica(UNet(num_classes, compute_dtype=compute_dtype, in_channels=in_channels)).to(device)
     if world > 1:
         net.module.grad_reducer = parallel.GradReducer()
 
@@ -105,6 +120,8 @@ def main(args):
         if args.resume:
             optimizer.load_state_dict(chkpt["optimizer"])
             resume = chkpt["epoch"]
+    # replicas must start identical (each rank drew its own random decoder): rank 0's parameters and buffers everywhere
+    parallel.broadcast_module(net)
 
     loss_name = model["opt"]["loss"]
     if loss_name == "CrossEntropy":
@@ -152,6 +169,7 @@ def main(args):
         for k, v in train_hist.items():
             history["train " + k].append(v)
 
+        parallel.broadcast_bn_buffers(net)  # validate (and save) the model rank 0 holds
         val_hist = validate(val_loader, num_classes, device, net, criterion, master)
         say(fmt.format("Validate", val_hist["loss"], val_hist["miou"], fg, val_hist["fg_iou"], val_hist["mcc"]))
         for k, v in val_hist.items():
@@ -201,11 +219,11 @@ def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, 
         metrics.add_batch(masks, outputs.detach())
 
     # one sync per epoch; same normalisation quirk as the reference: sum of batch-mean losses / number of samples
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    # (with W ranks a global batch's loss is the mean of the ranks' shard losses and it holds W shards' samples)
     total_loss, total_samples = parallel.average_scalars([float(running_loss.item()), float(num_samples)], device)
+    total_samples *= dist.get_world_size() if dist.is_initialized() else 1
     if metrics._counts is not None:
         parallel.sum_counts(metrics._counts)
-    del world
     return {
         "loss": total_loss / total_samples if total_samples else float("nan"),
         "miou": metrics.get_miou(),
@@ -249,7 +267,7 @@ class ShardedBatchSampler:
 
 def get_dataset_loaders(model, dataset, workers, rank=0, world=1):
     target_size = (model["common"]["image_size"],) * 2
-    batch_size = model["common"]["batch_size"]
+    batch_size = model["common"]["batch_size"] // world  # the TOML batch is the global one (DataParallel scatters it)
     path = dataset["common"]["dataset"]
 
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]

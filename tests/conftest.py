@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The tools re-execute themselves once per visible GPU (robosat_amd.launch); tests that call a tool's main() in-process
+# must stay one process whatever box they run on.  The launcher tests set ROBOSAT_GPUS themselves.
+os.environ.setdefault("ROBOSAT_GPUS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

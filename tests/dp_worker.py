@@ -1,0 +1,121 @@
+"""Rank body of the world-size-2 data-parallel tests (started by robosat_amd.launch.spawn_ranks; see
+tests/test_parallel_gloo.py and tests/test_gpu_parallel.py).  ``python dp_worker.py <mode> <outdir>``: every rank writes
+``<outdir>/rank<r>.json``."""
+
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def cpu_logic(rank, world):
+    """gloo on CPU tensors: flat-arena reducer, replica broadcast, tile sharding."""
+    from robosat_amd import parallel
+    from robosat_amd.tools.predict import RankBatchSampler
+
+    torch.manual_seed(100 + rank)  # every rank draws different weights, as independent processes do
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
+    net[1].running_mean.add_(rank + 1.0)
+    before = float(sum(p.abs().sum() for p in net.parameters()))
+    parallel.broadcast_module(net)
+    sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, torch.tensor([float(sum(t.double().abs().sum() for t in net.state_dict().values()))], dtype=torch.float64))
+    net[1].running_var.mul_(rank + 2.0)
+    parallel.broadcast_bn_buffers(net)
+    red = parallel.GradReducer()
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red.reduce_async(flat[0:400])
+    red.reduce_async(flat[400:1000])
+    red.wait()
+    return {"before": before, "sums": [float(s) for s in sums], "running_var": net[1].running_var.tolist(),
+            "flat_ok": bool(torch.allclose(flat, torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1)) / world)),
+            "loss": parallel.average_scalars([float(rank)], torch.device("cpu"))[0],
+            "counts": parallel.sum_counts(torch.tensor([1, 2, 3, 4 + rank])).tolist(),
+            "shards": parallel.shard_indices(10, 2, rank, world),
+            "predict_batches": list(RankBatchSampler(10, 3, rank, world))}
+
+
+def gpu_unet(rank, world, dtype):
+    """Two replicas on ONE MI355X (gloo reduces the device tensors through the host): a full U-Net training step through
+    GradArena + GradReducer must give every rank the MEAN of the ranks' local gradients, and the replicas must stay
+    identical through optimizer steps."""
+    from robosat_amd import losses, parallel
+    from robosat_amd.unet import UNet
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(100 + rank)
+    net = UNet(2, pretrained=False, compute_dtype=dtype).to(dev).train()
+    parallel.broadcast_module(net)
+    g = torch.Generator().manual_seed(7 + rank)
+    x = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    t = torch.randint(0, 2, (2, 64, 64), generator=g).to(dev)
+    crit = losses.LovaszLoss2d().to(dev)
+    params = [p for n, p in net.named_parameters() if not n.startswith("resnet.fc.")]
+
+    def grads(reducer):
+        net.grad_reducer = reducer
+        for p in net.parameters():
+            p.grad = None
+        loss = crit(net(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.reshape(-1).float() for p in params]), float(loss)
+
+    local, loss_local = grads(None)
+    want = local.clone()
+    dist.all_reduce(want, op=dist.ReduceOp.SUM)
+    want /= world
+    got, loss_dp = grads(parallel.GradReducer())
+    peers = [torch.zeros_like(got) for _ in range(world)]
+    dist.all_gather(peers, got)
+    err = float((got - want).abs().max() / want.abs().max())
+    differs = float((local - want).abs().max() / want.abs().max())  # the shards are different: local != mean
+
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for _ in range(2):
+        opt.zero_grad()
+        crit(net(x), t).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    drift = 0.0
+    for name, v in net.state_dict().items():
+        if "running_" in name or "num_batches" in name:  # BatchNorm statistics stay per replica (as DataParallel's)
+            continue
+        ref = v.detach().clone()
+        dist.broadcast(ref, src=0)
+        drift = max(drift, float((v.float() - ref.float()).abs().max()))
+    fc_grad = net.resnet.fc.weight.grad is None
+    return {"grad_rel_err": err, "local_vs_mean": differs, "peer_equal": bool(all(torch.equal(p, got) for p in peers)),
+            "replica_drift": drift, "fc_has_no_grad": bool(fc_grad), "loss_local": loss_local, "loss_dp": loss_dp}
+
+
+def main():
+    mode, outdir = sys.argv[1], sys.argv[2]
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    from robosat_amd import parallel
+
+    parallel.init_process_group(world, rank, backend="gloo")
+    if mode == "cpu":
+        res = cpu_logic(rank, world)
+    elif mode == "fail":
+        if rank == 1:
+            sys.exit(3)  # a lost rank: the launcher must stop the survivor (who would wait forever below)
+        dist.barrier()
+        res = {}
+    else:
+        res = gpu_unet(rank, world, torch.bfloat16 if mode == "gpu_bf16" else torch.float32)
+    with open(os.path.join(outdir, "rank{}.json".format(rank)), "w") as fp:
+        json.dump(res, fp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

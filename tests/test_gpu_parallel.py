@@ -1,0 +1,96 @@
+"""The data-parallel path with REAL kernels: two ranks on the ONE MI355X of the test box, started by the product
+launcher, gradients averaged by the gloo backend on the device tensors (RCCL refuses two ranks per device).  What is under
+test is everything but the wire: replica broadcast, ``GradArena`` carving + side-stream ordering + bucket flushes,
+``GradReducer``, the sharded samplers, rank-0 logging / checkpointing, ``rs train`` / ``rs predict`` spawning ranks."""
+
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import synth
+from test_parallel_gloo import run_world2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode", ["gpu_fp32", "gpu_bf16"])
+def test_two_rank_train_step_averages_gradients_and_keeps_replicas_identical(tmp_path, mode):
+    rc, res = run_world2(mode, tmp_path, timeout=900)
+    assert rc == 0, res
+    for r in res:
+        # the same kernels produce the local gradients both times; the only difference is WHO sums them (the reducer's
+        # bucketed in-place all-reduces vs one all-reduce of the concatenation): identical up to nothing
+        assert r["grad_rel_err"] <= 1e-6, r
+        assert r["local_vs_mean"] > 1e-3, r  # the ranks' shards differ, so averaging did something
+        assert r["peer_equal"]
+        assert r["replica_drift"] == 0.0, r
+        assert r["fc_has_no_grad"]
+    assert res[0]["loss_local"] != res[1]["loss_local"]
+
+
+def _rs(args, env_extra, cwd):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, "-m", "robosat_amd.tools"] + args, env=env, cwd=cwd, capture_output=True, text=True,
+                          timeout=900)
+
+
+def test_rs_train_and_predict_spawn_one_process_per_gpu(tmp_path):
+    """A plain ``rs train`` / ``rs predict`` with two devices visible (ROBOSAT_GPUS=2 maps both ranks onto the one GPU of
+    this box) runs two ranks: global batch 4 = 2 tiles per rank, one log, one checkpoint, every tile predicted once and
+    byte-identical to the single-process run."""
+    tmp = str(tmp_path)
+    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=8, n_val=4, size=128, seed=11)
+    ckdir = os.path.join(tmp, "pth")
+    model_toml, ds_toml = synth.write_configs(tmp, ds_root, ckdir, loss="Lovasz", batch_size=4, image_size=128, epochs=1)
+    two = {"ROBOSAT_GPUS": "2", "ROBOSAT_DIST_BACKEND": "gloo"}
+    r = _rs(["train", "--model", model_toml, "--dataset", ds_toml], two, tmp)
+    assert r.returncode == 0, r.stdout + r.stderr
+    log = open(os.path.join(ckdir, "log")).read().splitlines()
+    pat = r"^(Train   |Validate) loss: \d+\.\d{4}, mIoU: (\d\.\d{3}|nan), parking IoU: (\d\.\d{3}|nan), MCC: (-?\d\.\d{3}|nan)$"
+    assert sum(bool(re.match(pat, l)) for l in log) == 2, log  # rank 0 alone logs
+    assert "Batch Size:\t 4" in log
+    ck_path = os.path.join(ckdir, "checkpoint-00001-of-00001.pth")
+    ck = torch.load(ck_path, map_location="cpu")
+    assert int(ck["state_dict"]["module.resnet.bn1.num_batches_tracked"]) == 2  # 8 tiles / GLOBAL batch 4
+    assert len(ck["optimizer"]["state"]) == 168
+
+    tiles_dir = os.path.join(ds_root, "validation", "images")
+    outs = {}
+    for name, env in (("two", two), ("one", {"ROBOSAT_GPUS": "1"})):
+        probs = os.path.join(tmp, "probs_" + name)
+        r = _rs(["predict", "--batch_size", "1", "--checkpoint", ck_path, "--overlap", "32", "--tile_size", "128", "--model", model_toml,
+                 "--dataset", ds_toml, tiles_dir, probs], env, tmp)
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = sorted(os.path.relpath(os.path.join(d, f), probs) for d, _, fs in os.walk(probs) for f in fs)
+        assert len(files) == 4
+        outs[name] = {f: np.array(Image.open(os.path.join(probs, f))) for f in files}
+    assert outs["one"].keys() == outs["two"].keys()
+    for f in outs["one"]:
+        assert np.array_equal(outs["one"][f], outs["two"][f]), f
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(tmp_path):
+    """``python bench.py --gpus 2`` must itself start 2 ranks and report n_gpus = 2 (gloo: both on this box's one GPU)."""
+    env = dict(os.environ)
+    env.update({"ROBOSAT_DIST_BACKEND": "gloo"})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+                        "--size", "128", "--train-batch", "2", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["train"]["value"] > 0 and line["value"] > 0
+    assert "dp2" in line["train"]["config"]["parallelism"]

@@ -1,60 +1,51 @@
-"""N>1 data-parallel path on CPU: world_size-2 gloo processes exercise the flat-arena gradient reducer and the
-tile sharding (one process per GPU in production, RCCL instead of gloo)."""
+"""N>1 data-parallel path on CPU: two gloo ranks started by the product launcher (``robosat_amd.launch.spawn_ranks``,
+the code behind ``rs train`` / ``bench.py --gpus N``) exercise the flat-arena gradient reducer, the replica broadcast
+and the tile sharding (one process per GPU in production, RCCL instead of gloo).  The same two-rank job with REAL
+kernels runs on the GPU box: tests/test_gpu_parallel.py."""
 
+import json
 import os
-import socket
+import sys
 
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "dp_worker.py")
 
 
-def _worker(rank, world, port, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from robosat_amd.parallel import GradReducer, average_scalars, shard_indices, sum_counts
+def run_world2(mode, outdir, timeout=300):
+    from robosat_amd import launch
 
-    red = GradReducer()
-    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)  # the arena
-    red.reduce_async(flat[0:400])  # bucket 1 while "backward" continues
-    red.reduce_async(flat[400:1000])
-    red.wait()
-    want = torch.arange(1000, dtype=torch.float32) * (1 + 2) / 2.0
-    ok = torch.allclose(flat, want)
-    loss = average_scalars([float(rank)], torch.device("cpu"))[0]
-    counts = sum_counts(torch.tensor([1, 2, 3, 4 + rank], dtype=torch.int64))
-    shards = shard_indices(10, 2, rank, world)
-    out.put((rank, ok, loss, counts.tolist(), shards))
-    dist.barrier()
-    dist.destroy_process_group()
+    env = dict(os.environ)
+    env["ROBOSAT_DIST_BACKEND"] = "gloo"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    rc = launch.spawn_ranks([sys.executable, WORKER, mode, str(outdir)], 2, env=env, timeout=timeout)
+    res = []
+    for r in range(2):
+        path = os.path.join(str(outdir), "rank{}.json".format(r))
+        res.append(json.load(open(path)) if os.path.exists(path) else None)
+    return rc, res
 
 
-def test_grad_reducer_and_sharding_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, ok, loss, counts, shards in res:
-        assert ok
-        assert abs(loss - 0.5) < 1e-12
-        assert counts == [2, 4, 6, 9]
-    # 10 samples, batch 2 per rank, 2 ranks -> 2 global batches of 4 (drop_last), split contiguously like DataParallel
-    assert res[0][4] == [[0, 1], [4, 5]] and res[1][4] == [[2, 3], [6, 7]]
+def test_launcher_reducer_broadcast_and_sharding_world2(tmp_path):
+    rc, res = run_world2("cpu", tmp_path)
+    assert rc == 0
+    for rank, r in enumerate(res):
+        assert r["flat_ok"]
+        assert abs(r["loss"] - 0.5) < 1e-12
+        assert r["counts"] == [2, 4, 6, 9]
+        assert r["sums"][0] == r["sums"][1]  # after broadcast_module both replicas hold rank 0's parameters + buffers
+        assert r["running_var"] == [2.0] * 4  # rank 0's running_var (x2), also on rank 1 (which had x3)
+    assert res[0]["before"] != res[1]["before"]  # ... and they really started different
+    # 10 samples, 2 per rank, 2 ranks -> 2 global batches of 4 (drop_last), split contiguously like DataParallel
+    assert res[0]["shards"] == [[0, 1], [4, 5]] and res[1]["shards"] == [[2, 3], [6, 7]]
+    # rs predict: sequential batches of 3 dealt round-robin, every tile exactly once
+    assert res[0]["predict_batches"] == [[0, 1, 2], [6, 7, 8]] and res[1]["predict_batches"] == [[3, 4, 5], [9]]
+
+
+def test_launcher_stops_the_survivors_of_a_failed_rank(tmp_path):
+    rc, res = run_world2("fail", tmp_path, timeout=120)
+    assert rc == 3
+    assert res == [None, None]
 
 
 def test_shard_indices_single_rank_is_reference_order():
@@ -62,3 +53,13 @@ def test_shard_indices_single_rank_is_reference_order():
 
     assert shard_indices(7, 2, 0, 1) == [[0, 1], [2, 3], [4, 5]]  # drop_last=True as the reference loaders
     assert shard_indices(5, 2, 0, 1, epoch_order=[4, 3, 2, 1, 0]) == [[4, 3], [2, 1]]
+
+
+def test_ranks_for_batch_follows_dataparallel_scatter():
+    from robosat_amd.launch import ranks_for_batch
+
+    assert ranks_for_batch(2, 8) == 2    # the reference's default batch_size = 2 keeps two of eight GPUs busy
+    assert ranks_for_batch(32, 8) == 8
+    assert ranks_for_batch(12, 8) == 6
+    assert ranks_for_batch(7, 4) == 1
+    assert ranks_for_batch(16, 1) == 1

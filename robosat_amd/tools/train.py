@@ -100,7 +100,11 @@ def main(args):
     # [model] compute_dtype = "bf16" (extension key; default "fp32" = the parity path) selects the bf16 MFMA kernels
     compute_dtype = model.get("model", {}).get("compute_dtype", "fp32")
     in_channels = int(model.get("model", {}).get("in_channels", 3))  # extension key: 4 = RGB + IR (BASELINE configs[4])
-    net = Replica(UNet(num_classes, compute_dtype=compute_dtype, in_channels=in_channels)).to(device)
+    # The reference always starts from torchvision's ImageNet encoder (unet.py:94).  Without a checkpoint to fine-tune
+    # from, a missing weights file is an error unless `[model] pretrained = false` (extension key) asks for a random one.
+    pretrained = model.get("model", {}).get("pretrained", True)
+    pretrained = False if (args.checkpoint or not pretrained) else "require"
+    net = Replica(UNet(num_classes, pretrained=pretrained, compute_dtype=compute_dtype, in_channels=in_channels)).to(device)
     if world > 1:
         net.module.grad_reducer = parallel.GradReducer()
 

@@ -216,12 +216,31 @@ class UNet(nn.Module):
         if pretrained:
             path = _find_pretrained()
             if path is None:
+                if pretrained == "require":  # `rs train` without a checkpoint: the reference ALWAYS starts from ImageNet weights
+                    raise FileNotFoundError(
+                        "robosat_amd.UNet: no local {} found (set $ROBOSAT_RESNET50_WEIGHTS or put it in torch's checkpoint "
+                        "cache; there is no network to download it), and training from a random encoder was not asked for "
+                        "([model] pretrained = false)".format(_RESNET50_FILE))
                 warnings.warn("robosat_amd.UNet(pretrained=True): no local {} found; encoder stays randomly initialised".format(_RESNET50_FILE))
             else:
-                state = torch.load(path, map_location="cpu")
-                if in_channels != 3:
-                    state.pop("conv1.weight", None)
-                self.resnet.load_state_dict(state, strict=in_channels == 3)
+                self.load_pretrained_encoder(torch.load(path, map_location="cpu"))
+
+    def load_pretrained_encoder(self, state):
+        """Load a torchvision ``resnet50`` state dict into the encoder.  The file torchvision 0.3.0 downloads
+        (resnet50-19c8e357.pth, reference unet.py:94) predates BatchNorm's ``num_batches_tracked`` buffer;
+        ``nn.BatchNorm2d`` tolerates that through its version-2 loading shim, which these parameter holders replicate:
+        the missing counters stay at 0 -- and nothing else may be missing or unexpected."""
+
+        state = dict(state)
+        if self.in_channels != 3:
+            state.pop("conv1.weight", None)  # a 4-band stem keeps its own initialisation
+        result = self.resnet.load_state_dict(state, strict=False)
+        missing = [k for k in result.missing_keys if not k.endswith(".num_batches_tracked")]
+        if self.in_channels != 3:
+            missing = [k for k in missing if k != "conv1.weight"]
+        if missing or result.unexpected_keys:
+            raise RuntimeError("pretrained resnet50 state dict does not fit: missing {}, unexpected {}".format(
+                missing, list(result.unexpected_keys)))
 
     # -- plumbing -----------------------------------------------------------------------------------------------
 

@@ -45,7 +45,8 @@ def write_configs(tmp, dataset_root, checkpoint_dir, loss="Lovasz", batch_size=2
 
     model, ds = os.path.join(tmp, "model.toml"), os.path.join(tmp, "dataset.toml")
     save_config({"common": {"cuda": True, "batch_size": batch_size, "image_size": image_size, "checkpoint": checkpoint_dir},
-                 "opt": {"epochs": epochs, "lr": lr, "loss": loss}}, model)
+                 "opt": {"epochs": epochs, "lr": lr, "loss": loss},
+                 "model": {"pretrained": False}}, model)  # (no ImageNet file in the sandbox: random encoder on request)
     save_config({"common": {"dataset": dataset_root, "classes": ["background", "parking"], "colors": ["denim", "orange"]},
                  "weights": {"values": [1.6248, 5.762827]}}, ds)
     return model, ds

@@ -142,3 +142,34 @@ def test_dispatcher_choices_for_the_benchmark_layers():
     ]
     for args, want in fp32 + bf16:
         assert cfg(*args) == want, (args, cfg(*args), want)
+
+
+def test_pretrained_encoder_loads_a_legacy_torchvision_state_dict(tmp_path, monkeypatch):
+    """resnet50-19c8e357.pth (torchvision 0.3.0's download, reference unet.py:94) has no ``num_batches_tracked`` keys:
+    the encoder must load it like nn.BatchNorm2d's version shim does, find it through $ROBOSAT_RESNET50_WEIGHTS, and a
+    missing file must be an error when the caller requires the ImageNet start (``rs train`` without a checkpoint)."""
+    from robosat_amd.unet import UNet
+
+    ref = R.UNetRef(2)
+    legacy = {k[len("resnet."):]: v.clone() + 0.25 for k, v in ref.state_dict().items()
+              if k.startswith("resnet.") and not k.endswith("num_batches_tracked")}
+    assert len(legacy) == 267 and "fc.weight" in legacy
+    path = tmp_path / "resnet50-19c8e357.pth"
+    torch.save(legacy, str(path))
+    monkeypatch.setenv("ROBOSAT_RESNET50_WEIGHTS", str(path))
+    net = UNet(2, pretrained="require")
+    for k, v in legacy.items():
+        assert torch.equal(net.resnet.state_dict()[k], v), k
+    assert int(net.resnet.bn1.num_batches_tracked) == 0
+    net4 = UNet(2, pretrained=True, in_channels=4)  # 4-band stem: everything but conv1.weight comes from the file
+    assert net4.resnet.conv1.weight.shape == (64, 4, 7, 7) and torch.equal(net4.resnet.layer1[0].conv1.weight, legacy["layer1.0.conv1.weight"])
+    bad = dict(legacy)
+    bad.pop("layer2.0.conv1.weight")
+    with pytest.raises(RuntimeError, match="does not fit"):
+        UNet(2, pretrained=False).load_pretrained_encoder(bad)
+    monkeypatch.setenv("ROBOSAT_RESNET50_WEIGHTS", str(tmp_path / "absent.pth"))
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nohome"))
+    with pytest.raises(FileNotFoundError, match="pretrained = false"):
+        UNet(2, pretrained="require")
+    with pytest.warns(UserWarning):
+        UNet(2, pretrained=True)

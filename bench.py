@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
                     help="compute dtype: fp32 (exact-fp32 MFMA, the parity path; BASELINE configs[1]) or bf16 (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-line comparison of one output tile with the CPU oracle")
     ap.add_argument("--no-train-leg", action="store_true", help="predict phase only: skip the bf16 train leg reported under \"train\"")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU per step of the train leg (configs[2]: 32)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
@@ -124,7 +125,7 @@ def roofline(step):
         achieved = alg_bytes / ms / 1e6
         out.update({"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)})
     out.update({
-        "traffic": pmc_traffic(dom), "launches": launches,
+        "traffic": pmc_traffic(dom), "traffic_source": traffic_source(), "launches": launches,
         # `achieved` (mfma) counts ALGORITHMIC flops (2*N*Cout*Cin*k*k*Ho*Wo on the reference's shapes).  The phase-form
         # decoder kernels execute 4/9 of them (conv3x3 over a nearest-x2 upsample = four 2x2 convolutions with pre-summed
         # taps), so their algorithmic rate can exceed the MFMA peak; `executed` is what the matrix cores actually do.
@@ -150,12 +151,26 @@ def pmc_traffic(kernel):
     passes, corrected as MI355X_MICROARCH.md prescribes) -- profiles/pmc_traffic.json, written by scripts/pmc_summary.py
     from a run of this same command.  None when no counter run has been committed for this kernel."""
 
+    return _pmc_table().get(kernel)
+
+
+def _pmc_table():
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fp:
-            return json.load(fp).get(kernel)
+            return json.load(fp)
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def traffic_source():
+    """Where `roofline.traffic` comes from: the counter passes are separate rocprofv3 runs (a --pmc run cannot share a
+    process with this one), so the number is read from the committed summary; `_meta` there names the commit, the command
+    and the date of the passes (scripts/gpu_round.sh writes it), and is passed through so a reader can tell whether the
+    kernel has changed since."""
+
+    meta = _pmc_table().get("_meta")
+    return {"file": "profiles/pmc_traffic.json", "measured": meta} if meta else {"file": "profiles/pmc_traffic.json", "measured": None}
 
 
 def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
@@ -211,9 +226,33 @@ def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
                 n, size, size, bs, what, best, avail, cands)}
 
 
+def parity_vs_oracle(net, x, classes, got=None):
+    """The in-line output check: probabilities of ONE tile of the benchmark batch from the model the timed loop just ran
+    (``got``: that loop's own last output row when given) against the CPU oracle (oracle/robosat_ref.py) holding the same
+    state dict.  A kernel that wrote zeros -- or anything else -- at the benchmarked shapes shows up here, in the same JSON
+    line as the throughput it would have posted."""
+
+    from oracle import robosat_ref as R
+
+    ref = R.UNetRef(classes)
+    ref.load_state_dict({k: v.detach().float().cpu() for k, v in net.state_dict().items()})
+    ref.eval()
+    was_training = net.training
+    net.eval()
+    try:
+        if got is None:
+            got = net.predict_probs(x[:1])[0]
+    finally:
+        net.train(was_training)
+    want = R.predict_probs(ref, x[:1].float().cpu())[0]
+    got = got.float().cpu()
+    return {"max_abs_vs_oracle": float((got - want).abs().max()), "argmax_agreement": float((got.argmax(0) == want.argmax(0)).float().mean()),
+            "what": "softmax probabilities of tile 0 of the benchmark batch vs oracle/robosat_ref.py (fp32, CPU) on the same weights"}
+
+
 def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
     """Builds the model for `phase`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
-    returns (max-over-ranks seconds, step function)."""
+    returns (max-over-ranks seconds, step function, parity record of rank 0 or None)."""
 
     import torch.distributed as td
 
@@ -257,15 +296,21 @@ def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
         step()
     barrier()
     t0 = time.perf_counter()
+    last = None
     for _ in range(steps):
-        step()
+        last = step()
     barrier()
     el = time.perf_counter() - t0
     if dist:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         el = float(t.item())
-    return el, step
+    parity = None
+    if rank == 0 and not args.no_parity:  # (outside the timed region)
+        parity = parity_vs_oracle(net, x, args.classes, got=None if train else last[0])
+        if train:
+            parity["train_loss_last_step"] = float(last)
+    return el, step, parity
 
 
 def workload(args, phase, dtype, batch, world):
@@ -308,7 +353,7 @@ def main():
             td.barrier()
         ctypes.CDLL(None).fflush(None)
 
-    el, step = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)
+    el, step, parity = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)
     line = None
     # every rank runs the two untimed roofline passes: a train step contains the gradient all-reduce, so rank 0 alone
     # would wait for its peers forever
@@ -323,7 +368,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": workload(args, args.phase, args.dtype, args.batch, world),
-            "roofline": roof,
+            "roofline": roof, "parity": parity,
         }
     del step
     torch.cuda.empty_cache()
@@ -332,18 +377,20 @@ def main():
     # (configs[2]: bf16, bs 32 per GPU, fwd + Lovasz + bwd + RCCL gradient all-reduce + Adam) rides in the same line.
     if args.phase == "predict" and not args.no_train_leg:
         tb, ts, tw = args.train_batch, max(1, min(args.steps, 10)), max(3, min(args.warmup, 5))
-        tel, tstep = run_phase(args, "train", "bf16", tb, ts, tw, device, dist, rank)
+        tel, tstep, tparity = run_phase(args, "train", "bf16", tb, ts, tw, device, dist, rank)
         troof, _ = roofline(tstep)
         if rank == 0:
             line["train"] = {"value": round(world * tb * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
                              "ms_per_step": round(tel / ts * 1e3, 3), "dtype": "bf16", "scaling": "weak",
-                             "config": workload(args, "train", "bf16", tb, world), "roofline": troof}
+                             "config": workload(args, "train", "bf16", tb, world), "roofline": troof, "parity": tparity}
         del tstep
         torch.cuda.empty_cache()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds, args.phase, args.loss)
+            if "train" in line:  # the train leg's own CPU number (the oracle's fwd + Lovasz + bwd + Adam), shorter sample
+                line["train"]["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds * 0.7, "train", args.loss)
     if dist:
         import ctypes
 

@@ -207,6 +207,12 @@ int rs_conv2d_tile_bf16(const rs_conv_desc* d);
 /* Tile index (rs_conv2d_tile_name order) and K-chunk row size (64 | 128 bytes) the dispatcher picks for `d` with `es`-byte
  * activations, direct (phase4 = 0) or phase form: kernel names in reports then map 1:1 to the launched symbols. */
 int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* rowb);
+/* Dispatcher override for the parity tests and A/B measurements (process-global; not a tuning API for callers): force the
+ * tile (index as above; honoured for every launch that tile can run, -1 = the measured heuristics) and the K-chunk row
+ * size (64 | 128; 0 = heuristics).  rs_conv2d_config reports what a launch will then use, so a test can assert that the
+ * symbol it means to cover is the one that ran.  The reference has no counterpart: cuDNN's autotuner
+ * (torch.backends.cudnn.benchmark, tools/train.py:72-73) is its equivalent of the heuristics this overrides. */
+int rs_conv2d_set_tuning(int tile, int rowb);
 const char* rs_conv2d_tile_name_bf16(int tile);
 
 /* rs_conv2d_wgrad with bf16 dy / sources; dw is fp32 KRSC (the optimizer's master gradient). */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 12
+ABI_VERSION = 13
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "rs_conv2d_fwd_bf16": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     "rs_conv2d_tile_bf16": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_config": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "rs_conv2d_set_tuning": (c_int, [c_int, c_int]),
     "rs_conv2d_tile_name_bf16": (c_char_p, [c_int]),
     "rs_conv2d_wgrad_bf16_workspace_bytes": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_wgrad_bf16_form": (c_int, [POINTER(ConvDesc)]),

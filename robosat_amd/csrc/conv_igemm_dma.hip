@@ -62,7 +62,7 @@ struct ConvArgsT {
   int csplit;
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
-  int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4, direct;
+  int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -123,26 +123,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_make_rsrc(const void* base,
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
 }
 
-// One LDS-DMA wave instruction (buffer_load_dwordx4 ... lds): lane l's 16 bytes at buffer offset `voff` land at LDS byte
-// `lds_dst` + 16*l (lds_dst wave-uniform, in M0); offset -1 is out of range => zeros (scripts/probes/probe_glds.hip).
+// One LDS-DMA wave instruction (buffer_load_dwordx4 ... lds): lane l's 16 bytes at buffer offset `voff` + `soff` land at
+// LDS byte `lds_dst` + 16*l (lds_dst wave-uniform, in M0); an out-of-range offset => zeros (scripts/probes/probe_glds.hip).
 // Inline asm on purpose: through the builtin hipcc cannot tell that the DMA's destination (the OTHER pipeline buffer) is
 // disjoint from the fragment reads that follow and drains the queue (s_waitcnt vmcnt(0)) before the first ds_read of
 // every chunk.  As asm the copy is invisible to its counters, so the kernel waits itself (rb_dma_wait) ahead of the
 // barrier that publishes the buffer.
-__device__ __forceinline__ void rb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int lds_dst, int voff) {
-  unsigned int keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(lds_dst), "s"(r)
-      : "memory");
-}
-
-// The same with a wave-uniform byte offset `soff` added to the address (the SOFFSET operand): the per-lane offsets of a
+// `soff` is a wave-uniform byte offset added to the address (the SOFFSET operand): the per-lane offsets of a
 // (tap, source) stay in registers and the K loop advances through the channels with one SGPR.  kDmaOOB + soff is out of
 // range for every rsrc rb_make_rsrc builds (zeros land in the LDS): the per-lane offset of a padding / past-the-end row.
 // m0 is declared clobbered rather than saved and restored (two SALU per piece, eight pieces per chunk per wave): the
@@ -159,32 +146,19 @@ __device__ __forceinline__ void rb_dma16s(__amdgpu_buffer_rsrc_t r, unsigned int
       : "memory", "m0");
 }
 
-// A bare s_barrier that hipcc may not move LDS accesses across (the builtin is IntrNoMem) and that carries no fence: a
-// fence would drain the LDS-DMAs in flight (they count on vmcnt).
-__device__ __forceinline__ void rb_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
 __device__ __forceinline__ void rb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <int N>
-__device__ __forceinline__ void rb_dma_wait_n() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
   return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
 constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 data gradient of an upsampled 3x3)
 
-// DBG (measurement builds only, RS_CONV_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = MFMAs on
-// the first chunk's fragments only (no LDS reads in the loop): the three legs of the main loop, timed apart.
-// STAG (8 waves, 64-byte rows, 4 buffers): the two wave groups {0-3} / {4-7} -- one wave of each per SIMD -- run half a chunk
-// apart, so one group's MFMAs cover the other's barrier, fragment reads and DMA issue (see the schedule at the loop).
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int NBUF = 2, int DBG = 0, bool STAG = false>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_igemm_dma(const ConvArgsT<T> p) {
-  static_assert(!STAG || (WGM * WGN == 8 && ROWB == 64 && NBUF == 4 && DBG == 0), "staggered schedule: 8 waves, 2 k-steps per chunk, 4 buffers");
-  static_assert(NBUF >= 2 && NBUF <= 4, "2..4 pipeline buffers");
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 && 2 * (BM + BN) * ROWB <= 80 * 1024) ? 2 : 1) void conv_igemm_dma(
+    const ConvArgsT<T> p) {
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
   static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
+  constexpr int NBUF = 2;  // pipeline buffers (3 and 4 with counted vmcnt waits were measured: no gain)
   constexpr int NW = WGM * WGN;  // waves; the 8-wave blocks (256- and 512-row tiles) run one per CU
   constexpr int NT = 64 * NW;
   constexpr int ES = (int)sizeof(T);  // element size
@@ -204,7 +178,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_i
   constexpr int TABN = (2 * kMaxK + 1) * BM;  // separable gather table (tap row | tap column) x tile row + output rows
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
   static_assert((IA % NW) == 0 && IB >= 1 && (BM % RI) == 0 && (BN % RI) == 0, "DMA instruction split");
-  static_assert(NBUF == 2 || ((IA + IB) % NW) == 0, "counted vmcnt waits need the same DMA count in every wave");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAINB + TABN * 4];
   int* taby = reinterpret_cast<int*>(smem + MAINB);  // [kh][BM]: ((n - nfirst)*Hs + iy) * Ws, or -1
@@ -354,58 +327,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_i
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(L + bbase + 32 * tn * ROWB + foff[s]);
   };
-  // ---- main loop: the chunks k+1 .. k+NBUF-1 stream HBM -> LDS by DMA while the MFMAs of chunk k run; one barrier per
-  //      chunk.  Each wave first waits for ITS OWN DMA instructions of chunk k with a COUNTED s_waitcnt (loads complete in
-  //      order: allowing NI*(chunks still in flight) outstanding == chunk k has landed), the barrier publishes everybody's,
-  //      and only then the buffer freed by chunk k-1 is refilled.  With three buffers a chunk has two iterations to land:
-  //      the short-K encoder layers, whose iteration is one DMA round trip and 8 MFMAs long, run ~1.5x faster per block.
-  constexpr int AHEAD = STAG ? NBUF - 2 : NBUF - 1;
+  // ---- main loop: chunk k+1 streams HBM -> LDS by DMA while the MFMAs of chunk k run; one barrier per chunk.  Each wave
+  //      first waits for ITS OWN DMA instructions of chunk k, the barrier publishes everybody's, and only then the buffer
+  //      freed by chunk k-1 is refilled.
+  if (p.nk > 0) {
+    begin_chunk(0);
 #pragma unroll
-  for (int j = 0; j < AHEAD; ++j)
-    if (j < p.nk) {
-      begin_chunk(j);
-#pragma unroll
-      for (int q = 0; q < NI; ++q) issue_piece(q);
-    }
-  // The pieces of chunk kc+AHEAD are issued BETWEEN the MFMAs of chunk kc (one piece every PSTEP MFMAs from the start
-  // of the chunk): an LDS-DMA instruction costs the issuing wave 60-180 cycles, which a burst at the top of the chunk
-  // would add to the critical path of every wave of the block at once.
+    for (int q = 0; q < NI; ++q) issue_piece(q);
+  }
+  // The pieces of chunk kc+1 are issued BETWEEN the MFMAs of chunk kc (one piece every PSTEP MFMAs from the start of the
+  // chunk): an LDS-DMA instruction costs the issuing wave 60-180 cycles, which a burst at the top of the chunk would add
+  // to the critical path of every wave of the block at once.
   constexpr int NMMA = KS * TM * TN;
   constexpr int PSTEP = NMMA / (2 * NI) >= 1 ? NMMA / (2 * NI) : 1;  // front-loaded: the tail of the chunk covers the latency
   constexpr int PIN = (NMMA + PSTEP - 1) / PSTEP < NI ? (NMMA + PSTEP - 1) / PSTEP : NI;  // pieces placed between MFMAs
-  // One chunk: wait for it, publish it, then its MFMAs -- with the pieces of chunk kc+AHEAD in between when FETCH.  Two
-  // loops (steady state with FETCH, then the last AHEAD chunks without) rather than a branch per piece: a diamond inside
-  // one loop made hipcc keep the 64 accumulator registers of the two arms apart (64 v_mov per chunk).
+  // One chunk: wait for it, publish it, then its MFMAs -- with the pieces of chunk kc+1 in between when FETCH.  Two loops
+  // (steady state with FETCH, then the last chunk without) rather than a branch per piece: a diamond inside one loop
+  // made hipcc keep the 64 accumulator registers of the two arms apart (64 v_mov per chunk).
   auto chunk = [&](int kc, auto fetch_tag) __attribute__((always_inline)) {
     constexpr bool FETCH = decltype(fetch_tag)::value;
-    {  // chunks kc+1 .. kc+NBUF-2 may stay in flight (fewer at the tail of the loop)
-      const int fly = p.nk - 1 - kc;
-      if (NBUF >= 4 && fly >= 2) rb_dma_wait_n<2 * NI>();
-      else if (NBUF >= 3 && fly >= 1) rb_dma_wait_n<NI>();
-      else rb_dma_wait();
-    }
+    rb_dma_wait();
     __syncthreads();
-    if (FETCH) begin_chunk((kc + AHEAD) % NBUF);  // refills the buffer chunk kc-1 was read from
-    if (DBG & 2) {
-      if (FETCH) {
-#pragma unroll
-        for (int q = 0; q < NI; ++q) issue_piece(q);
-      }
-      return;
-    }
-    const unsigned char* L = smem + ((DBG & 4) ? 0 : (kc % NBUF)) * BUF;
+    if (FETCH) begin_chunk((kc + 1) % NBUF);  // refills the buffer chunk kc-1 was read from
+    const unsigned char* L = smem + (kc % NBUF) * BUF;
     u32x4 fa[2][TM], fb[2][TN];
     read_frag(L, 0, fa[0], fb[0]);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS && !(DBG & 4)) read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      if (s + 1 < KS) read_frag(L, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           const int q = (s * TM + tm) * TN + tn;  // MFMA index within the chunk (compile-time after unrolling)
           if (FETCH && q % PSTEP == 0 && q / PSTEP < PIN) issue_piece(q / PSTEP);
-          mma16(acc[tn][tm], fb[(DBG & 4) ? 0 : (s & 1)][tn], fa[(DBG & 4) ? 0 : (s & 1)][tm], T());
+          mma16(acc[tn][tm], fb[s & 1][tn], fa[s & 1][tm], T());
         }
     }
     if (FETCH) {
@@ -413,121 +369,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 4 ? 2 : 1) void conv_i
       for (int q = PIN; q < NI; ++q) issue_piece(q);  // (tiles with fewer MFMAs per chunk than pieces)
     }
   };
-  const int nfetch = (DBG & 1) ? 0 : (p.nk - AHEAD > 0 ? p.nk - AHEAD : 0);
-  if constexpr (STAG) {
-    // Global barrier sequence: group A executes S_0 M_0 S_1 M_1 ... S_{n-1} M_{n-1} E, group B executes X S_0 M_0 ...
-    // M_{n-1}: B's S_c is A's M_c, B's M_c is A's S_{c+1} -- B runs one k-step (half a chunk) behind A.  Per chunk c each
-    // group: S_c, k-step 0, M_c, k-step 1.  Chunk c+2 is fetched (4 buffers) by A during its k-step 0 of c and by B during
-    // its k-step 1 of c: both after the last reader of that buffer's previous chunk c-2 (B's k-step 1, which ends at B's
-    // S_{c-1} = A's M_{c-1}).  A chunk is read only after a barrier that every wave reached AFTER waiting for its own
-    // pieces of it: A waits for chunk c ahead of S_c, B for chunk c+1 ahead of its M_c (= A's S_{c+1}).
-    auto kstep = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN], auto fetch_tag) __attribute__((always_inline)) {
-      constexpr bool FETCH = decltype(fetch_tag)::value;
-      constexpr int NM = TM * TN;
-      constexpr int PS = NM / NI >= 1 ? NM / NI : 1;
-      if (p.direct & 2) __builtin_amdgcn_s_setprio(1);  // (experiment: RS_CONV_STAG=2) favour the group that is in its MFMAs
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int q = tm * TN + tn;
-          if (FETCH && q % PS == 0 && q / PS < NI) issue_piece(q / PS);
-          mma16(acc[tn][tm], fb[tn], fa[tm], T());
-        }
-      if (FETCH) {
-#pragma unroll
-        for (int q = (NM + PS - 1) / PS; q < NI; ++q) issue_piece(q);
-      }
-      if (p.direct & 2) __builtin_amdgcn_s_setprio(0);
-    };
-    const int grp = wave >> 2;  // (wave-uniform)
-    if (grp == 0) {
-      auto chunk_a = [&](int kc, auto fetch_tag) __attribute__((always_inline)) {
-        if (kc + 1 < p.nk) rb_dma_wait_n<NI>();  // chunk kc landed (own pieces); kc+1's may still fly
-        else rb_dma_wait();
-        rb_barrier();  // S_kc
-        if (decltype(fetch_tag)::value) begin_chunk((kc + AHEAD) % NBUF);
-        const unsigned char* L = smem + (kc % NBUF) * BUF;
-        u32x4 fa[2][TM], fb[2][TN];
-        read_frag(L, 0, fa[0], fb[0]);
-        read_frag(L, 1, fa[1], fb[1]);
-        kstep(fa[0], fb[0], fetch_tag);
-        rb_barrier();  // M_kc
-        kstep(fa[1], fb[1], std::false_type());
-      };
-      int kc = 0;
-      for (; kc < nfetch; ++kc) chunk_a(kc, std::true_type());
-      for (; kc < p.nk; ++kc) chunk_a(kc, std::false_type());
-      rb_barrier();  // E (pairs with B's M_{n-1})
-    } else {
-      if (p.nk > 1) rb_dma_wait_n<NI>();  // chunk 0 landed before X = A's S_0
-      else rb_dma_wait();
-      rb_barrier();  // X
-      auto chunk_b = [&](int kc, auto fetch_tag) __attribute__((always_inline)) {
-        rb_barrier();  // S_kc
-        const unsigned char* L = smem + (kc % NBUF) * BUF;
-        u32x4 fa[2][TM], fb[2][TN];
-        read_frag(L, 0, fa[0], fb[0]);
-        read_frag(L, 1, fa[1], fb[1]);
-        kstep(fa[0], fb[0], std::false_type());
-        rb_dma_wait();  // own pieces of chunk kc+1 (everything this wave has issued so far) before A reads it
-        rb_barrier();  // M_kc
-        if (decltype(fetch_tag)::value) begin_chunk((kc + AHEAD) % NBUF);
-        kstep(fa[1], fb[1], fetch_tag);
-      };
-      int kc = 0;
-      for (; kc < nfetch; ++kc) chunk_b(kc, std::true_type());
-      for (; kc < p.nk; ++kc) chunk_b(kc, std::false_type());
-    }
-  } else {
+  {
     int kc = 0;
-    for (; kc < nfetch; ++kc) chunk(kc, std::true_type());
+    for (; kc < p.nk - 1; ++kc) chunk(kc, std::true_type());
     for (; kc < p.nk; ++kc) chunk(kc, std::false_type());
   }
   __syncthreads();  // every wave is done with the pipeline buffers: the epilogue stages through them
-
-  // ---- direct epilogue (p.direct; no BatchNorm statistics): D[i = cout][j = pixel] puts 4 consecutive couts of one pixel
-  //      in registers 4g..4g+3, so a lane can apply the epilogue and store them itself (16 bytes fp32 / 8 bytes bf16; the
-  //      two half-waves fill 32 / 16 contiguous bytes per pixel row and L2 merges the rows across g, tn) -- no LDS round
-  //      trip, no barrier.  Which of the two wins is shape dependent (measured; see pick_direct).
-  if (p.direct & 1) {
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int opix = orow[wm * WM + 32 * tm + (lane & 31)];
-      if (opix < 0) continue;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c0 = n0 + wn * WN + 32 * tn + 8 * g + 4 * hh;
-          if (c0 >= p.Cout) continue;  // ragged last N tile
-          const long o = (long)opix * p.Cout + c0;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = acc[tn][tm][4 * g + e];
-            v[e] = a * (p.scale ? p.scale[c0 + e] : 1.f) + (p.shift ? p.shift[c0 + e] : 0.f);
-          }
-          if (p.res) {
-            const f32x4 r = rs_ld4(p.res + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
-          }
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (p.mask) {
-            const f32x4 z = rs_ld4(p.mask + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
-          }
-          rs_st4(p.out + o, v);
-        }
-    }
-    return;
-  }
 
   // ---- epilogue: registers -> LDS [pixel][cout] fp32 -> one 16-byte piece of couts per thread, row-wise stores.
   //      TM passes of WGM*32 rows each (pass t = sub-tile tm = t of every wave) keep the staging tile at
@@ -724,13 +571,34 @@ extern "C" int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int to
 }
 
 // (index 4 is the fp32 stem kernel of conv_igemm.hip: the two files share the index space of rs_conv2d_tile_name)
-// T256x256 / T512x128: 8-wave blocks, one per CU, bf16 only (see pick_tile)
-enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, T512x128, NTILES };
+// T256x256: 8-wave blocks, one per CU, bf16 only (see pick_tile); T256x128: 4 waves with 128x64 wave tiles
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, NTILES };
 const char* const kTileNamesBf16[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
                                             "conv_igemm_bf16<64x64>", "", "conv_igemm_bf16<256x128>",
-                                            "conv_igemm_bf16<256x256>", "conv_igemm_bf16<512x128>"};
-const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 512};
-const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 128};
+                                            "conv_igemm_bf16<256x256>"};
+const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256};
+const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256};
+
+// Dispatcher overrides (rs_conv2d_set_tuning): process-global, for the parity tests (which must reach every tile with
+// small problems) and for A/B measurements.  -1 / 0 = the measured heuristics below.  Initialised from the environment
+// (RS_CONV_TILE, RS_CONV_ROWB, RS_CONV_BIG) so that a whole benchmark run can be steered from outside.
+struct Tuning {
+  int tile = -1;  // forced tile index, honoured whenever the launch can run it
+  int rowb = 0;   // forced K-chunk row bytes: 64 | 128
+  int big = 1;    // 8-wave 256x256 tile allowed (bf16, no fused statistics)
+  int min256 = 384;  // ... for launches with at least this many 256x256 blocks
+};
+Tuning& tuning() {
+  static Tuning t = [] {
+    Tuning v;
+    if (const char* e = getenv("RS_CONV_TILE")) v.tile = atoi(e);
+    if (const char* e = getenv("RS_CONV_ROWB")) v.rowb = atoi(e);
+    if (const char* e = getenv("RS_CONV_BIG")) v.big = atoi(e);
+    if (const char* e = getenv("RS_CONV_MIN256")) v.min256 = atoi(e);
+    return v;
+  }();
+  return t;
+}
 
 bool valid(const rs_conv_desc* d) {
   if (!d) return false;
@@ -749,40 +617,28 @@ bool phase_ok(const rs_conv_desc* d) {
 int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats = false) {
   const long M = phase4 ? (long)d->N * d->Hs * d->Ws * 4 : (long)d->N * d->Ho * d->Wo;  // (x4: the phases share the grid)
   const long want = 512;  // >= 2 blocks per CU
-  static const int forced_tile = [] {  // RS_CONV_TILE=0..3 (128x128, 128x64, 128x32, 64x64): measurement knob
-    const char* e = getenv("RS_CONV_TILE");
-    return e ? atoi(e) : -1;
-  }();
-  if (forced_tile >= 0 && forced_tile < NTILES && forced_tile != TSTEM_RESERVED && d->Cout % kTileBN[forced_tile] == 0 &&
-      (forced_tile < T256x256 || (es == 2 && !stats)))
-    return forced_tile;
-  // 8-wave tiles (bf16, no fused statistics; one block per CU): half the LDS-DMA bytes per MFMA of the 128x128 tile,
+  const Tuning& tu = tuning();
+  const int ft = tu.tile;
+  // a forced tile must be able to run the launch: N tiles whole (or the ragged 128-wide form below), 8 waves only in bf16
+  // without fused statistics (the statistics' block reduction is laid out for 256 threads)
+  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
+      (ft != T256x256 || (es == 2 && !stats)))
+    return ft;
+  // 8-wave 256x256 tile (bf16, no fused statistics; one block per CU): half the LDS-DMA bytes per MFMA of the 128x128 tile,
   // which is what bounds that tile (~23 B/clk/CU of DMA = ~900 TFLOP/s at 64 flop/B).  Measured per layer (bs 32):
-  // 256x256 +21 % on 256->256 3x3 at 64^2 (512 blocks, 1071 vs 882 TFLOP/s) but -30 % with 128 blocks; 512x128 +3..6 % on
-  // the N = 128 layers (within run-to-run noise: off by default).  On the whole bf16 train step either is a wash
-  // (29.3 ms with and without): few launches qualify.  RS_CONV_BIG = bit 0: 256x256, bit 1: 512x128 (A/B knob).
-  static const int big = [] {  // bit 0: 256x256, bit 1: 512x128
-    const char* e = getenv("RS_CONV_BIG");
-    return e ? atoi(e) : 1;
-  }();
-  if (big && es == 2 && !stats) {
+  // +21 % on 256->256 3x3 at 64^2 (512 blocks, 1071 vs 882 TFLOP/s) but -30 % with 128 blocks.
+  if (tu.big && es == 2 && !stats) {
     const long mrows = phase4 ? (long)d->N * d->Hs * d->Ws : M;  // rows per launch grid slice (each phase tiles its own)
     const long nph = phase4 ? 4 : 1;
     const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
     // (short-K launches are DMA-latency / HBM bound: there the 256-row tile ties the 128x128 one at best)
-    if ((big & 1) && d->Cout % 256 == 0 && nk128 >= 32 && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= 384) return T256x256;
-    const bool n128 = d->Cout % 128 == 0 || (d->Cout > 128 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5);
-    if ((big & 2) && n128 && rs_cdiv(mrows, 512) * rs_cdiv(d->Cout, 128) * nph >= 512) return T512x128;
+    if (d->Cout % 256 == 0 && nk128 >= 32 && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= tu.min256) return T256x256;
   }
   if (d->Cout % 128 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 128) >= want) return T128x128;
   // ragged last N tile (weight rows past Cout read as zeros through the buffer bound, the epilogue skips their columns):
   // worth it when <= 1/5 of the MFMAs are padding -- Cout = 320, the data gradient of the 256 + 64 concat, runs the
-  // 128x128 tile's 2x higher MFMA : LDS-read ratio instead of five 128x64 tiles.  RS_CONV_RAGGED=0 disables (A/B knob).
-  static const bool ragged = [] {
-    const char* e = getenv("RS_CONV_RAGGED");
-    return !e || atoi(e) != 0;
-  }();
-  if (ragged && d->Cout > 128 && d->Cout % 128 != 0 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5 &&
+  // 128x128 tile's 2x higher MFMA : LDS-read ratio instead of five 128x64 tiles.
+  if (d->Cout > 128 && d->Cout % 128 != 0 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5 &&
       (long)rs_cdiv(M, 128) * rs_cdiv(d->Cout, 128) >= want)
     return T128x128;
   if (d->Cout % 64 == 0) {
@@ -793,12 +649,9 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats
 }
 
 // 128-byte rows (4 k-steps per barrier, 2 blocks per CU) or 64-byte rows (2 k-steps per barrier, 4 blocks per CU)?
-// RS_CONV_ROWB=64|128 overrides (measurement knob).
+// rs_conv2d_set_tuning / RS_CONV_ROWB=64|128 overrides.
 int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false, bool stats = false) {
-  static const int forced = [] {
-    const char* e = getenv("RS_CONV_ROWB");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = tuning().rowb;
   // Measured per layer with both row sizes forced, on both paths (bs-32 bf16 train, bs-16 fp32 predict; after the DMA
   // pieces moved between the MFMAs).  64-byte rows = half the LDS per block, twice the blocks per CU, a barrier every 2
   // k-steps: they win on short K loops (the 1x1 convolutions of the encoder: 25-37 % at nk128 <= 8, where a block is
@@ -806,7 +659,6 @@ int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false, bool stats = f
   // 128-byte rows win on long K (20-40 % on layer3/4's 3x3 and the decoder's phase / 4x4 forms in bf16).  fp32: the
   // 64-cycle MFMAs hide the extra barriers, 64-byte rows tie or win up to nk128 = 16 and whenever the grid is large.
   const int tile = pick_tile(d, phase4, es, stats);
-  if (tile == T512x128) return 64;  // (512 + 128) rows x 128 bytes x 2 buffers would not fit the LDS
   if (forced == 64 || forced == 128) return forced;
   const long blocks = (long)rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[tile]) * rs_cdiv(d->Cout, kTileBN[tile]);
   const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
@@ -821,66 +673,9 @@ int pick_rowb(const rs_conv_desc* d, int es, bool phase4 = false, bool stats = f
 template <typename T, int ROWB, bool PHASE>
 void launch(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
   if constexpr (sizeof(T) == 2) {
-    if (tile == T256x256 || tile == T512x128) {  // 8 waves, 1 block per CU; RS_CONV_NBUF overrides the pipeline depth
-      static const int nb = [] {
-        const char* e = getenv("RS_CONV_NBUF");
-        return e ? atoi(e) : 0;
-      }();
-      if (tile == T256x256) {
-        if constexpr (ROWB == 128) {
-          conv_igemm_dma<T, 256, 256, 2, 4, 128, PHASE, 2><<<grid, 512, 0, s>>>(a);
-        } else {
-          static const int stag = [] {
-            const char* e = getenv("RS_CONV_STAG");
-            return e ? atoi(e) : 0;
-          }();
-          if (stag) {
-            ConvArgsT<T> b = a;
-            b.direct = stag == 2 ? 2 : 0;  // (bit 1 = s_setprio around the MFMA clusters; the direct epilogue is off here)
-            conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 4, 0, true><<<grid, 512, 0, s>>>(b);
-          }
-          else if (nb == 2) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 2><<<grid, 512, 0, s>>>(a);
-          else if (nb == 3) conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 3><<<grid, 512, 0, s>>>(a);
-          else conv_igemm_dma<T, 256, 256, 2, 4, 64, PHASE, 4><<<grid, 512, 0, s>>>(a);
-        }
-      } else {
-        if constexpr (ROWB == 64) {
-          if (nb == 2) conv_igemm_dma<T, 512, 128, 4, 2, 64, PHASE, 2><<<grid, 512, 0, s>>>(a);
-          else conv_igemm_dma<T, 512, 128, 4, 2, 64, PHASE, 3><<<grid, 512, 0, s>>>(a);
-        }
-      }
+    if (tile == T256x256) {  // 8 waves, 1 block per CU
+      conv_igemm_dma<T, 256, 256, 2, 4, ROWB, PHASE><<<grid, 512, 0, s>>>(a);
       return;
-    }
-  }
-  // RS_CONV_NBUF=3 (measurement knob): three pipeline buffers with counted vmcnt waits for the 64-byte-row kernels (two
-  // chunks in flight per block, but 3 instead of 4 blocks per CU).  Measured per layer on both paths: a wash to slightly
-  // slower (fp32 predict 14.48 -> 14.79 ms of convolutions, bf16 train 17.5 -> 18.0) -- occupancy hides the DMA round trip
-  // better than depth here -- so two buffers stay the default.
-  static const int nbuf3 = [] {
-    const char* e = getenv("RS_CONV_NBUF");
-    return e && atoi(e) == 3;
-  }();
-  if (ROWB == 64 && nbuf3 && tile != T128x32) {
-    switch (tile) {
-      case T128x128: conv_igemm_dma<T, 128, 128, 2, 2, 64, PHASE, 3><<<grid, 256, 0, s>>>(a); break;
-      case T128x64: conv_igemm_dma<T, 128, 64, 2, 2, 64, PHASE, 3><<<grid, 256, 0, s>>>(a); break;
-      default: conv_igemm_dma<T, 64, 64, 2, 2, 64, PHASE, 3><<<grid, 256, 0, s>>>(a); break;
-    }
-    return;
-  }
-  if constexpr (sizeof(T) == 2 && !PHASE) {
-    static const int dbg = [] {
-      const char* e = getenv("RS_CONV_DBG");
-      return e ? atoi(e) : 0;
-    }();
-    if (dbg && tile == T128x128) {
-      switch (dbg) {
-        case 1: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 1><<<grid, 256, 0, s>>>(a); return;
-        case 2: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 2><<<grid, 256, 0, s>>>(a); return;
-        case 4: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 4><<<grid, 256, 0, s>>>(a); return;
-        case 5: conv_igemm_dma<T, 128, 128, 2, 2, ROWB, PHASE, 2, 5><<<grid, 256, 0, s>>>(a); return;
-        default: break;
-      }
     }
   }
   switch (tile) {
@@ -925,13 +720,6 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.C1 = d->C1;
   a.C2 = d->C2;
   a.phase4 = phase4 ? 1 : 0;
-  {
-    static const int forced = [] {  // RS_CONV_DIRECT=0|1 overrides (measurement knob)
-      const char* e = getenv("RS_CONV_DIRECT");
-      return e ? atoi(e) : -1;
-    }();
-    a.direct = (forced >= 0 ? forced != 0 : false) && !stats;
-  }
   a.ups = phase4 ? 0 : d->ups;  // phase mode gathers on the source grid itself
   a.Hv = a.ups == 0 ? d->Hs : (a.ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
   a.Wv = a.ups == 0 ? d->Ws : (a.ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
@@ -967,7 +755,6 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
 
   const int tile = pick_tile(d, phase4, (int)ES, stats != nullptr);
   if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
-  a.direct = a.direct && !out2;
   a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
   hipStream_t s = (hipStream_t)stream;
@@ -990,6 +777,13 @@ int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2,
 }
 
 int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
+
+extern "C" int rs_conv2d_set_tuning(int tile, int rowb) {
+  if (tile < -1 || tile >= NTILES || tile == TSTEM_RESERVED || (rowb != 0 && rowb != 64 && rowb != 128)) return RS_EINVAL;
+  tuning().tile = tile;
+  tuning().rowb = rowb;
+  return 0;
+}
 
 // For the roofline report (kernel names that map 1:1 to the launched symbol): tile index and K-chunk row bytes the
 // dispatcher picks for `d` with activations of `es` bytes, in the direct (phase4 = 0) or phase form.

@@ -326,6 +326,27 @@ def conv_tile_name(d, bf16=False, phase=False):
     return base.replace("<", "<phase," if phase else "<").replace(">", ",r{}>".format(rowb.value))
 
 
+TILES = {"128x128": 0, "128x64": 1, "128x32": 2, "64x64": 3, "256x128": 5, "256x256": 6}
+
+
+class tuning:
+    """``with ops.tuning(tile="256x256", rowb=128): ...`` -- force the convolution dispatcher (``rs_conv2d_set_tuning``) for
+    the launches inside: the parity tests use it to reach every kernel symbol with small problems, the layer benchmarks
+    for A/B runs.  Process-global; restores the measured heuristics on exit."""
+
+    def __init__(self, tile=None, rowb=0):
+        self.tile = -1 if tile is None else (TILES[tile] if isinstance(tile, str) else int(tile))
+        self.rowb = int(rowb)
+
+    def __enter__(self):
+        check(_lib.lib().rs_conv2d_set_tuning(self.tile, self.rowb), "rs_conv2d_set_tuning")
+        return self
+
+    def __exit__(self, *exc):
+        check(_lib.lib().rs_conv2d_set_tuning(-1, 0), "rs_conv2d_set_tuning")
+        return False
+
+
 def cast_bf16(t):
     """fp32 -> bf16 copy (round to nearest even); used for the per-step compute copies of the fp32 master weights."""
 

@@ -1,4 +1,12 @@
-"""The remaining BASELINE.json configurations on the MI355X, through the public operator surface:
+"""The BASELINE.json configurations on the MI355X at their FULL sizes, through the public operator
+surface -- tile and row-size dispatch depends on M and the grid, so "same kernels as the small tests" is checked, not
+inferred:
+
+  configs[1]  rs predict bs 16, 3x512x512 fp32 (the headline benchmark shape) -> oracle parity on two of the 16 tiles
+              (<= 1e-3) and bit-for-bit batch independence;
+  configs[2]  rs train bf16 bs 32, 3x512x512 (the train leg's shape) -> one full training step against the fp32 CPU
+              oracle on the same seeded weights / batch: loss within 2 %, decoder + head gradients cosine >= 0.98, every
+              gradient finite, mean cosine over all 168 tensors reported and held to >= 0.90;
 
   configs[3]  rs predict 1024x1024 3-band tiles, bs 8, fp32      -> oracle parity on one 1024^2 tile (the CPU oracle needs
               ~15 s per such tile) + the size-independent property that a tile's probabilities do not depend on its
@@ -91,3 +99,65 @@ def test_cfg5_four_band_four_class_lovasz_train_step():
     for name, p in nb.named_parameters():
         if rp[name].grad is not None:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+
+
+def test_cfg2_predict_bs16_512_fp32_headline_shape():
+    ref, net = _pair(2, 31)
+    ref.eval()
+    net.eval()
+    x = seeded.synthetic_images(16, 3, 512, 512, seed=12)
+    got = net.predict_probs(x.to(DEV))
+    assert got.shape == (16, 2, 512, 512) and got.dtype == torch.float32
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    for i in (0, 15):
+        want = R.predict_probs(ref, x[i:i + 1])
+        err = float((got[i:i + 1].cpu() - want).abs().max())
+        print("cfg2 bs16 512^2 tile", i, "max|dprob| vs oracle", err)
+        assert err <= 1e-3  # north_star tolerance (fp32)
+    pair = net.predict_probs(x[[5, 9]].to(DEV))  # same numbers whether a tile travels in a batch of 2 or of 16
+    assert torch.equal(pair[0], got[5]) and torch.equal(pair[1], got[9])
+    assert float((got.sum(1) - 1).abs().max()) <= 1e-5
+
+
+def test_cfg3_train_bs32_512_bf16_step_vs_oracle():
+    from robosat_amd import losses
+
+    n, size = 32, 512
+    x = seeded.synthetic_images(n, 3, size, size, 13)
+    t = seeded.synthetic_targets(n, 2, size, size, 13)
+    ref, net = _pair(2, 33, compute_dtype=torch.bfloat16)
+    torch.set_num_threads(min(32, torch.get_num_threads()))  # (torch's intra-op pool degrades badly on a 256-thread host)
+    ref.train()
+    out = ref(x)
+    rl = R.lovasz2d(out, t)
+    rl.backward()
+    rgrads = {k: p.grad for k, p in ref.named_parameters()}
+    del out
+
+    net.train()
+    crit = losses.LovaszLoss2d().to(DEV)
+    logits = net(x.to(DEV))
+    loss = crit(logits, t.to(DEV))
+    loss.backward()
+    print("cfg3 bf16 bs32 512^2 loss", loss.item(), "oracle fp32", rl.item())
+    assert abs(loss.item() - rl.item()) <= 2e-2 * max(1.0, abs(rl.item()))
+    cos = {}
+    for name, p in net.named_parameters():
+        want = rgrads[name]
+        if want is None:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        if float(want.norm()) < 1e-9:
+            continue
+        g = p.grad.float().cpu()
+        cos[name] = float((g * want).sum() / (g.norm() * want.norm() + 1e-30))
+    mean, worst = sum(cos.values()) / len(cos), min(cos.items(), key=lambda kv: kv[1])
+    print("cfg3 gradient cosine vs fp32 oracle: mean {:.4f}, worst {} {:.4f} ({} tensors)".format(mean, worst[0], worst[1], len(cos)))
+    assert len(cos) >= 160
+    for name, c in cos.items():
+        if name.startswith(("dec", "center", "final")):
+            assert c >= 0.98, (name, c)
+    # 16 384 samples per channel in the deepest BatchNorm (vs 32 in the bs-2 128^2 calibration test): bf16 storage noise
+    # averages out and the encoder's gradients line up with fp32 far better than at toy sizes
+    assert mean >= 0.90, mean

@@ -1,0 +1,232 @@
+"""Every convolution symbol the benchmark launches, reached on purpose.
+
+The dispatcher (``pick_tile`` / ``pick_rowb``) routes by problem size: the 8-wave 256x256 bf16 tile needs >= 384 blocks,
+the 128-byte rows a long K, ... -- sizes a CPU reference cannot check in seconds.  ``rs_conv2d_set_tuning`` forces tile and
+K-chunk row size, so each (tile, rows, form) symbol is compared with plain PyTorch fp32 on problems of a few thousand
+pixels, including M tails, ragged N, both concat sources, every epilogue option, the phase form (DecoderBlock), its
+4x4 / stride-2 data gradient and the two-destination store.  ``test_bench_symbols_are_covered`` closes the loop: every
+kernel name a full-size ``bench.py`` run reports must be in the set these tests exercise.
+
+Reference semantics: robosat/unet.py:32-44 (ConvRelu), :63-73 (DecoderBlock), :134-137 (torch.cat) and their autograd."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TILES = ["128x128", "128x64", "128x32", "64x64", "256x128", "256x256"]
+ROWS = [64, 128]
+# symbols these tests launch (and assert they launched): conv_igemm_<f32|bf16><[phase,|dgrad4x4,]tile,r<rows>>
+COVERED = set()
+for _dt in ("f32", "bf16"):
+    for _t in TILES:
+        if _t == "256x256" and _dt == "f32":
+            continue
+        for _r in ROWS:
+            for _form in ("", "phase,", "dgrad4x4,"):
+                COVERED.add("conv_igemm_{}<{}{},r{}>".format(_dt, _form, _t, _r))
+# non-implicit-GEMM symbols of the step have their own parity tests (test_gpu_ops / test_gpu_train_ops / test_gpu_bf16)
+COVERED |= {"conv_igemm_f32<128x64,stem>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_bf16", "conv_wgrad_thin_bf16",
+            "conv_wgrad_bf16<phase>", "conv_wgrad_f32"}
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def prep(t, dtype):  # operand as the kernel sees it, in fp32 on the host
+    return t.to(BF).float() if dtype == BF else t
+
+
+def nhwc(t, dtype):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def krsc(w, dtype):
+    return w.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+
+
+def close(got, want, dtype, what=""):
+    tol = 1e-2 if dtype == BF else 2e-4
+    scale = max(1e-6, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, "{} max abs err {} (scale {})".format(what, err, scale)
+
+
+def combos():
+    out = []
+    for dtype in (torch.float32, BF):
+        for tile in TILES:
+            if tile == "256x256" and dtype != BF:
+                continue
+            for rowb in ROWS:
+                out.append(pytest.param(dtype, tile, rowb, id="{}-{}-r{}".format("bf16" if dtype == BF else "f32", tile, rowb)))
+    return out
+
+
+def launched(d_args, dtype, phase, tile, rowb, dgrad=False):
+    """Name of the symbol the forced dispatcher reports for this launch; asserts it is the one meant."""
+    from robosat_amd import ops
+
+    d = ops.conv_desc(*d_args[0], **d_args[1]) if not phase else d_args
+    name = ops.conv_tile_name(d, dtype == BF, phase=phase)
+    if dgrad:
+        name = name.replace("<", "<dgrad4x4,")
+    want = "conv_igemm_{}<{}{},r{}>".format("bf16" if dtype == BF else "f32", "phase," if phase else ("dgrad4x4," if dgrad else ""), tile, rowb)
+    assert name == want, (name, want)
+    assert name in COVERED
+    return name
+
+
+@pytest.mark.parametrize("dtype,tile,rowb", combos())
+def test_forced_tile_plain_conv_all_epilogues(dtype, tile, rowb):
+    """3x3 / pad 1 over two concatenated sources, M = 2*23*21 = 966 (tail in every tile height), Cout = 256; epilogue
+    scale/shift + residual + ReLU, then the ReLU-mask form; then the fused BatchNorm statistics where the tile has them."""
+    from robosat_amd import ops
+
+    n, c1, c2, h, w, cout = 2, 128, 64, 23, 21, 256
+    a, b = prep(rnd(n, c1, h, w, seed=1), dtype), prep(rnd(n, c2, h, w, seed=2), dtype)
+    wt = prep(rnd(cout, c1 + c2, 3, 3, seed=3) * (2.0 / ((c1 + c2) * 9)) ** 0.5, dtype)
+    sc, sh = rnd(cout, seed=4), rnd(cout, seed=5)
+    res, mask = prep(rnd(n, cout, h, w, seed=6), dtype), prep(rnd(n, cout, h, w, seed=7), dtype)
+    base = F.conv2d(torch.cat([a, b], 1), wt, padding=1)
+    full = base * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res
+    ad, bd, wd = nhwc(a, dtype), nhwc(b, dtype), krsc(wt, dtype)
+    with ops.tuning(tile, rowb):
+        launched(((ad, wd), dict(src2=bd, pad=1)), dtype, False, tile, rowb)
+        got = ops.conv2d(ad, wd, src2=bd, pad=1, scale=sc.to(DEV), shift=sh.to(DEV), residual=nhwc(res, dtype), relu=True)
+        close(nchw(got), F.relu(full), dtype, "relu")
+        got = ops.conv2d(ad, wd, src2=bd, pad=1, relu_mask=nhwc(mask, dtype))
+        close(nchw(got), base * (mask > 0), dtype, "mask")
+        if tile != "256x256":  # the statistics' block reduction is laid out for the 4-wave tiles
+            y, partial = ops.conv2d_bnstats(ad, wd, src2=bd, pad=1)
+            close(nchw(y), base, dtype, "bnstats y")
+            yf = y.float()
+            s = partial.sum(0).cpu()
+            want0, want1 = yf.sum((0, 1, 2)).cpu(), (yf * yf).sum((0, 1, 2)).cpu()
+            assert float((s[0] - want0).abs().max()) <= 1e-3 * float(want0.abs().max() + 1)
+            assert float((s[1] - want1).abs().max()) <= 1e-3 * float(want1.abs().max() + 1)
+
+
+@pytest.mark.parametrize("dtype,tile,rowb", combos())
+def test_forced_tile_strided_and_1x1(dtype, tile, rowb):
+    """3x3 stride 2 (odd input) and a 1x1 with K = 64 -- one chunk of 128-byte bf16 rows: the shortest K loop there is."""
+    from robosat_amd import ops
+
+    n, cin, h, w, cout = 3, 64, 19, 17, 256
+    x = prep(rnd(n, cin, h, w, seed=8), dtype)
+    w3 = prep(rnd(cout, cin, 3, 3, seed=9) * 0.05, dtype)
+    w1 = prep(rnd(cout, cin, 1, 1, seed=10) * 0.1, dtype)
+    xd = nhwc(x, dtype)
+    with ops.tuning(tile, rowb):
+        close(nchw(ops.conv2d(xd, krsc(w3, dtype), stride=2, pad=1)), F.conv2d(x, w3, stride=2, padding=1), dtype, "3x3 s2")
+        close(nchw(ops.conv2d(xd, krsc(w1, dtype))), F.conv2d(x, w1), dtype, "1x1")
+        close(nchw(ops.conv2d(xd, krsc(w1, dtype), stride=2)), F.conv2d(x, w1, stride=2), dtype, "1x1 s2")
+
+
+@pytest.mark.parametrize("dtype,tile,rowb", combos())
+def test_forced_tile_phase_form_and_its_gradients(dtype, tile, rowb):
+    """DecoderBlock (unet.py:63-73) in phase form on cat[skip, prev], its 4x4/stride-2 data gradient, and that gradient
+    with torch.cat's backward fused into the store (two destinations + ReLU masks) -- against autograd."""
+    from robosat_amd import _lib, ops
+
+    n, c1, c2, hs, ws, cout = 2, 256, 256, 11, 13, 256
+    a = prep(rnd(n, c1, hs, ws, seed=11), dtype).requires_grad_(True)
+    b = prep(rnd(n, c2, hs, ws, seed=12), dtype).requires_grad_(True)
+    wt = rnd(cout, c1 + c2, 3, 3, seed=13) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    # the phase / dgrad packs sum fp32 taps and round once: the host reference uses the fp32 weights with rounded activations
+    y = F.relu(F.conv2d(F.interpolate(torch.cat([a, b], 1), scale_factor=2, mode="nearest"), wt, padding=1))
+    gy = prep(rnd(*y.shape, seed=14), dtype)
+    y.backward(gy)
+    w_krsc = krsc(wt, torch.float32)
+    ad, bd = nhwc(a.detach(), dtype), nhwc(b.detach(), dtype)
+    with ops.tuning(tile, rowb):
+        d = _lib.ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 1, 0)
+        launched(d, dtype, True, tile, rowb)
+        got = ops.conv2d_phase(ad, ops.pack_phase_weight(w_krsc, dtype), src2=bd, relu=True)
+        tol_dtype = dtype
+        close(nchw(got), y.detach(), tol_dtype, "phase fwd")
+        # data gradient: dz = gy masked by the ReLU, one 4x4 / stride-2 convolution back to the source grid
+        dz = (gy * (y.detach() > 0))
+        wd = ops.pack_dgrad_phase_weight(w_krsc, dtype)
+        dzd = nhwc(dz, dtype)
+        launched(((dzd, wd), dict(stride=2, pad=1, out_hw=(hs, ws))), dtype, False, tile, rowb, dgrad=True)
+        dsrc = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws))
+        want = torch.cat([a.grad, b.grad], 1)
+        close(nchw(dsrc), want, dtype, "dgrad4x4")
+        m1, m2 = prep(rnd(n, c1, hs, ws, seed=15), dtype), prep(rnd(n, c2, hs, ws, seed=16), dtype)
+        if c1 % int(tile.split("x")[1]) == 0:
+            d1, d2 = ops.conv2d_split(dzd, wd, c1, stride=2, pad=1, out_hw=(hs, ws), mask1=nhwc(m1, dtype), mask2=nhwc(m2, dtype))
+            close(nchw(d1), a.grad * (m1 > 0), dtype, "split d1")
+            close(nchw(d2), b.grad * (m2 > 0), dtype, "split d2")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["f32", "bf16"])
+@pytest.mark.parametrize("rowb", ROWS)
+def test_ragged_last_n_tile_with_split_store(dtype, rowb):
+    """Cout = 320 = 256 + 64 on 128-wide tiles (dec3's data gradient): the third N tile is half padding (weight rows past
+    Cout read as zeros, the epilogue skips their columns) and the store splits at 256."""
+    from robosat_amd import ops
+
+    n, cin, h, w, c1, c2 = 2, 128, 24, 22, 256, 64
+    x = prep(rnd(n, cin, h, w, seed=17), dtype)
+    wt = prep(rnd(c1 + c2, cin, 3, 3, seed=18) * 0.04, dtype)
+    want = F.conv2d(x, wt, padding=1)
+    m1, m2 = prep(rnd(n, c1, h, w, seed=19), dtype), prep(rnd(n, c2, h, w, seed=20), dtype)
+    xd, wd = nhwc(x, dtype), krsc(wt, dtype)
+    with ops.tuning("128x128", rowb):
+        got = ops.conv2d(xd, wd, pad=1)
+        close(nchw(got), want, dtype, "ragged")
+        d1, d2 = ops.conv2d_split(xd, wd, c1, pad=1, mask1=nhwc(m1, dtype), mask2=nhwc(m2, dtype))
+        close(nchw(d1), want[:, :c1] * (m1 > 0), dtype, "ragged split 1")
+        close(nchw(d2), want[:, c1:] * (m2 > 0), dtype, "ragged split 2")
+
+
+def test_dispatcher_reaches_the_8_wave_tile_unforced():
+    """One launch big enough for the heuristics themselves to pick 256x256 (>= 384 blocks, long K), checked on a strided
+    sample of images against fp32 PyTorch: 1280 -> 256 3x3 at 32 x 56^2 = 100 352 pixels (392 blocks)."""
+    from robosat_amd import ops
+
+    n, cin, h, w, cout = 32, 1280, 56, 56, 256
+    g = torch.Generator(device=DEV).manual_seed(21)
+    xd = torch.randn(n, h, w, cin, device=DEV, generator=g).to(BF)
+    wd = (torch.randn(cout, 3, 3, cin, device=DEV, generator=g) * 0.01).to(BF)
+    d = ops.conv_desc(xd, wd, pad=1)
+    assert ops.conv_tile_name(d, True) == "conv_igemm_bf16<256x256,r128>"
+    got = ops.conv2d(xd, wd, pad=1)
+    # reference on a sample: images 0 and 31, full (fp32 math on the same bf16 operands, on the host)
+    for img in (0, n - 1):
+        x = xd[img:img + 1].float().permute(0, 3, 1, 2).cpu()
+        want = F.conv2d(x, wd.float().permute(0, 3, 1, 2).cpu(), padding=1)
+        close(nchw(got[img:img + 1]), want, BF, "image {}".format(img))
+
+
+def test_bench_symbols_are_covered(tmp_path):
+    """Run the real benchmark (BASELINE configs[1] + the configs[2] train leg, 1 timed step each) and require every
+    convolution symbol it reports to be one the tests above exercise; also that its in-line parity check ran."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    names = set(line["roofline"]["per_kernel"]) | set(line["train"]["roofline"]["per_kernel"])
+    assert names, line
+    missing = sorted(n for n in names if n not in COVERED)
+    assert not missing, missing
+    assert line["parity"]["max_abs_vs_oracle"] <= 1e-3
+    assert line["train"]["parity"]["max_abs_vs_oracle"] <= 5e-2

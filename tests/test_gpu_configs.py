@@ -122,6 +122,10 @@ def test_cfg2_predict_bs16_512_fp32_headline_shape():
 def test_cfg3_train_bs32_512_bf16_step_vs_oracle():
     from robosat_amd import losses
 
+    import psutil
+
+    if psutil.virtual_memory().available < 64e9:  # the fp32 CPU oracle keeps ~1.2 GB of autograd state per 512^2 tile
+        pytest.skip("host has < 64 GB free for the bs-32 CPU oracle step")
     n, size = 32, 512
     x = seeded.synthetic_images(n, 3, size, size, 13)
     t = seeded.synthetic_targets(n, 2, size, size, 13)

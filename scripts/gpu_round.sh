@@ -1,0 +1,63 @@
+#!/bin/bash
+# One GPU-box visit, staged:  scripts/gpu_round.sh TAG stage [stage ...]
+#   tests   pytest -m gpu (full log)               smoke   __graft_entry__.smoke()
+#   bench   default bench.py line + per-layer tables (predict + train legs)
+#   trace   rocprofv3 --kernel-trace --stats of the same bench command (predict, train, serial train)
+#   pmc     counter passes, each its own rocprofv3 run with --kernel-trace only: MFMA/LDS/wait, FETCH_SIZE, WRITE_SIZE
+#   sweep   scripts/bench_layer.py tile / row-size sweeps over the benchmark's layers
+#   others  the non-headline configurations, one line each
+# Everything lands in gpurun_out/$TAG/ (merged back by gpurun); summaries to keep are copied to profiles/ by hand.
+TAG=$1; shift
+export TMPDIR=/tmp
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+B="python $REPO/bench.py --no-cpu-baseline"
+for STAGE in "$@"; do
+  echo "=== stage $STAGE ($(date +%T))"
+  case $STAGE in
+  tests)
+    timeout 2400 python -m pytest tests -m gpu -q -x --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/pytest_gpu.log ;;
+  smoke)
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+  bench)
+    timeout 900 python bench.py --layers-json $OUT/layers_predict.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
+    tail -1 $OUT/bench_default.log > $OUT/bench_default.json; cut -c1-700 $OUT/bench_default.json
+    timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --layers-json $OUT/layers_train.json > $OUT/bench_train.log 2>&1; echo "train bench exit $?"
+    tail -1 $OUT/bench_train.log > $OUT/bench_train_bf16_bs32.json; cut -c1-500 $OUT/bench_train_bf16_bs32.json ;;
+  trace)
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_predict -o p -- $B --no-train-leg --steps 5 --warmup 2 > $OUT/trace_predict.log 2>&1; echo "exit $?"
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o p -- $B --phase train --dtype bf16 --batch 32 --steps 5 --warmup 2 > $OUT/trace_train.log 2>&1; echo "exit $?"
+    ROBOSAT_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train_serial -o p -- $B --phase train --dtype bf16 --batch 32 --steps 5 --warmup 2 > $OUT/trace_train_serial.log 2>&1; echo "exit $?"
+    cd $REPO
+    for T in predict train train_serial; do
+      F=$(find $OUT/trace_$T -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/${T}_kernel_stats.csv
+      find $OUT/trace_$T -name "*kernel_trace.csv" -size +8M -delete
+    done ;;
+  pmc)
+    cd /tmp
+    C1="SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
+    P="$B --no-train-leg --no-parity --steps 1 --warmup 1"
+    T="$B --phase train --dtype bf16 --batch 32 --no-parity --steps 1 --warmup 1"
+    timeout 600 rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/pmc_mfma/predict -o p -- $P > $OUT/pmc_mfma_predict.log 2>&1; echo "exit $?"
+    ROBOSAT_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/pmc_mfma/trainbf16 -o p -- $T > $OUT/pmc_mfma_train.log 2>&1; echo "exit $?"
+    for CTR in FETCH_SIZE WRITE_SIZE; do
+      timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc/predict_pmc_$CTR -o p -- $P > $OUT/pmc_${CTR}_predict.log 2>&1; echo "exit $?"
+      ROBOSAT_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc/trainbf16_pmc_$CTR -o p -- $T > $OUT/pmc_${CTR}_train.log 2>&1; echo "exit $?"
+    done
+    cd $REPO
+    find $OUT/pmc $OUT/pmc_mfma -name "*kernel_trace.csv" -size +8M -delete
+    python scripts/pmc_mfma_summary.py $OUT/pmc_mfma > $OUT/pmc_mfma_per_kernel.txt 2>&1; head -30 $OUT/pmc_mfma_per_kernel.txt
+    python scripts/pmc_traffic.py $OUT/pmc $OUT/pmc_traffic.json "$TAG" > $OUT/pmc_hbm_traffic.txt 2>&1; head -20 $OUT/pmc_hbm_traffic.txt
+    du -sh $OUT ;;
+  sweep)
+    bash scripts/layer_sweep.sh > $OUT/layer_sweep.txt 2>&1; tail -n 120 $OUT/layer_sweep.txt ;;
+  others)
+    {
+      for A in "--dtype bf16 --no-train-leg --steps 20" "--phase train --batch 8 --steps 5 --warmup 2" "--size 1024 --batch 8 --no-train-leg --steps 10" "--phase train --dtype bf16 --batch 32 --classes 4 --steps 10" "--size 576 --batch 16 --no-train-leg --steps 10"; do
+        timeout 600 $B --no-parity $A 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], '->', d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['dtype'], '|', d['config']['workload'])" "$A"
+      done
+    } > $OUT/bench_others.txt 2>&1
+    cat $OUT/bench_others.txt ;;
+  esac
+done
+echo "=== done ($(date +%T))"

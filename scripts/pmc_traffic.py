@@ -6,7 +6,9 @@ Units and corrections (MI355X_MICROARCH.md "HBM" section, re-checked here on ker
     3 fp32 planes = 50.3 MB at bs 16 and reports 24 576 KiB = 25.2 MB);
   * WRITE_SIZE is exact for 16 B/lane stores (calibration: the stem's bn_apply<float> writes 134.2 MB at bs 8 and
     reports 131 072 KiB).
-usage: python scripts/pmc_traffic.py gpurun_out/profile_r01 [profiles/pmc_traffic.json]
+usage: python scripts/pmc_traffic.py gpurun_out/r02/pmc [profiles/pmc_traffic.json] [tag]
+The JSON carries a ``_meta`` record (tag, date, git commit of the tree that was profiled, the commands): bench.py passes it
+through as ``roofline.traffic_source`` so a reader can tell which kernels the counters belong to.
 """
 import csv
 import os
@@ -72,6 +74,19 @@ if __name__ == "__main__":
             lines.append("{:42s} launches {:4d}  read {:9.2f} MB  write {:9.2f} MB  total {:9.2f} MB".format(k, n, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
             if tag == "predict" or k not in result:
                 result[k] = round(rd + wr)
+    import datetime
+    import subprocess
+
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    result["_meta"] = {
+        "tag": sys.argv[3] if len(sys.argv) > 3 else None, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+        "commit": commit,  # None on the GPU box (the snapshot has no .git): filled in when the file is copied to profiles/
+        "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --no-cpu-baseline --no-parity "
+                   "--steps 1 --warmup 1 [--no-train-leg | --phase train --dtype bf16 --batch 32] (scripts/gpu_round.sh pmc)",
+        "corrections": "KiB units; FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64); WRITE_SIZE as reported"}
     with open(out, "w") as fp:
         json.dump(result, fp, indent=1, sort_keys=True)
     print("\n".join(lines))

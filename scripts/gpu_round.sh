@@ -15,7 +15,7 @@ for STAGE in "$@"; do
   echo "=== stage $STAGE ($(date +%T))"
   case $STAGE in
   tests)
-    timeout 2400 python -m pytest tests -m gpu -q -x --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/pytest_gpu.log ;;
+    timeout 2400 python -m pytest tests -m gpu -q --maxfail 20 --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/pytest_gpu.log ;;
   smoke)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   bench)

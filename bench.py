@@ -252,7 +252,7 @@ def parity_vs_oracle(net, x, classes, got=None):
 
 def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
     """Builds the model for `phase`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
-    returns (max-over-ranks seconds, step function, parity record of rank 0 or None)."""
+    returns (max-over-ranks seconds, step function, a callable producing rank 0's parity record)."""
 
     import torch.distributed as td
 
@@ -305,11 +305,14 @@ def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
         t = torch.tensor([el], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         el = float(t.item())
-    parity = None
-    if rank == 0 and not args.no_parity:  # (outside the timed region)
-        parity = parity_vs_oracle(net, x, args.classes, got=None if train else last[0])
+    def parity():  # (outside the timed region, and after the roofline passes: the CPU oracle lets the GPU go idle)
+        if rank != 0 or args.no_parity:
+            return None
+        rec = parity_vs_oracle(net, x, args.classes, got=None if train else last[0])
         if train:
-            parity["train_loss_last_step"] = float(last)
+            rec["train_loss_last_step"] = float(last)
+        return rec
+
     return el, step, parity
 
 
@@ -368,7 +371,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": workload(args, args.phase, args.dtype, args.batch, world),
-            "roofline": roof, "parity": parity,
+            "roofline": roof, "parity": parity(),
         }
     del step
     torch.cuda.empty_cache()
@@ -382,7 +385,7 @@ def main():
         if rank == 0:
             line["train"] = {"value": round(world * tb * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
                              "ms_per_step": round(tel / ts * 1e3, 3), "dtype": "bf16", "scaling": "weak",
-                             "config": workload(args, "train", "bf16", tb, world), "roofline": troof, "parity": tparity}
+                             "config": workload(args, "train", "bf16", tb, world), "roofline": troof, "parity": tparity()}
         del tstep
         torch.cuda.empty_cache()
 

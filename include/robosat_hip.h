@@ -332,12 +332,48 @@ int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const float* mean, 
 int rs_u8_to_nhwc4_norm(const uint8_t* img, float* out, const float* mean, const float* std, int N, int H, int W, int C,
                         rs_stream_t stream);
 
-/* self.final + softmax + un-buffer crop + 8-bit quantisation in one pass (tools/predict.py:87,96-103), binary models:
- * out[n][y][x] = uint8(np.digitize(p_foreground, anchors)) for the central (H-2*overlap) x (W-2*overlap) window, with
- * `anchors` = the 256 float64 values of np.linspace(0, 1, 256) in device memory (1-based bins, 256 wraps to 0 -- the
- * reference's behaviour).  x: NHWC [N][H][W][Cin] of `x_dtype`; w [2][Cin], bias [2]. */
+/* self.final + softmax + un-buffer crop + 8-bit quantisation in one pass (tools/predict.py:87,96-103):
+ * out[n][y][x][c-1] = uint8(np.digitize(p_c, anchors)) for every non-background class c = 1..C-1 over the central
+ * (H-2*overlap) x (W-2*overlap) window, with `anchors` = the 256 float64 values of np.linspace(0, 1, 256) in device memory
+ * (1-based bins, 256 wraps to 0 -- the reference's behaviour).  C = 2 is the reference's single-channel PNG payload, byte for
+ * byte; C > 2 (the reference asserts a binary model, predict.py:98) stores the same encoding per foreground class,
+ * interleaved.  x: NHWC [N][H][W][Cin] of `x_dtype`; w [C][Cin], bias [C]. */
 int rs_final_conv1x1_quantize_dt(const void* x, int x_dtype, const float* w, const float* bias, const double* anchors,
-                                 uint8_t* out, int N, int H, int W, int Cin, int overlap, rs_stream_t stream);
+                                 uint8_t* out, int N, int H, int W, int Cin, int C, int overlap, rs_stream_t stream);
+
+/* self.final + argmax over the classes -> one byte per pixel: Predictor.segment of `rs serve`
+ * (tools/serve.py:160-164: output.argmax(axis=0).astype(np.uint8); first maximum on ties). */
+int rs_final_conv1x1_argmax_dt(const void* x, int x_dtype, const float* w, const float* bias, uint8_t* out, int N, int H,
+                               int W, int Cin, int C, rs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The callers either side of the network, on the device (csrc/postproc.hip)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Metrics.add generalised to C classes (robosat/metrics.py:27-41; its Todo at :87-88): counts[actual * C + predicted] += 1
+ * per pixel, predicted = argmax over the C scores (first maximum).  counts: int64 [C*C] in device memory, accumulated.
+ * For C = 2 the reference's counters are tn = counts[0], "fn" = counts[1], "fp" = counts[2], tp = counts[3].  C <= 8. */
+int rs_confusion_matrix(const float* scores, const int64_t* targets, int64_t* counts, int N, int C, int H, int W,
+                        rs_stream_t stream);
+
+/* np.bincount over label tiles (robosat/tools/weights.py:41-47): counts256[v] += number of labels equal to v.
+ * labels: n bytes in device memory, 16-byte aligned; counts256: int64 [256], accumulated. */
+int rs_label_histogram_u8(const uint8_t* labels, long n, int64_t* counts256, rs_stream_t stream);
+
+/* `rs masks` (robosat/tools/masks.py:42-84): K models' quantised probabilities q [K][P][C-1] (the bytes rs predict writes)
+ * -> class index per pixel: np.argmax(np.average(probs, axis=0, weights), axis=0) with probs_k = [1 - sum_c f_c, f_1, ..],
+ * f_c = anchors[q]; float64, models accumulated in order, first maximum.  weights: K doubles in device memory or NULL. */
+int rs_softvote_masks(const uint8_t* q, const double* weights, const double* anchors, uint8_t* out, int K, long P, int C,
+                      rs_stream_t stream);
+
+/* Training-set augmentation from a cache of decoded tiles in HBM (robosat/tools/train.py:248-260,
+ * robosat/transforms.py:127-221): for batch item n take tile index[n] of images [T][S][S][C] (uint8 HWC) / masks [T][S][S],
+ * apply op[n] = f + 2*k (PIL FLIP_LEFT_RIGHT when f, then k x ROTATE_90), ToTensor + Normalize ((v/255 - mean)/std, fp32),
+ * and write what the reference's loader yields: images NCHW fp32 [N][C][S][S], masks int64 [N][S][S].
+ * mean / std: HOST arrays of C floats.  masks / out_masks may be NULL together. */
+int rs_augment_tiles(const uint8_t* images, const uint8_t* masks, const int32_t* index, const int32_t* op, const float* mean,
+                     const float* std, float* out_images, int64_t* out_masks, int N, int S, int C, rs_stream_t stream);
+
 
 #ifdef __cplusplus
 }

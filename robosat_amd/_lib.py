@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 13
+ABI_VERSION = 14
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -104,7 +104,13 @@ SIGNATURES = {
     "rs_stem_conv_wgrad_bf16": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     # device-side predict input / output (N1)
     "rs_u8_to_nhwc4_norm": (c_int, [P, P, POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, P]),
-    "rs_final_conv1x1_quantize_dt": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_final_conv1x1_quantize_dt": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_final_conv1x1_argmax_dt": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    # callers either side of the network (N2-N4)
+    "rs_confusion_matrix": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "rs_label_histogram_u8": (c_int, [P, c_long, P, P]),
+    "rs_softvote_masks": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),
+    "rs_augment_tiles": (c_int, [P, P, P, P, POINTER(c_float), POINTER(c_float), P, P, c_int, c_int, c_int, P]),
 }
 
 _lib = None

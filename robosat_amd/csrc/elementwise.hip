@@ -146,18 +146,30 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const T* __restrict_
     for (int c = 0; c < C; ++c) acc[c] = acc[c] / sum;
   }
   const long n = pix / HW, hw = pix - n * HW;
-  if (softmax == 2) {
+  if (softmax == 2) {  // un-buffer crop + np.digitize of every non-background class: C - 1 bytes per pixel
     if (C < 2) return;
     const int Himg = (int)(HW / Wimg);
     const int yy = (int)(hw / Wimg), xx = (int)(hw - (long)yy * Wimg);
     const int S_h = Himg - 2 * ov, S_w = Wimg - 2 * ov;
     if (yy < ov || yy >= Himg - ov || xx < ov || xx >= Wimg - ov) return;
-    const double pf = (double)acc[C > 1 ? 1 : 0];
-    int q = (int)(pf * 255.0);  // anchors[i] ~ i/255: first guess, then settle on the exact table (anchors ascending)
-    q = q < 0 ? 0 : (q > 255 ? 255 : q);
-    while (q < 255 && anchors[q + 1] <= pf) ++q;
-    while (q >= 0 && anchors[q] > pf) --q;
-    qout[(n * S_h + (yy - ov)) * (long)S_w + (xx - ov)] = (uint8_t)((q + 1) & 0xff);  // bins are 1-based; 256 wraps to 0
+    uint8_t* qo = qout + ((n * S_h + (yy - ov)) * (long)S_w + (xx - ov)) * (C - 1);
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+      const double pf = (double)acc[c];
+      int q = (int)(pf * 255.0);  // anchors[i] ~ i/255: first guess, then settle on the exact table (anchors ascending)
+      q = q < 0 ? 0 : (q > 255 ? 255 : q);
+      while (q < 255 && anchors[q + 1] <= pf) ++q;
+      while (q >= 0 && anchors[q] > pf) --q;
+      qo[c - 1] = (uint8_t)((q + 1) & 0xff);  // bins are 1-based; 256 wraps to 0
+    }
+    return;
+  }
+  if (softmax == 3) {  // class index of the first maximum logit (np.argmax over axis 0), one byte per pixel
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < C; ++c)
+      if (acc[c] > acc[best]) best = c;
+    qout[pix] = (uint8_t)best;
     return;
   }
   float* o = out + n * C * HW + hw;
@@ -220,7 +232,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 
 }  // namespace
 
-extern "C" int rs_abi_version(void) { return 13; }
+extern "C" int rs_abi_version(void) { return 14; }
 
 extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
@@ -289,17 +301,45 @@ extern "C" int rs_u8_to_nhwc4_norm(const uint8_t* img, float* out, const float* 
   return RS_LAUNCH_RESULT();
 }
 
+template <typename T>
+int dispatch_final_bytes(const T* x, const float* w, const float* bias, long P, long HW, int Cin, int C, int mode, hipStream_t s,
+                         const double* anchors, uint8_t* out, int W, int overlap) {
+  float* none = nullptr;
+  switch (C) {
+    case 2: return launch_final<2>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    case 3: return launch_final<3>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    case 4: return launch_final<4>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    case 5: return launch_final<5>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    case 6: return launch_final<6>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    case 7: return launch_final<7>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    case 8: return launch_final<8>(x, w, bias, none, P, HW, Cin, mode, s, anchors, out, W, overlap);
+    default: return RS_EINVAL;
+  }
+}
+
 extern "C" int rs_final_conv1x1_quantize_dt(const void* x, int x_dtype, const float* w, const float* bias,
-                                            const double* anchors, uint8_t* out, int N, int H, int W, int Cin, int overlap,
-                                            rs_stream_t stream) {
+                                            const double* anchors, uint8_t* out, int N, int H, int W, int Cin, int C,
+                                            int overlap, rs_stream_t stream) {
   if (!x || !w || !anchors || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cin > 128 || overlap < 0 ||
-      2 * overlap >= H || 2 * overlap >= W)
+      2 * overlap >= H || 2 * overlap >= W || C < 2 || C > 8)
     return RS_EINVAL;
   const long HW = (long)H * W, P = (long)N * HW;
   hipStream_t s = (hipStream_t)stream;
   if (x_dtype == RS_F32)
-    return launch_final<2>(reinterpret_cast<const float*>(x), w, bias, (float*)nullptr, P, HW, Cin, 2, s, anchors, out, W, overlap);
+    return dispatch_final_bytes(reinterpret_cast<const float*>(x), w, bias, P, HW, Cin, C, 2, s, anchors, out, W, overlap);
   if (x_dtype == RS_BF16)
-    return launch_final<2>(reinterpret_cast<const bf16_t*>(x), w, bias, (float*)nullptr, P, HW, Cin, 2, s, anchors, out, W, overlap);
+    return dispatch_final_bytes(reinterpret_cast<const bf16_t*>(x), w, bias, P, HW, Cin, C, 2, s, anchors, out, W, overlap);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_final_conv1x1_argmax_dt(const void* x, int x_dtype, const float* w, const float* bias, uint8_t* out, int N,
+                                          int H, int W, int Cin, int C, rs_stream_t stream) {
+  if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cin > 128 || C < 2 || C > 8) return RS_EINVAL;
+  const long HW = (long)H * W, P = (long)N * HW;
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == RS_F32)
+    return dispatch_final_bytes(reinterpret_cast<const float*>(x), w, bias, P, HW, Cin, C, 3, s, nullptr, out, W, 0);
+  if (x_dtype == RS_BF16)
+    return dispatch_final_bytes(reinterpret_cast<const bf16_t*>(x), w, bias, P, HW, Cin, C, 3, s, nullptr, out, W, 0);
   return RS_EINVAL;
 }

@@ -82,3 +82,80 @@ class BufferedSlippyMapDirectory(_TileDirectory):
     def unbuffer(self, probs):
         o = self.overlap
         return probs[:, o:probs.shape[1] - o, o:probs.shape[2] - o]
+
+
+class DecodedTileCache:
+    """Every (image, mask) tile of a training / validation split decoded ONCE into uint8 tensors in HBM (SURVEY.md section
+    8f, N4).  What is cached is the output of the DETERMINISTIC head of the reference's transform chain -- mode
+    conversion, resize, centre crop (tools/train.py:250-253) -- i.e. exactly the pixels the random flips / rotations and
+    ``ToTensor`` + ``Normalize`` start from.  A 512x512 RGB tile + its mask is 1 MiB: 100 000 tiles fit the MI355X's 288 GB
+    with room to spare, and an epoch then costs no PNG/JPEG decode at all."""
+
+    def __init__(self, image_dirs, label_dir, size, device, head_transform=None):
+        import numpy as np
+        from PIL import Image
+
+        from .transforms import CenterCrop, ConvertImageMode, Resize
+
+        self.source = SlippyMapTilesConcatenation(image_dirs, label_dir, joint_transform=None)
+        target = (size, size)
+        to_image = [ConvertImageMode("RGB"), Resize(target, Image.BILINEAR), CenterCrop(target)]
+        to_mask = [ConvertImageMode("P"), Resize(target, Image.NEAREST), CenterCrop(target)]
+        images, masks, self.tiles = [], [], []
+        for i in range(len(self.source.target)):
+            tiles_and_images = [ds[i] for ds in self.source.inputs]
+            mask, mask_tile = self.source.target[i]
+            assert all(tile == mask_tile for _, tile in tiles_and_images), "image tile is the same as label tile"
+            planes = []
+            for image, _ in tiles_and_images:
+                for fn in to_image:
+                    image = fn(image)
+                planes.append(np.asarray(image, dtype=np.uint8))
+            for fn in to_mask:
+                mask = fn(mask)
+            images.append(np.concatenate(planes, axis=2))
+            masks.append(np.asarray(mask, dtype=np.uint8))
+            self.tiles.append(mask_tile)
+        self.size = size
+        self.images = torch.from_numpy(np.stack(images)).to(device)  # [T, S, S, C] uint8
+        self.masks = torch.from_numpy(np.stack(masks)).to(device)    # [T, S, S] uint8
+        self.device = device
+
+    def __len__(self):
+        return len(self.tiles)
+
+
+class DeviceAugmentLoader:
+    """Iterates a ``DecodedTileCache`` like the reference's training ``DataLoader`` (tools/train.py:248-274): batches of
+    ``(images [N,C,S,S] fp32 normalised, masks [N,S,S] int64, tiles)`` -- already on the device.  The random part of the
+    transform chain -- horizontal flip with p = 0.5, then three independent 90-degree rotations with p = 0.5 each -- is drawn
+    on the host from Python's ``random`` in the reference's order (four numbers per sample), so a seeded run augments every
+    sample exactly as the host chain would; flip, rotations, ``ToTensor`` and ``Normalize`` then run in ONE kernel
+    (``rs_augment_tiles``) straight from the cache."""
+
+    def __init__(self, cache, batch_sampler, mean, std):
+        self.cache, self.batch_sampler, self.mean, self.std = cache, batch_sampler, list(mean), list(std)
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    @staticmethod
+    def draw_op():
+        import random
+
+        flip = random.random() < 0.5
+        turns = sum(random.random() < 0.5 for _ in range(3))
+        return int(flip) + 2 * turns
+
+    def __iter__(self):
+        from . import ops
+
+        c = self.cache
+        channels = c.images.shape[3]
+        mean, std = (self.mean * channels)[:channels], (self.std * channels)[:channels]  # (several image dirs: per-band repeat)
+        for batch in self.batch_sampler:
+            codes = [self.draw_op() for _ in batch]
+            index = torch.tensor(batch, dtype=torch.int32).to(c.device, non_blocking=True)
+            op = torch.tensor(codes, dtype=torch.int32).to(c.device, non_blocking=True)
+            images, masks = ops.augment_tiles(c.images, c.masks, index, op, mean, std)
+            yield images, masks, [[c.tiles[i]] for i in batch]

@@ -459,23 +459,40 @@ def u8_to_nhwc4_norm(img, mean, std):
 _ANCHORS = {}
 
 
-def final_conv1x1_quantize(x, w, bias, overlap):
-    """self.final + softmax + crop of the `overlap` border + np.digitize(p_fg, linspace(0,1,256)).astype(uint8)
-    (tools/predict.py:87,96-103) in one kernel: uint8 [N, H-2*overlap, W-2*overlap]."""
-
+def _anchors(device):
     import numpy as np
 
-    n, h, wd, cin = x.shape
-    assert w.shape[0] == 2, "single channel requires binary model"  # the reference's assertion (predict.py:98)
-    anchors = _ANCHORS.get(x.device)
+    anchors = _ANCHORS.get(device)
     if anchors is None:
-        anchors = torch.from_numpy(np.linspace(0, 1, 256)).to(x.device)  # numpy's own float64 anchors
-        _ANCHORS[x.device] = anchors
-    out = torch.empty((n, h - 2 * overlap, wd - 2 * overlap), device=x.device, dtype=torch.uint8)
+        anchors = torch.from_numpy(np.linspace(0, 1, 256)).to(device)  # numpy's own float64 anchors
+        _ANCHORS[device] = anchors
+    return anchors
+
+
+def final_conv1x1_quantize(x, w, bias, overlap):
+    """self.final + softmax + crop of the `overlap` border + np.digitize(p_c, linspace(0,1,256)).astype(uint8) of every
+    non-background class (tools/predict.py:87,96-103) in one kernel: uint8 [N, H-2*overlap, W-2*overlap] for a binary
+    model (the reference's case, byte for byte), [N, H', W', C-1] for C > 2 classes."""
+
+    n, h, wd, cin = x.shape
+    c = w.shape[0]
+    shape = (n, h - 2 * overlap, wd - 2 * overlap) + ((c - 1,) if c > 2 else ())
+    out = torch.empty(shape, device=x.device, dtype=torch.uint8)
     rc = _lib.lib().rs_final_conv1x1_quantize_dt(_dev(x, "x", x.dtype), _dt(x), _dev(w, "w"), _dev(bias, "bias"),
-                                                 _dev(anchors, "anchors", torch.float64), _dev(out, "out", torch.uint8), n, h,
-                                                 wd, cin, overlap, _stream())
+                                                 _dev(_anchors(x.device), "anchors", torch.float64), _dev(out, "out", torch.uint8),
+                                                 n, h, wd, cin, c, overlap, _stream())
     check(rc, "rs_final_conv1x1_quantize_dt")
+    return out
+
+
+def final_conv1x1_argmax(x, w, bias):
+    """self.final + argmax over the classes: uint8 [N,H,W] class indices (tools/serve.py:160-164)."""
+
+    n, h, wd, cin = x.shape
+    out = torch.empty((n, h, wd), device=x.device, dtype=torch.uint8)
+    rc = _lib.lib().rs_final_conv1x1_argmax_dt(_dev(x, "x", x.dtype), _dt(x), _dev(w, "w"), _dev(bias, "bias"),
+                                               _dev(out, "out", torch.uint8), n, h, wd, cin, w.shape[0], _stream())
+    check(rc, "rs_final_conv1x1_argmax_dt")
     return out
 
 
@@ -765,3 +782,56 @@ def confusion_counts(scores, targets, counts):
                                         _dev(counts, "counts", torch.int64), n, c, h, w, _stream())
     check(rc, "rs_confusion_counts")
     return counts
+
+
+def confusion_matrix(scores, targets, counts):
+    """counts (int64 [C*C] device tensor, row = actual, column = predicted) += the batch's confusion matrix."""
+
+    n, c, h, w = scores.shape
+    assert counts.numel() == c * c
+    rc = _lib.lib().rs_confusion_matrix(_dev(scores, "scores"), _dev(targets, "targets", torch.int64),
+                                        _dev(counts, "counts", torch.int64), n, c, h, w, _stream())
+    check(rc, "rs_confusion_matrix")
+    return counts
+
+
+def label_histogram_u8(labels, counts256):
+    """counts256 (int64 [256] device tensor) += np.bincount(labels) of a uint8 device tensor (tools/weights.py:41-47)."""
+
+    rc = _lib.lib().rs_label_histogram_u8(_dev(labels, "labels", torch.uint8), labels.numel(), _dev(counts256, "counts", torch.int64),
+                                          _stream())
+    check(rc, "rs_label_histogram_u8")
+    return counts256
+
+
+def softvote_masks(quantized, weights=None):
+    """quantized uint8 [K, P] (binary models) or [K, P, C-1] -> uint8 [P] class indices: the weighted soft vote of
+    tools/masks.py:42-84 over K models' probability bytes."""
+
+    if quantized.dim() == 2:
+        quantized = quantized.unsqueeze(-1)
+    k, p, cq = quantized.shape
+    out = torch.empty(p, device=quantized.device, dtype=torch.uint8)
+    wt = None if weights is None else torch.as_tensor(list(weights), dtype=torch.float64).to(quantized.device)
+    rc = _lib.lib().rs_softvote_masks(_dev(quantized, "quantized", torch.uint8), _dev(wt, "weights", torch.float64),
+                                      _dev(_anchors(quantized.device), "anchors", torch.float64), _dev(out, "out", torch.uint8),
+                                      k, p, cq + 1, _stream())
+    check(rc, "rs_softvote_masks")
+    return out
+
+
+def augment_tiles(images, masks, index, op, mean, std):
+    """Batch from a decoded-tile cache: images uint8 [T,S,S,C], masks uint8 [T,S,S] or None, index / op int32 [N] device
+    tensors -> (images fp32 NCHW [N,C,S,S], masks int64 [N,S,S] or None): flip / rot90 / ToTensor / Normalize in one pass."""
+
+    t, s, s2, c = images.shape
+    assert s == s2, "square tiles (a 90-degree rotation must keep the shape)"
+    n = index.numel()
+    out = torch.empty((n, c, s, s), device=images.device, dtype=torch.float32)
+    om = torch.empty((n, s, s), device=images.device, dtype=torch.int64) if masks is not None else None
+    fm, fs = (ctypes.c_float * c)(*mean), (ctypes.c_float * c)(*std)
+    rc = _lib.lib().rs_augment_tiles(_dev(images, "images", torch.uint8), _dev(masks, "masks", torch.uint8),
+                                     _dev(index, "index", torch.int32), _dev(op, "op", torch.int32), fm, fs, _dev(out, "out"),
+                                     _dev(om, "out_masks", torch.int64), n, s, c, _stream())
+    check(rc, "rs_augment_tiles")
+    return out, om

@@ -1,6 +1,8 @@
 """``rs predict``: same flags and output files as the reference (``robosat/tools/predict.py``) -- one mode-P PNG per
 tile holding the 8-bit quantised foreground probability with the continuous pink palette -- computed by the
-MI355X-native model with the softmax fused into the last kernel.  A plain ``rs predict`` uses every visible GPU like
+MI355X-native model with the softmax fused into the last kernel.  Models with 3 / 4 / 5 classes, which the reference
+refuses (predict.py:98 asserts a binary model), get the same encoding per non-background class in a mode LA / RGB / RGBA
+PNG (``rs masks`` reads both; C = 2 stays byte-identical to the reference).  A plain ``rs predict`` uses every visible GPU like
 the reference's ``DataParallel`` (tools/predict.py:63): it re-executes itself once per GPU (``robosat_amd.launch``);
 the batches are dealt round-robin to the ranks by the batch sampler (each rank decodes only its own tiles) and there is
 no collective."""
@@ -104,8 +106,8 @@ def main(args):
     if host_pipeline:
         transform = Compose([ConvertImageMode(mode="RGB"), ImageToTensor(), Normalize(mean=mean, std=std)])
     else:
-        assert num_classes == 2, "single channel requires binary model"
         transform = Compose([ConvertImageMode(mode="RGB"), ImageToUint8()])
+    assert 2 <= num_classes <= 5, "the probability PNGs hold 1..4 channels: binary models (reference) up to 5 classes"
 
     directory = BufferedSlippyMapDirectory(args.tiles, transform=transform, size=args.tile_size, overlap=args.overlap)
     assert len(directory) > 0, "at least one tile in dataset"
@@ -120,16 +122,19 @@ def main(args):
             quantized = []
             for prob in probs:
                 prob = directory.unbuffer(prob)
-                assert prob.shape[0] == 2, "single channel requires binary model"
-                assert np.allclose(np.sum(prob, axis=0), 1.0), "single channel requires probabilities to sum up to one"
-                quantized.append(quantize(prob[1:, :, :]).squeeze())
+                assert np.allclose(np.sum(prob, axis=0), 1.0, atol=1e-6), "single channel requires probabilities to sum up to one"
+                q = quantize(prob[1:, :, :])
+                quantized.append(q.squeeze() if num_classes == 2 else np.ascontiguousarray(q.transpose(1, 2, 0)))
         else:
             quantized = net.predict_quantized(images.to(device, non_blocking=True), overlap=args.overlap, mean=mean, std=std).cpu().numpy()
 
         for tile, q in zip(tiles, quantized):
             x, y, z = list(map(int, tile))
-            out = Image.fromarray(q, mode="P")
-            out.putpalette(palette)
+            if num_classes == 2:
+                out = Image.fromarray(q, mode="P")
+                out.putpalette(palette)
+            else:
+                out = Image.fromarray(q, mode={2: "LA", 3: "RGB", 4: "RGBA"}[num_classes - 1])
 
             os.makedirs(os.path.join(args.probs, str(z), str(x)), exist_ok=True)
             out.save(os.path.join(args.probs, str(z), str(x), str(y) + ".png"), optimize=True)

@@ -139,7 +139,12 @@ def main(args):
     else:
         sys.exit("Error: Unknown [opt][loss] value !")
 
-    train_loader, val_loader = get_dataset_loaders(model, dataset, args.workers, rank, world)
+    # [model] device_augment = true (extension key): decoded-tile cache in HBM + flip / rot90 / ToTensor / Normalize in one
+    # kernel instead of PIL work in DataLoader workers (same augmentation distribution, same seeded draws)
+    if model.get("model", {}).get("device_augment", False):
+        train_loader, val_loader = get_device_loaders(model, dataset, device, rank, world)
+    else:
+        train_loader, val_loader = get_dataset_loaders(model, dataset, args.workers, rank, world)
 
     num_epochs = model["opt"]["epochs"]
     if resume >= num_epochs:
@@ -267,6 +272,24 @@ class ShardedBatchSampler:
 
     def __len__(self):
         return self.n // (self.bs * self.world)
+
+
+def get_device_loaders(model, dataset, device, rank=0, world=1):
+    """The loaders of ``get_dataset_loaders`` with the tiles decoded once into HBM and augmented on the device."""
+    from robosat_amd.datasets import DecodedTileCache, DeviceAugmentLoader
+
+    size = model["common"]["image_size"]
+    batch_size = model["common"]["batch_size"] // world
+    path = dataset["common"]["dataset"]
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    seed = int(os.environ.get("ROBOSAT_SEED", "0"))
+    loaders = []
+    for split, shuffle in (("training", True), ("validation", False)):
+        cache = DecodedTileCache([os.path.join(path, split, "images")], os.path.join(path, split, "labels"), size, device)
+        assert len(cache) > 0, "at least one tile in {} dataset".format(split)
+        sampler = ShardedBatchSampler(len(cache), batch_size, rank, world, shuffle, seed if shuffle else 0)
+        loaders.append(DeviceAugmentLoader(cache, sampler, mean, std))
+    return loaders
 
 
 def get_dataset_loaders(model, dataset, workers, rank=0, world=1):

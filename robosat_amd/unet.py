@@ -321,7 +321,8 @@ class UNet(nn.Module):
         uint8 HWC ``[N,H,W,C]`` in -> ToTensor + Normalize -> U-Net -> softmax -> crop of the ``overlap`` border ->
         ``np.digitize(p_foreground, np.linspace(0,1,256)).astype(uint8)`` out, ``[N,H-2*overlap,W-2*overlap]`` uint8:
         exactly the bytes the reference writes into its probability PNGs (tools/predict.py:71-103), 1 byte per pixel each
-        way over PCIe instead of 12 in / 8 out."""
+        way over PCIe instead of 12 in / 8 out.  Models with more than two classes (which the reference's predict tool
+        asserts away) return ``[N,H',W',C-1]``: the same encoding for every non-background class."""
 
         assert not self.training, "predict_quantized is an eval-mode call"
         assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.size(3) == self.in_channels
@@ -333,7 +334,23 @@ class UNet(nn.Module):
             x4 = x4.to(torch.bfloat16)  # (device-side cast of the 4-channel image; the stem then runs in bf16)
         return self._forward_eval(None, softmax=False, x4=x4, quantize_overlap=overlap)
 
-    def _forward_eval(self, x, softmax, x4=None, quantize_overlap=None):
+    @torch.no_grad()
+    def predict_classes(self, images_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """The device side of ``rs serve``'s ``Predictor.segment`` (reference tools/serve.py:149-164): uint8 HWC tiles
+        ``[N,H,W,C]`` in -> ToTensor + Normalize -> U-Net -> ``argmax`` over the class logits -> uint8 ``[N,H,W]`` class
+        indices out (``self.final`` and the argmax are one kernel; the logits never reach HBM)."""
+
+        assert not self.training, "predict_classes is an eval-mode call"
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.size(3) == self.in_channels
+        assert images_u8.size(1) % 32 == 0 and images_u8.size(2) % 32 == 0, "image resolution has to be divisible by 32 for resnet"
+        if not images_u8.is_cuda:
+            raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(images_u8.device))
+        x4 = ops.u8_to_nhwc4_norm(images_u8.contiguous(), list(mean)[:self.in_channels], list(std)[:self.in_channels])
+        if self.compute_dtype == torch.bfloat16:
+            x4 = x4.to(torch.bfloat16)
+        return self._forward_eval(None, softmax=False, x4=x4, argmax=True)
+
+    def _forward_eval(self, x, softmax, x4=None, quantize_overlap=None, argmax=False):
         r = self.resnet
         dt = self.compute_dtype  # activations after the stem pool (the stem itself always runs in fp32)
         if x4 is None:
@@ -379,6 +396,8 @@ class UNet(nn.Module):
         dec5 = ops.conv2d(dec4, self.dec5.block.krsc(dt), pad=1, relu=True)
 
         wf = self.final.weight.detach().reshape(self.num_classes, -1)
+        if argmax:
+            return ops.final_conv1x1_argmax(dec5, wf, self.final.bias.detach())
         if quantize_overlap is not None:
             return ops.final_conv1x1_quantize(dec5, wf, self.final.bias.detach(), quantize_overlap)
         return ops.final_conv1x1(dec5, wf, self.final.bias.detach(), softmax=softmax)

@@ -51,9 +51,9 @@ def test_rs_train_and_predict_spawn_one_process_per_gpu(tmp_path):
     this box) runs two ranks: global batch 4 = 2 tiles per rank, one log, one checkpoint, every tile predicted once and
     byte-identical to the single-process run."""
     tmp = str(tmp_path)
-    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=8, n_val=4, size=128, seed=11)
+    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=8, n_val=4, size=256, seed=11)
     ckdir = os.path.join(tmp, "pth")
-    model_toml, ds_toml = synth.write_configs(tmp, ds_root, ckdir, loss="Lovasz", batch_size=4, image_size=128, epochs=1)
+    model_toml, ds_toml = synth.write_configs(tmp, ds_root, ckdir, loss="Lovasz", batch_size=4, image_size=256, epochs=1)
     two = {"ROBOSAT_GPUS": "2", "ROBOSAT_DIST_BACKEND": "gloo"}
     r = _rs(["train", "--model", model_toml, "--dataset", ds_toml], two, tmp)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -70,7 +70,7 @@ def test_rs_train_and_predict_spawn_one_process_per_gpu(tmp_path):
     outs = {}
     for name, env in (("two", two), ("one", {"ROBOSAT_GPUS": "1"})):
         probs = os.path.join(tmp, "probs_" + name)
-        r = _rs(["predict", "--batch_size", "1", "--checkpoint", ck_path, "--overlap", "32", "--tile_size", "128", "--model", model_toml,
+        r = _rs(["predict", "--batch_size", "1", "--checkpoint", ck_path, "--overlap", "32", "--tile_size", "256", "--model", model_toml,
                  "--dataset", ds_toml, tiles_dir, probs], env, tmp)
         assert r.returncode == 0, r.stdout + r.stderr
         files = sorted(os.path.relpath(os.path.join(d, f), probs) for d, _, fs in os.walk(probs) for f in fs)

@@ -303,7 +303,15 @@ class UNet(nn.Module):
 
             return unet_train_forward(self, x)
         if self.training:
-            raise NotImplementedError("robosat_amd.UNet: train-mode forward under no_grad is not supported (the reference never does this: validate() calls net.eval())")
+            # train mode without autograd (e.g. a forward under torch.no_grad() to refresh BatchNorm statistics): the
+            # training forward -- batch statistics, running buffers updated -- with its tape thrown away
+            from .autograd import _Tape, _forward
+
+            if not x.is_cuda:
+                raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
+            assert x.size(1) == self.in_channels
+            with torch.no_grad():
+                return _forward(self, x.detach().float().contiguous(), _Tape())
         return self._forward_eval(x, softmax=False)
 
     @torch.no_grad()

@@ -13,6 +13,7 @@ from oracle import robosat_ref as R, seeded
 pytestmark = pytest.mark.gpu
 
 TOL_PROBS = 1e-3  # north_star tolerance
+DEV = "cuda:0"
 
 
 def _pair(num_classes, seed, in_channels=3):
@@ -68,3 +69,31 @@ def test_resolution_assert_and_no_cpu_path():
         net(torch.zeros(1, 3, 48, 64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 64, 64))
+
+
+def test_train_mode_forward_without_autograd_updates_batchnorm_like_the_reference():
+    """net.train() + torch.no_grad(): logits from batch statistics and updated running buffers, as nn.BatchNorm2d does
+    (the reference's modules are plain torch modules, so this works there: robosat/unet.py:110-141)."""
+    from robosat_amd.unet import UNet
+
+    ref = R.UNetRef(2)
+    sd = seeded.seeded_state_dict(ref.state_dict(), 19)
+    ref.load_state_dict(sd)
+    net = UNet(2, pretrained=False)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    x = seeded.synthetic_images(2, 3, 64, 96, seed=4)
+    ref.train()
+    net.train()
+    with torch.no_grad():
+        want = ref(x)
+        got = net(x.to(DEV))
+    assert not got.requires_grad
+    assert float((got.cpu() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))
+    rb = dict(ref.named_buffers())
+    for name, b in net.named_buffers():
+        w = rb[name]
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == int(w) == 1
+        else:
+            assert float((b.cpu() - w).abs().max()) <= 1e-3 * max(1.0, float(w.abs().max())), name

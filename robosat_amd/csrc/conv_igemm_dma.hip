@@ -158,8 +158,9 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats
     const long mrows = phase4 ? (long)d->N * d->Hs * d->Ws : M;  // rows per launch grid slice (each phase tiles its own)
     const long nph = phase4 ? 4 : 1;
     const long nk128 = (long)(phase4 ? 4 : d->kh * d->kw) * (d->C1 + d->C2) * es / 128;
-    // (short-K launches are DMA-latency / HBM bound: there the 256-row tile ties the 128x128 one at best)
-    if (d->Cout % 256 == 0 && nk128 >= 32 && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= tu.min256) return T256x256;
+    // (short-K launches are DMA-latency / HBM bound: there the 256-row tile ties the 128x128 one at best; from 16 chunks on
+    // it wins: +22 % on dec2's 4x4/s2 data gradient, 64 -> 768 at 64^2 x 32 -- profiles/r02/layer_sweep.txt)
+    if (d->Cout % 256 == 0 && nk128 >= ((phase4 || d->kh > 1) ? 16 : 32) && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= tu.min256) return T256x256;
   }
   if (d->Cout % 128 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 128) >= want) return T128x128;
   // ragged last N tile (weight rows past Cout read as zeros through the buffer bound, the epilogue skips their columns):

@@ -293,6 +293,10 @@ def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual
     c2 = 0 if src2 is None else src2.shape[3]
     cout = weight_phase.shape[1]
     assert tuple(weight_phase.shape) == (4, cout, 2, 2, c1 + c2)
+    if src2 is not None and tuple(src2.shape[:3]) != (n, hs, ws):
+        # what torch.cat raises in the reference (unet.py:134-137) when a skip and the decoder tensor disagree
+        raise RuntimeError("Sizes of tensors must match except in dimension 1: skip {} vs decoder {}".format(
+            tuple(src1.shape[:3]), tuple(src2.shape[:3])))
     act = src1.dtype
     d = ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, int(relu), 0)
     out = torch.empty((n, 2 * hs, 2 * ws, cout), device=src1.device, dtype=act)

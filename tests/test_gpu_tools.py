@@ -134,9 +134,9 @@ def test_multiclass_predict_encoding_and_masks_roundtrip(tmp_path):
     classes = 4
     net = _net(classes, 41)
     g = torch.Generator().manual_seed(8)
-    u8 = torch.randint(0, 256, (2, 128, 160, 3), generator=g, dtype=torch.uint8)
+    u8 = torch.randint(0, 256, (2, 128, 192, 3), generator=g, dtype=torch.uint8)
     got = net.predict_quantized(u8.to(DEV), overlap=16).cpu().numpy()
-    assert got.shape == (2, 96, 128, classes - 1)
+    assert got.shape == (2, 96, 160, classes - 1)
     from robosat_amd.transforms import ImageToTensor, Normalize
 
     norm = Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])

@@ -97,3 +97,11 @@ def test_train_mode_forward_without_autograd_updates_batchnorm_like_the_referenc
             assert int(b) == int(w) == 1
         else:
             assert float((b.cpu() - w).abs().max()) <= 1e-3 * max(1.0, float(w.abs().max())), name
+
+
+def test_odd_multiple_of_32_fails_like_torch_cat_not_with_a_gpu_fault():
+    """H or W = 32 * odd passes the reference's own assertion (unet.py:120) but its torch.cat of enc4 with the pooled and
+    re-upsampled centre then raises a size mismatch; same here (an error, never an out-of-bounds gather)."""
+    _, net = _pair(2, 1)
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        net(seeded.synthetic_images(1, 3, 64, 160, seed=1).to(DEV))

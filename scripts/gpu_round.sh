@@ -5,6 +5,7 @@
 #   trace   rocprofv3 --kernel-trace --stats of the same bench command (predict, train, serial train)
 #   pmc     counter passes, each its own rocprofv3 run with --kernel-trace only: MFMA/LDS/wait, FETCH_SIZE, WRITE_SIZE
 #   sweep   scripts/bench_layer.py tile / row-size sweeps over the benchmark's layers
+#   loader  loader-inclusive tiles/s of rs predict / rs train (scripts/loader_bench.py)
 #   others  the non-headline configurations, one line each
 # Everything lands in gpurun_out/$TAG/ (merged back by gpurun); summaries to keep are copied to profiles/ by hand.
 TAG=$1; shift
@@ -51,6 +52,8 @@ for STAGE in "$@"; do
     du -sh $OUT ;;
   sweep)
     bash scripts/layer_sweep.sh > $OUT/layer_sweep.txt 2>&1; tail -n 120 $OUT/layer_sweep.txt ;;
+  loader)
+    timeout 1200 python scripts/loader_bench.py > $OUT/loader_bench.txt 2>&1; echo "exit $?"; cat $OUT/loader_bench.txt | cut -c1-300 ;;
   others)
     {
       for A in "--dtype bf16 --no-train-leg --steps 20" "--phase train --batch 8 --steps 5 --warmup 2" "--size 1024 --batch 8 --no-train-leg --steps 10" "--phase train --dtype bf16 --batch 32 --classes 4 --steps 10" "--size 576 --batch 16 --no-train-leg --steps 10"; do

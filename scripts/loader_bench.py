@@ -1,0 +1,93 @@
+"""Loader-inclusive throughput of the tools (measurement; SURVEY.md section 7 "report both"): `rs predict` over a real
+slippy-map directory of decoded-from-disk tiles, and `rs train` for one epoch with the host loader (PIL transforms in
+DataLoader workers) and with the device-side augmentation (decoded-tile cache in HBM).  Prints one JSON line per case.
+
+usage: python scripts/loader_bench.py [--tiles 512] [--size 512] [--workers 16] [--batch 16]"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+from PIL import Image
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tiles", type=int, default=512)
+ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--workers", type=int, default=16)
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--train-tiles", type=int, default=256)
+a = ap.parse_args()
+
+
+def rs(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    e.setdefault("ROBOSAT_GPUS", "1")
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-m", "robosat_amd.tools"] + args, env=e, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    if r.returncode != 0:
+        raise SystemExit(r.stdout[-2000:] + r.stderr[-2000:])
+    return dt
+
+
+with tempfile.TemporaryDirectory() as tmp:
+    import synth
+    from robosat_amd.config import load_config, save_config
+    from robosat_amd.unet import UNet
+
+    rng = np.random.default_rng(0)
+    # aerial-imagery-like tiles: smooth texture + objects, stored as JPEG (what tile servers deliver); labels PNG
+    def write(split, count, x0):
+        for i in range(count):
+            img, mask = synth.make_tile(rng, a.size)
+            base = np.kron(rng.integers(40, 200, size=(a.size // 16, a.size // 16, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+            img = (0.5 * img + 0.5 * base).astype(np.uint8)
+            x, y = x0 + i // 32, 5000 + i % 32
+            for kind, arr in (("images", img), ("labels", mask)):
+                d = os.path.join(tmp, "ds", split, kind, "18", str(x))
+                os.makedirs(d, exist_ok=True)
+                if kind == "images":
+                    Image.fromarray(arr, mode="RGB").save(os.path.join(d, "{}.jpg".format(y)), quality=90)
+                else:
+                    im = Image.fromarray(arr, mode="P")
+                    im.putpalette([0, 0, 0, 250, 0, 0] + [0] * (254 * 3))
+                    im.save(os.path.join(d, "{}.png".format(y)))
+
+    write("validation", a.tiles, 1000)
+    write("training", a.train_tiles, 3000)
+    ds_root = os.path.join(tmp, "ds")
+    model_toml, ds_toml = synth.write_configs(tmp, ds_root, os.path.join(tmp, "pth"), batch_size=a.batch, image_size=a.size, epochs=1)
+    net = UNet(2, pretrained=False)
+    ck = os.path.join(tmp, "ck.pth")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in net.state_dict().items()}}, ck)
+
+    tiles_dir = os.path.join(ds_root, "validation", "images")
+    for workers in (0, a.workers):
+        dt = rs(["predict", "--batch_size", str(a.batch), "--checkpoint", ck, "--overlap", "32", "--tile_size", str(a.size), "--workers", str(workers),
+                 "--model", model_toml, "--dataset", ds_toml, tiles_dir, os.path.join(tmp, "probs{}".format(workers))])
+        print(json.dumps({"case": "rs predict, {} JPEG tiles of {}^2 from disk, overlap 32 (9-tile composites), PNG out, bs {}, {} loader workers".format(
+            a.tiles, a.size, a.batch, workers), "tiles_per_s": round(a.tiles / dt, 1), "wall_s": round(dt, 2),
+            "note": "wall time of the whole tool: interpreter + model start-up (~6 s) included"}), flush=True)
+
+    for dtype, aug in (("fp32", False), ("bf16", False), ("bf16", True)):
+        cfg = load_config(model_toml)
+        cfg["model"]["compute_dtype"] = dtype
+        cfg["model"]["device_augment"] = aug
+        cfg["common"]["checkpoint"] = os.path.join(tmp, "pth_{}_{}".format(dtype, int(aug)))
+        save_config(cfg, model_toml)
+        dt = rs(["train", "--model", model_toml, "--dataset", ds_toml, "--workers", str(a.workers)])
+        n = a.train_tiles + a.tiles  # one training epoch + one validation pass
+        print(json.dumps({"case": "rs train 1 epoch, {} + {} tiles of {}^2, bs {}, {}, {}".format(
+            a.train_tiles, a.tiles, a.size, a.batch, dtype, "device-side augmentation (tile cache in HBM)" if aug else "{} DataLoader workers (PIL)".format(a.workers)),
+            "tiles_per_s": round(n / dt, 1), "wall_s": round(dt, 2), "note": "whole tool incl. start-up, validation pass and the 457 MB checkpoint write"}), flush=True)

@@ -255,6 +255,8 @@ class UNet(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_state_list", None)  # (.to() may replace the parameter tensors)
+        self.__dict__.pop("_graphs", None)
         for m in self.modules():  # .to()/.cuda() may drop the KRSC layout of size-1-dim weights: restore it
             if isinstance(m, _Conv) and not m.weight.is_contiguous(memory_format=torch.channels_last):
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
@@ -290,6 +292,56 @@ class UNet(nn.Module):
         for c, k, cast, dg in zip(convs, keys, st[0].cast, st[0].dgrad):
             c._bf16 = (k, cast)
             c._dgrad = (k, dg)
+
+    # -- hipGraph replay of the eval forward (latency path) -------------------------------------------------------
+
+    def _graph_replay(self, kind, fn, x):
+        """Run ``fn(x)`` through a captured hipGraph (one per input shape / dtype / entry point).
+
+        A small-batch forward is ~70 launches of 5-100 us kernels: the host (Python + ctypes, ~10 us per launch) is then
+        slower than the GPU, and ``rs serve``'s single-tile latency is launch-bound.  Capturing the launch sequence once
+        and replaying it removes the host from the loop.  The graph bakes in device addresses, so it is keyed on the input
+        signature AND on the version counters of every parameter / buffer: any in-place update (an optimizer step, a
+        ``load_state_dict``) drops the stale graphs.  Returns a fresh tensor (the graph's static output is reused)."""
+
+        sig = (kind, tuple(x.shape), x.dtype, x.device, self.compute_dtype,
+               tuple(t._version for t in self._state_tensors()), tuple(t.data_ptr() for t in self._state_tensors()[:4]))
+        cache = self.__dict__.setdefault("_graphs", {})
+        entry = cache.get(sig)
+        if entry is None:
+            if len(cache) >= 8:
+                cache.clear()
+            static_x = x.clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):  # warm-up off the capture: fills the weight / folded-BN caches, the workspaces
+                fn(static_x)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = fn(static_x)
+            entry = (graph, static_x, static_out)
+            cache[sig] = entry
+        graph, static_x, static_out = entry
+        static_x.copy_(x)
+        graph.replay()
+        return static_out.clone()
+
+    def _state_tensors(self):
+        st = self.__dict__.get("_state_list")
+        if st is None:
+            st = [p for p in self.parameters()] + [b for b in self.buffers()]
+            self.__dict__["_state_list"] = st
+        return st
+
+    @staticmethod
+    def _want_graph(x):
+        """Graphs for the latency regime (a few tiles per call); ROBOSAT_GRAPHS=0|1 overrides."""
+
+        forced = os.environ.get("ROBOSAT_GRAPHS")
+        if forced is not None:
+            return forced == "1"
+        return x.shape[0] * x.shape[1] * x.shape[2] <= 2 * 512 * 512
 
     # -- forward ------------------------------------------------------------------------------------------------
 
@@ -337,10 +389,18 @@ class UNet(nn.Module):
         assert images_u8.size(1) % 32 == 0 and images_u8.size(2) % 32 == 0, "image resolution has to be divisible by 32 for resnet"
         if not images_u8.is_cuda:
             raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(images_u8.device))
-        x4 = ops.u8_to_nhwc4_norm(images_u8.contiguous(), list(mean)[:self.in_channels], list(std)[:self.in_channels])
-        if self.compute_dtype == torch.bfloat16:
-            x4 = x4.to(torch.bfloat16)  # (device-side cast of the 4-channel image; the stem then runs in bf16)
-        return self._forward_eval(None, softmax=False, x4=x4, quantize_overlap=overlap)
+        mean, std = list(mean)[:self.in_channels], list(std)[:self.in_channels]
+
+        def run(u8):
+            x4 = ops.u8_to_nhwc4_norm(u8, mean, std)
+            if self.compute_dtype == torch.bfloat16:
+                x4 = x4.to(torch.bfloat16)  # (device-side cast of the 4-channel image; the stem then runs in bf16)
+            return self._forward_eval(None, softmax=False, x4=x4, quantize_overlap=overlap)
+
+        images_u8 = images_u8.contiguous()
+        if self._want_graph(images_u8):
+            return self._graph_replay(("quantized", overlap, tuple(mean), tuple(std)), run, images_u8)
+        return run(images_u8)
 
     @torch.no_grad()
     def predict_classes(self, images_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
@@ -353,10 +413,18 @@ class UNet(nn.Module):
         assert images_u8.size(1) % 32 == 0 and images_u8.size(2) % 32 == 0, "image resolution has to be divisible by 32 for resnet"
         if not images_u8.is_cuda:
             raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(images_u8.device))
-        x4 = ops.u8_to_nhwc4_norm(images_u8.contiguous(), list(mean)[:self.in_channels], list(std)[:self.in_channels])
-        if self.compute_dtype == torch.bfloat16:
-            x4 = x4.to(torch.bfloat16)
-        return self._forward_eval(None, softmax=False, x4=x4, argmax=True)
+        mean, std = list(mean)[:self.in_channels], list(std)[:self.in_channels]
+
+        def run(u8):
+            x4 = ops.u8_to_nhwc4_norm(u8, mean, std)
+            if self.compute_dtype == torch.bfloat16:
+                x4 = x4.to(torch.bfloat16)
+            return self._forward_eval(None, softmax=False, x4=x4, argmax=True)
+
+        images_u8 = images_u8.contiguous()
+        if self._want_graph(images_u8):
+            return self._graph_replay(("classes", tuple(mean), tuple(std)), run, images_u8)
+        return run(images_u8)
 
     def _forward_eval(self, x, softmax, x4=None, quantize_overlap=None, argmax=False):
         r = self.resnet

@@ -313,3 +313,28 @@ def test_predictor_segment_matches_oracle_argmax(tmp_path):
 
     assert np.array_equal(np.array(Image.open(io.BytesIO(resp.data))), got)
     assert client.get("/17/5/9.png").status_code == 404 and client.get("/18/5/10.png").status_code == 500
+
+
+def test_graph_replay_is_bit_identical_and_tracks_weight_updates(monkeypatch):
+    """The latency path (``rs serve`` / small ``rs predict`` batches) replays a captured hipGraph: same bytes as the eager
+    launch sequence, for new inputs too, and an in-place parameter update must not be served from a stale graph."""
+    net = _net(2, 5)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(0, 256, (1, 256, 256, 3), generator=g, dtype=torch.uint8).to(DEV)
+    b = torch.randint(0, 256, (1, 256, 256, 3), generator=g, dtype=torch.uint8).to(DEV)
+    monkeypatch.setenv("ROBOSAT_GRAPHS", "0")
+    ea, eb, ec = net.predict_quantized(a, overlap=32), net.predict_quantized(b, overlap=32), net.predict_classes(a)
+    monkeypatch.setenv("ROBOSAT_GRAPHS", "1")
+    ga = net.predict_quantized(a, overlap=32)
+    gb = net.predict_quantized(b, overlap=32)  # replay with a new input
+    ga2 = net.predict_quantized(a, overlap=32)
+    gc = net.predict_classes(a)
+    assert len(net._graphs) == 2
+    assert torch.equal(ga, ea) and torch.equal(gb, eb) and torch.equal(ga2, ea) and torch.equal(gc, ec)
+    assert not torch.equal(ea, eb)
+    with torch.no_grad():
+        net.final.bias[1] += 0.75  # what an optimizer step / fine-tune does: in place, version bump
+    gn = net.predict_quantized(a, overlap=32)
+    monkeypatch.setenv("ROBOSAT_GRAPHS", "0")
+    en = net.predict_quantized(a, overlap=32)
+    assert torch.equal(gn, en) and not torch.equal(en, ea)

@@ -60,7 +60,8 @@ for STAGE in "$@"; do
         timeout 600 $B --no-parity $A 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], '->', d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['dtype'], '|', d['config']['workload'])" "$A"
       done
     } > $OUT/bench_others.txt 2>&1
-    cat $OUT/bench_others.txt ;;
+    cat $OUT/bench_others.txt
+    timeout 600 python scripts/latency_bench.py > $OUT/latency.txt 2>&1; cat $OUT/latency.txt ;;
   esac
 done
 echo "=== done ($(date +%T))"

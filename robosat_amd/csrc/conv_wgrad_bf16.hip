@@ -41,6 +41,7 @@ struct WgradArgsB {
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kw, stride, pad, Ho, Wo, Cout;
   int M, K, tiles_co, tiles_ci, tiles_k, chunks_per_split;
+  int Ctot, ci_base;  // channels of the whole concat (tap stride inside K) and this launch's first channel in it
   rs_fastdiv div_howo, div_wo;
 };
 
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
 
   // D[i][j]: i = cout (tile-local) = (r&3) + 8*(r>>2) + 4*(lane>>5), j = cin (tile-local) = lane&31
   float* out = p.out + (long)split * p.Cout * p.K;
-  const int kbase = tap * (p.C1 + p.C2) + ci0;
+  const int kbase = tap * p.Ctot + p.ci_base + ci0;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -323,6 +324,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
 
 struct Plan {
   int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split, pk, phase;
+  // two-source layers whose sources allow different Cin tile widths (dec3: 256 + 64 channels) run one launch per source,
+  // each with its own widest tile (128-wide tiles feed twice the MFMAs per LDS-DMA byte of 64-wide ones): bno2 != 0
+  int bno2, variant2, tiles_ci2;
   long K;
 };
 
@@ -363,11 +367,7 @@ bool valid(const rs_conv_desc* d) {
 int largest_tile(int c) { return (c % 128 == 0) ? 128 : (c % 64 == 0) ? 64 : 32; }
 
 bool phase_ok(const rs_conv_desc* d) {
-  static const int off = [] {
-    const char* e = getenv("RS_WGRAD_PHASE");
-    return e && atoi(e) == 0;
-  }();
-  return !off && d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
+  return d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
 }
 
 Plan plan(const rs_conv_desc* d) {
@@ -376,9 +376,11 @@ Plan plan(const rs_conv_desc* d) {
   const long M = pl.phase ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo;
   pl.bmo = largest_tile(d->Cout);
   pl.bno = largest_tile(d->C1);
+  pl.bno2 = 0;
   if (d->C2 > 0) {
     const int b2 = largest_tile(d->C2);
-    if (b2 < pl.bno) pl.bno = b2;
+    if (b2 != pl.bno && b2 >= 64 && pl.bno >= 64 && pl.bmo >= 64) pl.bno2 = b2;  // one launch per source
+    else if (b2 < pl.bno) pl.bno = b2;
   }
   if (pl.bno == 32) pl.bmo = 32;
   if (pl.bmo == 32 && pl.bno == 64) pl.bno = 32;
@@ -386,18 +388,14 @@ Plan plan(const rs_conv_desc* d) {
                : pl.bmo == 64 ? (pl.bno == 128 ? V64x128 : V64x64)
                               : (pl.bno == 128 ? V32x128 : V32x32);
   pl.taps = pl.phase ? 16 : d->kh * d->kw;
-  pl.tiles_ci = (d->C1 + d->C2) / pl.bno;
+  pl.tiles_ci = (pl.bno2 ? d->C1 : d->C1 + d->C2) / pl.bno;
+  pl.tiles_ci2 = pl.bno2 ? d->C2 / pl.bno2 : 0;
+  pl.variant2 = pl.bmo == 128 ? (pl.bno2 == 128 ? V128x128 : V128x64) : (pl.bno2 == 128 ? V64x128 : V64x64);
   pl.K = (long)pl.taps * (d->C1 + d->C2);
   pl.tiles_co = d->Cout / pl.bmo;
   pl.tiles_k = pl.taps * pl.tiles_ci;
-  const long tiles = (long)pl.tiles_co * pl.tiles_k;
-  // pixels per chunk: RS_WGRAD_PK=32|64 overrides (measurement knob); 32-wide tiles only come with 64
-  static const int forced = [] {
-    const char* e = getenv("RS_WGRAD_PK");
-    return e ? atoi(e) : 0;
-  }();
-  pl.pk = (forced == 32 || forced == 64) ? forced : 64;
-  if (pl.bmo == 32 || pl.bno == 32 || pl.phase) pl.pk = 64;
+  const long tiles = (long)pl.tiles_co * pl.taps * (pl.tiles_ci + pl.tiles_ci2);
+  pl.pk = 64;  // pixels per chunk (32 was measured for the short reductions: no gain)
   const int PK = pl.pk;
   const long chunks = (M + PK - 1) / PK;
   long s = (1024 + tiles - 1) / tiles;            // aim at >= 1024 blocks ...
@@ -483,42 +481,51 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   a.M = (int)(pl.phase ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo);
   a.K = (int)pl.K;
   a.tiles_co = pl.tiles_co;
-  a.tiles_ci = pl.tiles_ci;
-  a.tiles_k = pl.tiles_k;
   a.chunks_per_split = pl.chunks_per_split;
-  const int grid = pl.tiles_co * pl.tiles_k * pl.splits;
+  a.Ctot = d->C1 + d->C2;
   hipStream_t s = (hipStream_t)stream;
-  if (pl.phase) {
-    switch (pl.variant) {
-      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
-      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
-      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
-      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
-      case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, true><<<grid, 256, 0, s>>>(a); break;
-      case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, true><<<grid, 64, 0, s>>>(a); break;
-      default: return RS_EINVAL;
+  // one launch, or one per concat source (Plan::bno2): each sees "its" source as a single-source problem whose channels
+  // start at ci_base inside the concat
+  const int nseg = pl.bno2 ? 2 : 1;
+  for (int seg = 0; seg < nseg; ++seg) {
+    int variant = pl.variant;
+    a.ci_base = 0;
+    a.tiles_ci = pl.tiles_ci;
+    if (pl.bno2) {
+      a.src1 = reinterpret_cast<const bf16_t*>(seg == 0 ? src1 : src2);
+      a.src2 = nullptr;
+      a.C1 = seg == 0 ? d->C1 : d->C2;
+      a.C2 = 0;
+      a.ci_base = seg == 0 ? 0 : d->C1;
+      a.tiles_ci = seg == 0 ? pl.tiles_ci : pl.tiles_ci2;
+      variant = seg == 0 ? pl.variant : pl.variant2;
     }
-  } else if (pl.pk == 32) {
-    switch (pl.variant) {
-      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
-      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
-      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
-      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 32, false><<<grid, 256, 0, s>>>(a); break;
-      default: return RS_EINVAL;
+    a.tiles_k = pl.taps * a.tiles_ci;
+    const int grid = pl.tiles_co * a.tiles_k * pl.splits;
+    if (pl.phase) {
+      switch (variant) {
+        case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+        case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+        case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+        case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
+        case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, true><<<grid, 256, 0, s>>>(a); break;
+        case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, true><<<grid, 64, 0, s>>>(a); break;
+        default: return RS_EINVAL;
+      }
+    } else {
+      switch (variant) {
+        case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+        case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+        case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+        case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+        case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;
+        case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, false><<<grid, 64, 0, s>>>(a); break;
+        default: return RS_EINVAL;
+      }
     }
-  } else {
-    switch (pl.variant) {
-      case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-      case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-      case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-      case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-      case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;
-      case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, false><<<grid, 64, 0, s>>>(a); break;
-      default: return RS_EINVAL;
-    }
+    const int rcl = RS_LAUNCH_RESULT();
+    if (rcl) return rcl;
   }
-  const int rc = RS_LAUNCH_RESULT();
-  if (rc) return rc;
   const long n = (long)d->Cout * pl.K;  // multiple of 4
   float* scratch = a.out + (long)pl.splits * n;
   if (!pl.phase) return rs_reduce_splits(a.out, dw, n, pl.splits, scratch, stream);

@@ -82,7 +82,7 @@ def test_train_mode_forward_without_autograd_updates_batchnorm_like_the_referenc
     net = UNet(2, pretrained=False)
     net.load_state_dict(sd)
     net = net.to(DEV)
-    x = seeded.synthetic_images(2, 3, 64, 96, seed=4)
+    x = seeded.synthetic_images(2, 3, 64, 128, seed=4)
     ref.train()
     net.train()
     with torch.no_grad():

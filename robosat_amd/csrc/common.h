@@ -82,6 +82,12 @@ __attribute__((visibility("hidden"))) int rs_wgrad_thin_plan(const rs_conv_desc*
 __attribute__((visibility("hidden"))) int rs_wgrad_thin_launch(const rs_conv_desc* d, const void* dy, const void* src,
                                                                float* partial, void* stream);
 
+// conv_thin_bf16.hip (library-internal): the bf16 decoder-tail convolutions with all taps from one LDS halo tile.
+// mode 0: 3x3 / pad 1, 32 -> 32;  1: phase form of DecoderBlock 128 -> 32 (weights from rs_pack_phase_weight_dt);
+// 2: its 4x4 / stride-2 data gradient 32 -> 128 (weights from rs_pack_dgrad_phase_weight_dt).
+__attribute__((visibility("hidden"))) int rs_conv_thin_bf16_launch(int mode, const void* src, const void* wgt, const void* mask,
+                                                                   void* out, int N, int Hs, int Ws, int relu, void* stream);
+
 // reduce.hip (library-internal): out[i] = sum over `splits` partial tiles of n floats (n % 4 == 0); `scratch` needs
 // rs_reduce_scratch_floats(n, splits) floats (may be NULL when that is 0).
 __attribute__((visibility("hidden"))) long rs_reduce_scratch_floats(long n, int splits);

@@ -102,9 +102,9 @@ extern "C" int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int to
 
 const char* const kTileNamesBf16[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
                                             "conv_igemm_bf16<64x64>", "", "conv_igemm_bf16<256x128>",
-                                            "conv_igemm_bf16<256x256>"};
-const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256};
-const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256};
+                                            "conv_igemm_bf16<256x256>", "conv_thin_bf16"};
+const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 128};
+const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 32};
 
 // Dispatcher overrides (rs_conv2d_set_tuning): process-global, for the parity tests (which must reach every tile with
 // small problems) and for A/B measurements.  -1 / 0 = the measured heuristics below.  Initialised from the environment
@@ -148,7 +148,7 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats
   const int ft = tu.tile;
   // a forced tile must be able to run the launch: N tiles whole (or the ragged 128-wide form below), 8 waves only in bf16
   // without fused statistics (the statistics' block reduction is laid out for 256 threads)
-  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
+  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && ft != TTHIN && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
       (ft != T256x256 || (es == 2 && !stats)))
     return ft;
   // 8-wave 256x256 tile (bf16, no fused statistics; one block per CU): half the LDS-DMA bytes per MFMA of the 128x128 tile,
@@ -211,6 +211,19 @@ void launch(int rowb, bool phase4, int epi, int tile, int grid, hipStream_t s, c
   else rs_conv_launch_bf16_plain_eval(tile, rowb, grid, s, a);
 }
 
+// Which all-taps kernel of conv_thin_bf16.hip runs this bf16 launch (-1: none): the 32-channel decoder tail, plain epilogue
+// (ReLU / ReLU mask only).  A forced igemm tile (rs_conv2d_set_tuning) keeps the generic kernel, for tests and A/B runs.
+int thin_mode(const rs_conv_desc* d, bool phase4, bool plain_epilogue) {
+  const int ft = tuning().tile;
+  if (!plain_epilogue || (ft != -1 && ft != TTHIN) || d->C2 != 0) return -1;
+  if (phase4) return (d->C1 == 128 && d->Cout == 32) ? 1 : -1;
+  if (d->ups != 0) return -1;
+  if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->C1 == 32 && d->Cout == 32 && d->Ho == d->Hs && d->Wo == d->Ws) return 0;
+  if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->C1 == 32 && d->Cout == 128 && 2 * d->Ho == d->Hs && 2 * d->Wo == d->Ws)
+    return 2;
+  return -1;
+}
+
 template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
@@ -222,6 +235,13 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   if (phase4 && (!phase_ok(d) || stats)) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
   constexpr long ES = (long)sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    const int tm = thin_mode(d, phase4, !scale && !shift && !residual && !stats && !out2);
+    if (tm >= 0) {
+      const int rc = rs_conv_thin_bf16_launch(tm, src1, weight, relu_mask, out, d->N, d->Hs, d->Ws, d->relu, stream);
+      if (rc != RS_EINVAL) return rc;  // (RS_EINVAL: the launch does not fit its 32-bit offsets -> generic kernel)
+    }
+  }
   ConvArgsT<T> a;
   a.src1 = reinterpret_cast<const T*>(src1);
   a.src2 = reinterpret_cast<const T*>(src2);
@@ -318,6 +338,11 @@ extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* 
   if (!valid(d) || (es != 2 && es != 4) || (phase4 && !phase_ok(d))) return RS_EINVAL;
   const int kc128 = 128 / es;
   const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
+  if (es == 2 && thin_mode(d, phase4 != 0, true) >= 0) {  // (as for a launch with a plain epilogue)
+    if (tile) *tile = TTHIN;
+    if (rowb) *rowb = d->C1 * 2;
+    return 0;
+  }
   if (tile) *tile = pick_tile(d, phase4 != 0, es);
   if (rowb) *rowb = (can128 && pick_rowb(d, es, phase4 != 0) == 128) ? 128 : 64;
   return 0;

@@ -13,7 +13,8 @@ enum { EPI_EVAL = 0, EPI_STATS = 1, EPI_BWD = 2 };
 constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 data gradient of an upsampled 3x3)
 // (index 4 is the fp32 stem kernel of conv_igemm.hip: the two files share the index space of rs_conv2d_tile_name)
 // T256x256: 8-wave blocks, one per CU, bf16 only (see pick_tile); T256x128: 8 waves as 4 x 2 (64x64 wave tiles)
-enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, NTILES };
+// TTHIN: the all-taps kernels of conv_thin_bf16.hip (the 32-channel decoder tail in bf16), reported through the same index space
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, TTHIN, NTILES };
 
 template <typename T>
 struct ConvArgsT {

@@ -1,0 +1,331 @@
+// The THIN convolutions of the decoder tail in bf16, all filter taps from one LDS halo tile, weights resident in registers.
+//
+//   dec5  ConvRelu 32 -> 32 3x3 at full resolution (reference robosat/unet.py:107,139)  and its data gradient   MODE 3x3
+//   dec4  DecoderBlock 128 -> 32 behind the nearest-x2 upsample (unet.py:106,138) in phase form:
+//         the four parity-specific 2x2 convolutions on the source grid (rs_pack_phase_weight)                   MODE PHASE
+//   dec4  data gradient: the 4x4 / stride-2 convolution 32 -> 128 over dz (rs_pack_dgrad_phase_weight)          MODE DG4
+//
+// These layers hold 14 % of the forward FLOPs but move the two largest activations of the network (32 channels at 512^2).
+// In bf16 they are HBM-bound by a wide margin (~150 flop/B against a machine balance of ~400), yet the generic implicit-GEMM
+// kernel (conv_igemm_dma_kernel.h) re-gathers every input pixel once per filter tap through L2 -> LDS (9x / 4x / 16x the
+// input bytes) and re-streams the weights for every 128-pixel tile: it runs at the ~12 TB/s the CUs' vector-memory path
+// sustains, i.e. 1.5-2.6 TB/s of useful traffic.  Here:
+//
+//   weights   live in REGISTERS for the whole launch: a wave's share is taps x Cin/16 MFMA operand fragments (18 or 32
+//             x 4 VGPRs) loaded once; blocks are persistent (one per CU) and walk patches of the image.
+//   input     per patch ONE halo tile (patch + filter border, pixel-major rows as they lie in HBM) is copied to LDS by
+//             LDS-DMA (buffer_load ... lds; out-of-image rows = out-of-range offsets = zeros), double buffered: the next
+//             patch's halo streams in between the MFMAs of the current one.  Every tap is then just an LDS row offset in
+//             the fragment read -- nothing is fetched twice.  In phase form the four output parities share the halo:
+//             wave w computes parity w from the same source pixels.
+//   MFMA      v_mfma_f32_32x32x16_bf16, D[i = cout][j = pixel]: the weight fragment is the A operand, four 32-pixel
+//             sub-tiles per wave.
+//   output    accumulators -> bf16 patch image in LDS (16-byte pieces XOR-swizzled by pixel) -> whole contiguous rows of
+//             the NHWC output with 16-byte stores, ReLU / ReLU-mask applied on the way out.
+//
+// Traffic per launch = input once (x 1.2-1.4 halo overlap) + output once (+ the mask once).
+#include "common.h"
+
+namespace {
+
+enum { THIN_33 = 0, THIN_PHASE = 1, THIN_DG4 = 2 };
+
+struct ThinConvArgs {
+  const bf16_t* src;   // [N][Hs][Ws][CIN]
+  const bf16_t* wgt;   // 3x3: [32][3][3][32] | PHASE: [4][32][2][2][128] | DG4: [128][4][4][32]
+  const bf16_t* mask;  // optional, shaped like out: result zeroed where mask <= 0
+  bf16_t* out;         // [N][Ho][Wo][COUT]
+  int N, Hs, Ws, Ho, Wo;
+  int relu;
+  int ppx, ppi, total;  // patches per row of the base grid / per image / in all
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tc_make_rsrc(const void* base, long bytes) {
+  const unsigned int n = bytes > 0x7FFF0000L ? 0x7FFF0000u : (unsigned int)(bytes < 0 ? 0 : bytes);
+  const unsigned long b = (unsigned long)base;  // (descriptor inputs made provably wave-uniform: cdna_hip_programming.md T20)
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b), hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+
+constexpr int kThinOOB = (int)0x80000000u;  // beyond every descriptor tc_make_rsrc builds: the DMA writes zeros
+
+// One LDS-DMA wave instruction: lane l's 16 bytes at buffer offset `voff` land at LDS byte `lds_dst` + 16*l (see rb_dma16s in
+// conv_igemm_dma_kernel.h for why this is inline asm and why m0 is a clobber).
+__device__ __forceinline__ void tc_dma16(__amdgpu_buffer_rsrc_t r, unsigned int lds_dst, int voff) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %2, 0 offen lds"
+      :
+      : "v"(voff), "s"(lds_dst), "s"(r)
+      : "memory", "m0");
+}
+__device__ __forceinline__ void tc_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned int tc_lds_addr(const void* p) {
+  return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int MODE>
+struct ThinGeom;
+template <>
+struct ThinGeom<THIN_33> {  // base grid = output grid; patch 16 x 32 pixels; sub-tile = one patch row
+  static constexpr int CIN = 32, COUT = 32, NTAP = 9, PH = 16, PW = 32, HALO_H = 18, HALO_W = 34;
+  static constexpr int OUT_ROWS = 16, OUT_PX = 32;  // output patch: rows x pixels per row
+};
+template <>
+struct ThinGeom<THIN_PHASE> {  // base grid = source grid; patch 8 x 16 source pixels -> 16 x 32 output pixels
+  static constexpr int CIN = 128, COUT = 32, NTAP = 4, PH = 8, PW = 16, HALO_H = 10, HALO_W = 18;
+  static constexpr int OUT_ROWS = 16, OUT_PX = 32;
+};
+template <>
+struct ThinGeom<THIN_DG4> {  // base grid = output grid (half the resolution of dz); patch 8 x 16 pixels
+  static constexpr int CIN = 32, COUT = 128, NTAP = 16, PH = 8, PW = 16, HALO_H = 18, HALO_W = 34;
+  static constexpr int OUT_ROWS = 8, OUT_PX = 16;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
+  typedef ThinGeom<MODE> G;
+  constexpr int CIN = G::CIN, COUT = G::COUT, NTAP = G::NTAP;
+  constexpr int ROWB = CIN * 2;             // bytes per halo pixel
+  constexpr int CPR = ROWB / 16;            // 16-byte pieces per halo row
+  constexpr int RI = 64 / CPR;              // halo rows per DMA instruction (1 KiB)
+  constexpr int KS = CIN / 16;              // MFMA k-steps per tap
+  constexpr int NF = NTAP * KS;             // weight fragments per wave
+  constexpr int HROWS = G::HALO_H * G::HALO_W;
+  constexpr int NINSTR = (HROWS + RI - 1) / RI;
+  constexpr int NJ = (NINSTR + 3) / 4;      // DMA instructions per wave per patch
+  constexpr int HALOB = NINSTR * 1024;
+  constexpr int OROWB = G::OUT_PX * COUT * 2;  // bytes per output patch row
+  constexpr int STAGEB = G::OUT_ROWS * OROWB;  // 32 KiB in every mode
+  constexpr int OPP = COUT / 8;                // 16-byte pieces per output pixel
+  static_assert(STAGEB == 32768, "output patch image");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HALOB + STAGEB + NINSTR * 64 * 4];
+  unsigned char* stage = smem + 2 * HALOB;
+  int* dtab = reinterpret_cast<int*>(smem + 2 * HALOB + STAGEB);  // per (DMA instruction, lane): hy << 20 | hx << 8 | piece, or -1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // ---- DMA lane constants (independent of the patch): halo row R = RI*ii + lane/CPR holds source pixel (R / HALO_W,
+  //      R % HALO_W) of the halo; LDS position pp = lane % CPR receives channel piece pp ^ swz(R) (the swizzle lives on the
+  //      SOURCE address: the DMA image is lane-linear).  swz: 64-byte rows (R >> 2) & 3, 256-byte rows R & 15.
+  for (int e = tid; e < NINSTR * 64; e += 256) {
+    const int ii = e >> 6, l = e & 63;
+    const int R = RI * ii + l / CPR, pp = l % CPR;
+    const int f = CPR == 4 ? ((R >> 2) & 3) : (R & 15);
+    dtab[e] = R < HROWS ? ((R / G::HALO_W) << 20) | ((R % G::HALO_W) << 8) | (pp ^ f) : -1;
+  }
+
+  // ---- this wave's weights -> registers: NF fragments of [32 rows][16 k]; lane holds row l31, k = 8*hi .. 8*hi + 7
+  u32x4 wf[NF];
+  {
+    const bf16_t* wbase;
+    if (MODE == THIN_33) wbase = p.wgt + (long)l31 * NTAP * CIN;                       // [cout][tap][cin]
+    else if (MODE == THIN_PHASE) wbase = p.wgt + ((long)wave * 32 + l31) * NTAP * CIN;  // [phase = wave][cout][tap][cin]
+    else wbase = p.wgt + ((long)wave * 32 + l31) * NTAP * CIN;                          // [cout = 32*wave + ..][tap][cin]
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wf[f] = *reinterpret_cast<const u32x4*>(wbase + (f / KS) * CIN + (f % KS) * 16 + 8 * hi);
+  }
+
+  const __amdgpu_buffer_rsrc_t rsrc = tc_make_rsrc(p.src, (long)p.N * p.Hs * p.Ws * ROWB);
+  const unsigned int lds0 = __builtin_amdgcn_readfirstlane(tc_lds_addr(smem));
+
+  // patch -> (image, base-grid origin, halo origin in source coordinates)
+  int pn = 0, by0 = 0, bx0 = 0, hy0 = 0, hx0 = 0;
+  auto locate = [&](int patch) __attribute__((always_inline)) {
+    pn = patch / p.ppi;
+    const int rem = patch - pn * p.ppi;
+    const int py = rem / p.ppx, px = rem - py * p.ppx;
+    by0 = py * G::PH;
+    bx0 = px * G::PW;
+    hy0 = MODE == THIN_DG4 ? 2 * by0 - 1 : by0 - 1;
+    hx0 = MODE == THIN_DG4 ? 2 * bx0 - 1 : bx0 - 1;
+  };
+  bool live = true;  // false once there is no next patch: the pieces are still issued (no branch between the MFMAs: a diamond
+                     // there makes hipcc keep two copies of the accumulators), out of range, into the buffer nobody reads
+  auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {
+    const int ii = wave + 4 * j;  // wave-uniform
+    if (ii < NINSTR) {  // (compile-time for all but the last j)
+      const int c = dtab[ii * 64 + lane];
+      const int sy = hy0 + (c >> 20), sx = hx0 + ((c >> 8) & 0xFFF);
+      const bool ok = live && c >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      const int voff = ok ? (((pn * p.Hs + sy) * p.Ws + sx) * ROWB + (c & 0xFF) * 16) : kThinOOB;
+      tc_dma16(rsrc, lds0 + buf * HALOB + ii * 1024, voff);
+    }
+  };
+
+  // ---- fragment addressing: sub-tile t of this wave, lane pixel (sy, sx) on the patch; halo row of tap (r, s) = baseR + r*HALO_W + s
+  int baseR[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (MODE == THIN_33) baseR[t] = (4 * wave + t) * G::HALO_W + l31;
+    else if (MODE == THIN_PHASE) baseR[t] = (2 * t + (l31 >> 4) + (wave >> 1)) * G::HALO_W + (l31 & 15) + (wave & 1);
+    else baseR[t] = (2 * (2 * t + (l31 >> 4))) * G::HALO_W + 2 * (l31 & 15);
+  }
+  // ---- staging addressing: where this lane's 4 consecutive couts (registers 4g .. 4g+3) of sub-tile t go
+  int sbase[4];  // byte offset of the pixel in the staged patch image; spx = swizzle key of the pixel
+  int sswz[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int row, col;
+    if (MODE == THIN_33) {
+      row = 4 * wave + t;
+      col = l31;
+    } else if (MODE == THIN_PHASE) {
+      row = 2 * (2 * t + (l31 >> 4)) + (wave >> 1);
+      col = 2 * (l31 & 15) + (wave & 1);
+    } else {
+      row = 2 * t + (l31 >> 4);
+      col = l31 & 15;
+    }
+    sbase[t] = row * OROWB + col * COUT * 2;
+    sswz[t] = OPP == 4 ? ((col >> 1) & 3) : (col & 15);
+  }
+
+  __syncthreads();  // dtab ready
+
+  int patch = blockIdx.x;
+  int buf = 0;
+  if (patch < p.total) {
+    locate(patch);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) issue_piece(j, 0);
+  }
+  while (patch < p.total) {
+    tc_dma_wait();     // this wave's pieces of the halo have landed ...
+    __syncthreads();   // ... everybody's have; and the previous patch's staged output has been written out
+    const int on = pn, oy0 = (MODE == THIN_PHASE ? 2 : 1) * by0, ox0 = (MODE == THIN_PHASE ? 2 : 1) * bx0;  // output origin
+    const int next = patch + gridDim.x;
+    live = next < p.total;
+    if (live) locate(next);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const unsigned char* H = smem + buf * HALOB;
+    constexpr int NMMA = NF * 4;
+    constexpr int PSTEP = NMMA / (2 * NJ) >= 1 ? NMMA / (2 * NJ) : 1;  // next halo's DMA pieces between the MFMAs, front-loaded
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      constexpr int TW = MODE == THIN_33 ? 3 : (MODE == THIN_PHASE ? 2 : 4);
+      const int toff = (tap / TW) * G::HALO_W + (tap % TW);
+      int rowoff[4], f[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int R = baseR[t] + toff;
+        rowoff[t] = R * ROWB;
+        f[t] = CPR == 4 ? ((R >> 2) & 3) : (R & 15);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const u32x4*>(H + rowoff[t] + (((2 * ks + hi) ^ f[t]) * 16));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int q = (tap * KS + ks) * 4 + t;  // MFMA index within the patch (compile-time after unrolling)
+          if (q % PSTEP == 0 && q / PSTEP < NJ) issue_piece(q / PSTEP, buf ^ 1);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[tap * KS + ks]), __builtin_bit_cast(bf16x8, a[t]),
+                                                           acc[t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = (NMMA + PSTEP - 1) / PSTEP; j < NJ; ++j) issue_piece(j, buf ^ 1);
+
+    // ---- stage: D[i = cout][j = pixel], lane holds couts (r&3) + 8*(r>>2) + 4*hi of pixel l31 -> 8-byte groups of 4 couts
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v;
+        v[0] = (bf16_t)acc[t][4 * g + 0];
+        v[1] = (bf16_t)acc[t][4 * g + 1];
+        v[2] = (bf16_t)acc[t][4 * g + 2];
+        v[3] = (bf16_t)acc[t][4 * g + 3];
+        const int piece = (MODE == THIN_DG4 ? 4 * wave : 0) + g;  // logical 16-byte piece of the pixel (8 couts)
+        *reinterpret_cast<bf16x4*>(stage + sbase[t] + ((piece ^ sswz[t]) * 16) + hi * 8) = v;
+      }
+    __syncthreads();
+
+    // ---- write out: the staged patch is OUT_ROWS rows of OROWB contiguous output bytes
+    constexpr int PPR = OROWB / 16;  // pieces per patch row
+#pragma unroll
+    for (int k = 0; k < STAGEB / 16 / 256; ++k) {
+      const int e = tid + 256 * k;
+      const int row = e / PPR, within = e - row * PPR;
+      const int px = within / OPP, pp = within - px * OPP;
+      const int piece = pp ^ (OPP == 4 ? ((px >> 1) & 3) : (px & 15));  // logical piece stored at position pp
+      const int oy = oy0 + row, ox = ox0 + px;
+      if (oy < p.Ho && ox < p.Wo) {
+        const long o = (((long)on * p.Ho + oy) * p.Wo + ox) * COUT + piece * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + row * OROWB + within * 16);
+        if (p.relu) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = (float)v[c] > 0.f ? v[c] : (bf16_t)0.f;
+        }
+        if (p.mask) {
+          const bf16x8 z = *reinterpret_cast<const bf16x8*>(p.mask + o);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = (float)z[c] > 0.f ? v[c] : (bf16_t)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      }
+    }
+    patch = next;
+    buf ^= 1;
+  }
+}
+
+}  // namespace
+
+// mode: 0 = 3x3 32 -> 32 (pad 1), 1 = phase form 128 -> 32 (output 2Hs x 2Ws), 2 = 4x4/s2 data gradient 32 -> 128 (output
+// Hs/2 x Ws/2).  Returns RS_EINVAL when the launch does not fit (the caller then takes the generic kernel).
+int rs_conv_thin_bf16_launch(int mode, const void* src, const void* wgt, const void* mask, void* out, int N, int Hs, int Ws, int relu,
+                             void* stream) {
+  if (!src || !wgt || !out || N <= 0 || Hs <= 0 || Ws <= 0) return RS_EINVAL;
+  ThinConvArgs a;
+  a.src = reinterpret_cast<const bf16_t*>(src);
+  a.wgt = reinterpret_cast<const bf16_t*>(wgt);
+  a.mask = reinterpret_cast<const bf16_t*>(mask);
+  a.out = reinterpret_cast<bf16_t*>(out);
+  a.N = N;
+  a.Hs = Hs;
+  a.Ws = Ws;
+  a.relu = relu;
+  int bh, bw, ph, pw;  // base grid, patch
+  long in_bytes;
+  if (mode == THIN_33) {
+    a.Ho = Hs, a.Wo = Ws, bh = Hs, bw = Ws, ph = 16, pw = 32, in_bytes = (long)N * Hs * Ws * 64;
+  } else if (mode == THIN_PHASE) {
+    a.Ho = 2 * Hs, a.Wo = 2 * Ws, bh = Hs, bw = Ws, ph = 8, pw = 16, in_bytes = (long)N * Hs * Ws * 256;
+  } else if (mode == THIN_DG4) {
+    if ((Hs & 1) || (Ws & 1)) return RS_EINVAL;
+    a.Ho = Hs / 2, a.Wo = Ws / 2, bh = Hs / 2, bw = Ws / 2, ph = 8, pw = 16, in_bytes = (long)N * Hs * Ws * 64;
+  } else {
+    return RS_EINVAL;
+  }
+  if (in_bytes >= 0x7FFF0000L) return RS_EINVAL;  // 32-bit DMA offsets over the whole input tensor
+  a.ppx = rs_cdiv(bw, pw);
+  a.ppi = a.ppx * rs_cdiv(bh, ph);
+  const long total = (long)a.ppi * N;
+  if (total >= (1L << 31)) return RS_EINVAL;
+  a.total = (int)total;
+  const int grid = a.total < 256 ? a.total : 256;  // persistent: one block per CU
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == THIN_33) conv_thin_bf16<THIN_33><<<grid, 256, 0, s>>>(a);
+  else if (mode == THIN_PHASE) conv_thin_bf16<THIN_PHASE><<<grid, 256, 0, s>>>(a);
+  else conv_thin_bf16<THIN_DG4><<<grid, 256, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}

@@ -115,7 +115,7 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     if PROFILE is not None:
         ev1.record()
         name = conv_tile_name(d, bf)
-        if alg_scale != 1.0:  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
+        if alg_scale != 1.0 and not name.startswith("conv_thin"):  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                 conv_bytes(d, 2 if bf else 4, (residual is not None) + (relu_mask is not None)), conv_flops(d))
@@ -327,10 +327,12 @@ def conv_tile_name(d, bf16=False, phase=False):
     tile, rowb = ctypes.c_int(0), ctypes.c_int(0)
     check(lib.rs_conv2d_config(ctypes.byref(d), 2 if bf16 else 4, int(phase), ctypes.byref(tile), ctypes.byref(rowb)), "rs_conv2d_config")
     base = (lib.rs_conv2d_tile_name_bf16 if bf16 else lib.rs_conv2d_tile_name)(tile.value).decode()
+    if tile.value == TILES["thin"]:  # conv_thin_bf16.hip: named by the form it computes
+        return "{}<{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"))
     return base.replace("<", "<phase," if phase else "<").replace(">", ",r{}>".format(rowb.value))
 
 
-TILES = {"128x128": 0, "128x64": 1, "128x32": 2, "64x64": 3, "256x128": 5, "256x256": 6}
+TILES = {"128x128": 0, "128x64": 1, "128x32": 2, "64x64": 3, "256x128": 5, "256x256": 6, "thin": 7}
 
 
 class tuning:

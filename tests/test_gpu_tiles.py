@@ -35,6 +35,7 @@ for _dt in ("f32", "bf16"):
             for _form in ("", "phase,", "dgrad4x4,"):
                 COVERED.add("conv_igemm_{}<{}{},r{}>".format(_dt, _form, _t, _r))
 # non-implicit-GEMM symbols of the step have their own parity tests (test_gpu_ops / test_gpu_train_ops / test_gpu_bf16)
+COVERED |= {"conv_thin_bf16<3x3>", "conv_thin_bf16<phase>", "conv_thin_bf16<dgrad4x4>"}  # test_thin_* below
 COVERED |= {"conv_igemm_f32<128x64,stem>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_bf16", "conv_wgrad_thin_bf16",
             "conv_wgrad_bf16<phase>", "conv_wgrad_f32"}
 
@@ -193,6 +194,66 @@ def test_ragged_last_n_tile_with_split_store(dtype, rowb):
         d1, d2 = ops.conv2d_split(xd, wd, c1, pad=1, mask1=nhwc(m1, dtype), mask2=nhwc(m2, dtype))
         close(nchw(d1), want[:, :c1] * (m1 > 0), dtype, "ragged split 1")
         close(nchw(d2), want[:, c1:] * (m2 > 0), dtype, "ragged split 2")
+
+
+THIN_SHAPES = [(2, 40, 72), (1, 16, 32), (5, 256, 256), (1, 24, 8)]  # edges in both directions; > 256 patches (persistent loop); tiny
+
+
+@pytest.mark.parametrize("n,h,w", THIN_SHAPES)
+def test_thin_3x3_c32_all_taps_kernel(n, h, w):
+    """dec5 (ConvRelu 32 -> 32, unet.py:107,139) and its data gradient on the all-taps kernel (conv_thin_bf16.hip): ReLU and
+    ReLU-mask epilogues vs fp32 PyTorch on the same bf16 operands, and vs the generic kernel forced on the same launch."""
+    from robosat_amd import ops
+
+    x = prep(rnd(n, 32, h, w, seed=31), BF)
+    wt = prep(rnd(32, 32, 3, 3, seed=32) * 0.08, BF)
+    mask = prep(rnd(n, 32, h, w, seed=33), BF)
+    xd, wd, md = nhwc(x, BF), krsc(wt, BF), nhwc(mask, BF)
+    assert ops.conv_tile_name(ops.conv_desc(xd, wd, pad=1), True) == "conv_thin_bf16<3x3>"
+    want = F.conv2d(x, wt, padding=1)
+    got = ops.conv2d(xd, wd, pad=1, relu=True)
+    close(nchw(got), F.relu(want), BF, "relu")
+    gotm = ops.conv2d(xd, wd, pad=1, relu_mask=md)
+    close(nchw(gotm), want * (mask > 0), BF, "mask")
+    plain = ops.conv2d(xd, wd, pad=1)
+    with ops.tuning("128x32", 64):  # the generic implicit-GEMM kernel on the same launch: same values up to one bf16 rounding
+        assert ops.conv_tile_name(ops.conv_desc(xd, wd, pad=1), True) == "conv_igemm_bf16<128x32,r64>"
+        ref = ops.conv2d(xd, wd, pad=1)
+    assert float((plain.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+    # a launch with a scale / residual epilogue is not the thin kernel's: it must fall through to the generic one
+    sc = torch.rand(32, device=DEV) + 0.5
+    close(nchw(ops.conv2d(xd, wd, pad=1, scale=sc, shift=torch.zeros(32, device=DEV))), want * sc.cpu().view(1, -1, 1, 1), BF, "scaled")
+
+
+@pytest.mark.parametrize("n,hs,ws", [(2, 20, 36), (1, 8, 16), (5, 128, 128), (1, 12, 4)])
+def test_thin_phase_c128_and_its_4x4_gradient(n, hs, ws):
+    """dec4 (DecoderBlock 128 -> 32, unet.py:106,138): phase form with the four parities sharing one source halo, and the
+    4x4 / stride-2 data gradient 32 -> 128 with the ReLU mask of dec3 -- against autograd on the reference formulation."""
+    from robosat_amd import _lib, ops
+
+    a = prep(rnd(n, 128, hs, ws, seed=34), BF).requires_grad_(True)
+    wt = rnd(32, 128, 3, 3, seed=35) * (2.0 / (128 * 9)) ** 0.5
+    y = F.relu(F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), wt, padding=1))
+    gy = prep(rnd(*y.shape, seed=36), BF)
+    y.backward(gy)
+    w_krsc = krsc(wt, torch.float32)
+    ad = nhwc(a.detach(), BF)
+    d = _lib.ConvDesc(n, hs, ws, 128, 0, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, 32, 1, 0)
+    assert ops.conv_tile_name(d, True, phase=True) == "conv_thin_bf16<phase>"
+    got = ops.conv2d_phase(ad, ops.pack_phase_weight(w_krsc, BF), relu=True)
+    close(nchw(got), y.detach(), BF, "phase fwd")
+    dz = gy * (y.detach() > 0)
+    wd = ops.pack_dgrad_phase_weight(w_krsc, BF)
+    dzd = nhwc(dz, BF)
+    assert ops.conv_tile_name(ops.conv_desc(dzd, wd, stride=2, pad=1, out_hw=(hs, ws)), True) == "conv_thin_bf16<dgrad4x4>"
+    m = prep(rnd(n, 128, hs, ws, seed=37), BF)
+    gsrc = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws), relu_mask=nhwc(m, BF), alg_scale=2.25)
+    close(nchw(gsrc), a.grad * (m > 0), BF, "dgrad4x4 + mask")
+    with ops.tuning("128x128", 64):
+        ref = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws), relu_mask=nhwc(m, BF))
+        refp = ops.conv2d_phase(ad, ops.pack_phase_weight(w_krsc, BF), relu=True)
+    assert float((gsrc.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+    assert float((got.float() - refp.float()).abs().max()) <= 2 ** -7 * float(refp.float().abs().max())
 
 
 def test_dispatcher_reaches_the_8_wave_tile_unforced():

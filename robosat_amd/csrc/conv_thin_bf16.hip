@@ -199,9 +199,13 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) issue_piece(j, 0);
   }
+  tc_dma_wait();  // (first halo: this wave's pieces)
   while (patch < p.total) {
-    tc_dma_wait();     // this wave's pieces of the halo have landed ...
-    __syncthreads();   // ... everybody's have; and the previous patch's staged output has been written out
+    // Every wave waited for ITS pieces of this halo before it got here (above; below, ahead of the write-out): the barrier
+    // makes that everybody's -- and says the previous patch's staged output has been read out.  The wait sits BEFORE the
+    // output stores on purpose: at the loop top it would also wait for those stores (vmcnt counts them), one HBM write
+    // round trip per patch; there it finds the DMA issued during the MFMAs long landed, and the stores overlap the next patch.
+    __syncthreads();
     const int on = pn, oy0 = (MODE == THIN_PHASE ? 2 : 1) * by0, ox0 = (MODE == THIN_PHASE ? 2 : 1) * bx0;  // output origin
     const int next = patch + gridDim.x;
     live = next < p.total;
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
         const int piece = (MODE == THIN_DG4 ? 4 * wave : 0) + g;  // logical 16-byte piece of the pixel (8 couts)
         *reinterpret_cast<bf16x4*>(stage + sbase[t] + ((piece ^ sswz[t]) * 16) + hi * 8) = v;
       }
+    tc_dma_wait();  // the next halo's pieces (this wave's)
     __syncthreads();
 
     // ---- write out: the staged patch is OUT_ROWS rows of OROWB contiguous output bytes

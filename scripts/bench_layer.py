@@ -71,7 +71,9 @@ for spec in a.specs:
         xs = rot((n, 2 * h, 2 * w, c1), dt, n * 4 * h * w * c1 * es)
         wt = (torch.randn(cout, 4, 4, c1, device=dev) * 0.02).to(dt)
         fn = lambda x: ops.conv2d(x, wt, stride=2, pad=1, out_hw=(h, w))
-        name = lambda: ops.conv_tile_name(ops.conv_desc(xs[0], wt, stride=2, pad=1, out_hw=(h, w)), es == 2).replace("<", "<dgrad4x4,")
+        def name():
+            nm = ops.conv_tile_name(ops.conv_desc(xs[0], wt, stride=2, pad=1, out_hw=(h, w)), es == 2)
+            return nm if nm.startswith("conv_thin") else nm.replace("<", "<dgrad4x4,")
         flops = 2.0 * n * h * w * cout * c1 * 16
         nbytes = es * (n * 4 * h * w * c1 + n * h * w * cout)
     else:

@@ -14,14 +14,17 @@
 //   weights   live in REGISTERS for the whole launch: a wave's share is taps x Cin/16 MFMA operand fragments (18 or 32
 //             x 4 VGPRs) loaded once; blocks are persistent (one per CU) and walk patches of the image.
 //   input     per patch ONE halo tile (patch + filter border, pixel-major rows as they lie in HBM) is copied to LDS by
-//             LDS-DMA (buffer_load ... lds; out-of-image rows = out-of-range offsets = zeros), double buffered: the next
-//             patch's halo streams in between the MFMAs of the current one.  Every tap is then just an LDS row offset in
+//             LDS-DMA (buffer_load ... lds; out-of-image rows = out-of-range offsets = zeros) into a ring of three: the
+//             halo two patches ahead is issued between the MFMAs of the current one, so two halos (~80-90 KB per CU) are
+//             in flight -- with one block per CU that is what covers the HBM round trip (one halo ahead ran at 2 TB/s).  Every tap is then just an LDS row offset in
 //             the fragment read -- nothing is fetched twice.  In phase form the four output parities share the halo:
 //             wave w computes parity w from the same source pixels.
 //   MFMA      v_mfma_f32_32x32x16_bf16, D[i = cout][j = pixel]: the weight fragment is the A operand, four 32-pixel
 //             sub-tiles per wave.
-//   output    accumulators -> bf16 patch image in LDS (16-byte pieces XOR-swizzled by pixel) -> whole contiguous rows of
-//             the NHWC output with 16-byte stores, ReLU / ReLU-mask applied on the way out.
+//   output    accumulators -> bf16 patch image staged in the patch's own, consumed halo slot (16-byte pieces XOR-swizzled by
+//             pixel) -> whole contiguous rows of the NHWC output with 16-byte stores, ReLU / ReLU-mask applied on the way
+//             out; the mask patch arrives by LDS-DMA as well (a register load would sit behind the in-flight halos in
+//             the compiler's vmcnt bookkeeping and drain them).
 //
 // Traffic per launch = input once (x 1.2-1.4 halo overlap) + output once (+ the mask once).
 #include "common.h"
@@ -87,6 +90,11 @@ struct ThinGeom<THIN_DG4> {  // base grid = output grid (half the resolution of 
   static constexpr int OUT_ROWS = 8, OUT_PX = 16;
 };
 
+template <int N>
+__device__ __forceinline__ void tc_dma_wait_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   typedef ThinGeom<MODE> G;
@@ -97,17 +105,21 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   constexpr int KS = CIN / 16;              // MFMA k-steps per tap
   constexpr int NF = NTAP * KS;             // weight fragments per wave
   constexpr int HROWS = G::HALO_H * G::HALO_W;
-  constexpr int NINSTR = (HROWS + RI - 1) / RI;
-  constexpr int NJ = (NINSTR + 3) / 4;      // DMA instructions per wave per patch
+  constexpr int NJ = ((HROWS + RI - 1) / RI + 3) / 4;  // DMA instructions per wave per halo (every wave issues exactly NJ:
+  constexpr int NINSTR = 4 * NJ;                       // the counted vmcnt waits need that; surplus rows are out of range)
   constexpr int HALOB = NINSTR * 1024;
+  constexpr int NB = 3;                        // halo ring: patch i computes, i+1 has landed or is landing, i+2 is issued
   constexpr int OROWB = G::OUT_PX * COUT * 2;  // bytes per output patch row
-  constexpr int STAGEB = G::OUT_ROWS * OROWB;  // 32 KiB in every mode
+  constexpr int STAGEB = G::OUT_ROWS * OROWB;  // 32 KiB in every mode: staged in the patch's own (consumed) halo buffer
   constexpr int OPP = COUT / 8;                // 16-byte pieces per output pixel
-  static_assert(STAGEB == 32768, "output patch image");
+  constexpr bool HAS_MASK = MODE != THIN_PHASE;  // (the forward DecoderBlock has no ReLU mask)
+  constexpr int MASKB = HAS_MASK ? STAGEB : 0;   // the patch of the mask tensor, by DMA like the halo (no VGPR round trip)
+  constexpr int NM = STAGEB / 1024 / 4;          // mask DMA instructions per wave
+  static_assert(STAGEB == 32768 && STAGEB <= HALOB, "output patch image fits a halo buffer");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HALOB + STAGEB + NINSTR * 64 * 4];
-  unsigned char* stage = smem + 2 * HALOB;
-  int* dtab = reinterpret_cast<int*>(smem + 2 * HALOB + STAGEB);  // per (DMA instruction, lane): hy << 20 | hx << 8 | piece, or -1
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NB * HALOB + MASKB + NINSTR * 64 * 2];
+  unsigned char* maskbuf = smem + NB * HALOB;
+  short* dtab = reinterpret_cast<short*>(smem + NB * HALOB + MASKB);  // per (DMA instruction, lane): hy << 10 | hx << 4 | piece, or -1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
     const int ii = e >> 6, l = e & 63;
     const int R = RI * ii + l / CPR, pp = l % CPR;
     const int f = CPR == 4 ? ((R >> 2) & 3) : (R & 15);
-    dtab[e] = R < HROWS ? ((R / G::HALO_W) << 20) | ((R % G::HALO_W) << 8) | (pp ^ f) : -1;
+    dtab[e] = R < HROWS ? (short)(((R / G::HALO_W) << 10) | ((R % G::HALO_W) << 4) | (pp ^ f)) : (short)-1;
   }
 
   // ---- this wave's weights -> registers: NF fragments of [32 rows][16 k]; lane holds row l31, k = 8*hi .. 8*hi + 7
@@ -136,30 +148,47 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   }
 
   const __amdgpu_buffer_rsrc_t rsrc = tc_make_rsrc(p.src, (long)p.N * p.Hs * p.Ws * ROWB);
+  const __amdgpu_buffer_rsrc_t rsrc_mask = tc_make_rsrc(p.mask ? (const void*)p.mask : (const void*)p.src,
+                                                        p.mask ? (long)p.N * p.Ho * p.Wo * COUT * 2 : 0);
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane(tc_lds_addr(smem));
 
-  // patch -> (image, base-grid origin, halo origin in source coordinates)
-  int pn = 0, by0 = 0, bx0 = 0, hy0 = 0, hx0 = 0;
-  auto locate = [&](int patch) __attribute__((always_inline)) {
-    pn = patch / p.ppi;
-    const int rem = patch - pn * p.ppi;
-    const int py = rem / p.ppx, px = rem - py * p.ppx;
-    by0 = py * G::PH;
-    bx0 = px * G::PW;
-    hy0 = MODE == THIN_DG4 ? 2 * by0 - 1 : by0 - 1;
-    hx0 = MODE == THIN_DG4 ? 2 * bx0 - 1 : bx0 - 1;
+  // patch -> (image, base-grid origin); halo origin in source coordinates, output origin
+  struct Where {
+    int n, by0, bx0;
+    bool live;
   };
-  bool live = true;  // false once there is no next patch: the pieces are still issued (no branch between the MFMAs: a diamond
-                     // there makes hipcc keep two copies of the accumulators), out of range, into the buffer nobody reads
-  auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {
+  auto locate = [&](int patch) __attribute__((always_inline)) {
+    Where w;
+    w.live = patch < p.total;
+    const int pc = w.live ? patch : 0;
+    w.n = pc / p.ppi;
+    const int rem = pc - w.n * p.ppi;
+    const int py = rem / p.ppx;
+    w.by0 = py * G::PH;
+    w.bx0 = (rem - py * p.ppx) * G::PW;
+    return w;
+  };
+  // Halo piece j of this wave for patch `w` into ring slot `slot`.  A patch past the end still issues its pieces -- out of
+  // range, zeros into a slot nobody reads: no branch between the MFMAs (a diamond there makes hipcc keep two copies of the
+  // accumulators) and the same DMA count in every wave and iteration (the counted waits rely on it).
+  auto issue_piece = [&](int j, int slot, const Where& w) __attribute__((always_inline)) {
     const int ii = wave + 4 * j;  // wave-uniform
-    if (ii < NINSTR) {  // (compile-time for all but the last j)
-      const int c = dtab[ii * 64 + lane];
-      const int sy = hy0 + (c >> 20), sx = hx0 + ((c >> 8) & 0xFFF);
-      const bool ok = live && c >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      const int voff = ok ? (((pn * p.Hs + sy) * p.Ws + sx) * ROWB + (c & 0xFF) * 16) : kThinOOB;
-      tc_dma16(rsrc, lds0 + buf * HALOB + ii * 1024, voff);
-    }
+    const int c = dtab[ii * 64 + lane];
+    const int hy0 = MODE == THIN_DG4 ? 2 * w.by0 - 1 : w.by0 - 1, hx0 = MODE == THIN_DG4 ? 2 * w.bx0 - 1 : w.bx0 - 1;
+    const int sy = hy0 + (c >> 10), sx = hx0 + ((c >> 4) & 63);
+    const bool ok = w.live && c >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+    const int voff = ok ? (((w.n * p.Hs + sy) * p.Ws + sx) * ROWB + (c & 15) * 16) : kThinOOB;
+    tc_dma16(rsrc, lds0 + slot * HALOB + ii * 1024, voff);
+  };
+  // Mask piece j of this wave for the patch being computed: the output-shaped patch of `mask`, linear rows (OROWB bytes each)
+  auto issue_mask = [&](int j, const Where& w) __attribute__((always_inline)) {
+    const int ii = wave + 4 * j;
+    const int byte = ii * 1024 + lane * 16;
+    const int row = byte / OROWB, inrow = byte - row * OROWB;
+    const int oy = (MODE == THIN_PHASE ? 2 : 1) * w.by0 + row, ox = (MODE == THIN_PHASE ? 2 : 1) * w.bx0 + inrow / (COUT * 2);
+    const bool ok = w.live && p.mask && oy < p.Ho && ox < p.Wo;
+    const int voff = ok ? (((w.n * p.Ho + oy) * p.Wo + ox) * COUT * 2 + inrow % (COUT * 2)) : kThinOOB;
+    tc_dma16(rsrc_mask, lds0 + NB * HALOB + ii * 1024, voff);
   };
 
   // ---- fragment addressing: sub-tile t of this wave, lane pixel (sy, sx) on the patch; halo row of tap (r, s) = baseR + r*HALO_W + s
@@ -171,8 +200,8 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
     else baseR[t] = (2 * (2 * t + (l31 >> 4))) * G::HALO_W + 2 * (l31 & 15);
   }
   // ---- staging addressing: where this lane's 4 consecutive couts (registers 4g .. 4g+3) of sub-tile t go
-  int sbase[4];  // byte offset of the pixel in the staged patch image; spx = swizzle key of the pixel
-  int sswz[4];
+  int sbase[4];  // byte offset of the pixel in the staged patch image
+  int sswz[4];   // its swizzle key
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     int row, col;
@@ -192,24 +221,26 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
 
   __syncthreads();  // dtab ready
 
+  // ---- ring prologue: halos of this block's first two patches
   int patch = blockIdx.x;
-  int buf = 0;
-  if (patch < p.total) {
-    locate(patch);
+  Where cur = locate(patch), nxt = locate(patch + gridDim.x);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) issue_piece(j, 0);
-  }
-  tc_dma_wait();  // (first halo: this wave's pieces)
-  while (patch < p.total) {
-    // Every wave waited for ITS pieces of this halo before it got here (above; below, ahead of the write-out): the barrier
-    // makes that everybody's -- and says the previous patch's staged output has been read out.  The wait sits BEFORE the
-    // output stores on purpose: at the loop top it would also wait for those stores (vmcnt counts them), one HBM write
-    // round trip per patch; there it finds the DMA issued during the MFMAs long landed, and the stores overlap the next patch.
+  for (int j = 0; j < NJ; ++j) issue_piece(j, 0, cur);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) issue_piece(j, 1, nxt);
+  tc_dma_wait_n<NJ>();  // halo 0 (this wave's pieces) has landed; halo 1 may still fly
+  int slot = 0;
+  while (cur.live) {
+    // Every wave waited for ITS pieces of this halo before it got here (above; below, ahead of the write-out): barrier A makes
+    // that everybody's -- and says the previous patch's staged output (and mask) have been read out, so the slot it was
+    // staged in (the one halo i+2 goes to) and the mask buffer are free.
     __syncthreads();
-    const int on = pn, oy0 = (MODE == THIN_PHASE ? 2 : 1) * by0, ox0 = (MODE == THIN_PHASE ? 2 : 1) * bx0;  // output origin
-    const int next = patch + gridDim.x;
-    live = next < p.total;
-    if (live) locate(next);
+    const Where nn = locate(patch + 2 * gridDim.x);
+    const int slot2 = slot >= 1 ? slot - 1 : NB - 1;  // (slot + 2) % NB
+    if (HAS_MASK && p.mask) {  // (uniform)
+#pragma unroll
+      for (int j = 0; j < NM; ++j) issue_mask(j, cur);  // needed one compute phase from now; older than this iteration's halo pieces
+    }
 
     f32x16 acc[4];
 #pragma unroll
@@ -217,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const unsigned char* H = smem + buf * HALOB;
+    unsigned char* H = smem + slot * HALOB;
     constexpr int NMMA = NF * 4;
-    constexpr int PSTEP = NMMA / (2 * NJ) >= 1 ? NMMA / (2 * NJ) : 1;  // next halo's DMA pieces between the MFMAs, front-loaded
+    constexpr int PSTEP = NMMA / (2 * NJ) >= 1 ? NMMA / (2 * NJ) : 1;  // halo i+2's DMA pieces between the MFMAs, front-loaded
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
       constexpr int TW = MODE == THIN_33 ? 3 : (MODE == THIN_PHASE ? 2 : 4);
@@ -239,15 +270,16 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int q = (tap * KS + ks) * 4 + t;  // MFMA index within the patch (compile-time after unrolling)
-          if (q % PSTEP == 0 && q / PSTEP < NJ) issue_piece(q / PSTEP, buf ^ 1);
+          if (q % PSTEP == 0 && q / PSTEP < NJ) issue_piece(q / PSTEP, slot2, nn);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[tap * KS + ks]), __builtin_bit_cast(bf16x8, a[t]),
                                                            acc[t], 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int j = (NMMA + PSTEP - 1) / PSTEP; j < NJ; ++j) issue_piece(j, buf ^ 1);
+    for (int j = (NMMA + PSTEP - 1) / PSTEP; j < NJ; ++j) issue_piece(j, slot2, nn);
 
+    __syncthreads();  // barrier B: every wave is done reading this halo -- its slot becomes the output staging area
     // ---- stage: D[i = cout][j = pixel], lane holds couts (r&3) + 8*(r>>2) + 4*hi of pixel l31 -> 8-byte groups of 4 couts
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -259,12 +291,16 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
         v[2] = (bf16_t)acc[t][4 * g + 2];
         v[3] = (bf16_t)acc[t][4 * g + 3];
         const int piece = (MODE == THIN_DG4 ? 4 * wave : 0) + g;  // logical 16-byte piece of the pixel (8 couts)
-        *reinterpret_cast<bf16x4*>(stage + sbase[t] + ((piece ^ sswz[t]) * 16) + hi * 8) = v;
+        *reinterpret_cast<bf16x4*>(H + sbase[t] + ((piece ^ sswz[t]) * 16) + hi * 8) = v;
       }
-    tc_dma_wait();  // the next halo's pieces (this wave's)
-    __syncthreads();
+    // All but this iteration's NJ halo pieces (halo i+2) have landed: halo i+1 (issued an iteration ago), this patch's
+    // mask, and the previous patch's output stores.  The wait sits BEFORE the output stores on purpose: after them it
+    // would wait for the stores as well (vmcnt counts them) -- one HBM write round trip per patch on the critical path.
+    tc_dma_wait_n<NJ>();
+    __syncthreads();  // barrier C: staging (and everybody's mask pieces) visible
 
     // ---- write out: the staged patch is OUT_ROWS rows of OROWB contiguous output bytes
+    const int oy0 = (MODE == THIN_PHASE ? 2 : 1) * cur.by0, ox0 = (MODE == THIN_PHASE ? 2 : 1) * cur.bx0;
     constexpr int PPR = OROWB / 16;  // pieces per patch row
 #pragma unroll
     for (int k = 0; k < STAGEB / 16 / 256; ++k) {
@@ -274,22 +310,24 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
       const int piece = pp ^ (OPP == 4 ? ((px >> 1) & 3) : (px & 15));  // logical piece stored at position pp
       const int oy = oy0 + row, ox = ox0 + px;
       if (oy < p.Ho && ox < p.Wo) {
-        const long o = (((long)on * p.Ho + oy) * p.Wo + ox) * COUT + piece * 8;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + row * OROWB + within * 16);
+        const long o = (((long)cur.n * p.Ho + oy) * p.Wo + ox) * COUT + piece * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(H + row * OROWB + within * 16);
         if (p.relu) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) v[c] = (float)v[c] > 0.f ? v[c] : (bf16_t)0.f;
         }
-        if (p.mask) {
-          const bf16x8 z = *reinterpret_cast<const bf16x8*>(p.mask + o);
+        if (HAS_MASK && p.mask) {
+          const bf16x8 z = *reinterpret_cast<const bf16x8*>(maskbuf + row * OROWB + (px * OPP + piece) * 16);
 #pragma unroll
           for (int c = 0; c < 8; ++c) v[c] = (float)z[c] > 0.f ? v[c] : (bf16_t)0.f;
         }
         *reinterpret_cast<bf16x8*>(p.out + o) = v;
       }
     }
-    patch = next;
-    buf ^= 1;
+    patch += gridDim.x;
+    cur = nxt;
+    nxt = nn;
+    slot = slot + 1 == NB ? 0 : slot + 1;
   }
 }
 

@@ -19,8 +19,10 @@
 //             in flight -- with one block per CU that is what covers the HBM round trip (one halo ahead ran at 2 TB/s).  Every tap is then just an LDS row offset in
 //             the fragment read -- nothing is fetched twice.  In phase form the four output parities share the halo:
 //             wave w computes parity w from the same source pixels.
-//   MFMA      v_mfma_f32_32x32x16_bf16, D[i = cout][j = pixel]: the weight fragment is the A operand, four 32-pixel
-//             sub-tiles per wave.
+//   MFMA      v_mfma_f32_32x32x16_bf16, D[i = cout][j = pixel]: the weight fragment is the A operand.  Eight waves, two per
+//             SIMD: a patch has 16 (row group | parity | cout group, sub-tile) work items of 32 pixels x 32 couts, two per
+//             wave; both waves of a SIMD hold the same weights, and one's address / staging / store phases run under the
+//             other's MFMAs (with four waves the epilogue VALU and the waits were ~55 % of the wave cycles).
 //   output    accumulators -> bf16 patch image staged in the patch's own, consumed halo slot (16-byte pieces XOR-swizzled by
 //             pixel) -> whole contiguous rows of the NHWC output with 16-byte stores, ReLU / ReLU-mask applied on the way
 //             out; the mask patch arrives by LDS-DMA as well (a register load would sit behind the in-flight halos in
@@ -96,7 +98,7 @@ __device__ __forceinline__ void tc_dma_wait_n() {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
+__global__ __launch_bounds__(512, 2) void conv_thin_bf16(const ThinConvArgs p) {
   typedef ThinGeom<MODE> G;
   constexpr int CIN = G::CIN, COUT = G::COUT, NTAP = G::NTAP;
   constexpr int ROWB = CIN * 2;             // bytes per halo pixel
@@ -105,8 +107,10 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   constexpr int KS = CIN / 16;              // MFMA k-steps per tap
   constexpr int NF = NTAP * KS;             // weight fragments per wave
   constexpr int HROWS = G::HALO_H * G::HALO_W;
-  constexpr int NJ = ((HROWS + RI - 1) / RI + 3) / 4;  // DMA instructions per wave per halo (every wave issues exactly NJ:
-  constexpr int NINSTR = 4 * NJ;                       // the counted vmcnt waits need that; surplus rows are out of range)
+  constexpr int NW = 8;                                // waves: two per SIMD, each with a full copy of its weight fragments and
+  constexpr int ST = 2;                                // ST of the patch's sub-tiles -- one wave's VALU / LDS phases hide under its partner's MFMAs
+  constexpr int NJ = ((HROWS + RI - 1) / RI + NW - 1) / NW;  // DMA instructions per wave per halo (every wave issues exactly NJ:
+  constexpr int NINSTR = NW * NJ;                            // the counted vmcnt waits need that; surplus rows are out of range)
   constexpr int HALOB = NINSTR * 1024;
   constexpr int NB = 3;                        // halo ring: patch i computes, i+1 has landed or is landing, i+2 is issued
   constexpr int OROWB = G::OUT_PX * COUT * 2;  // bytes per output patch row
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   constexpr int OPP = COUT / 8;                // 16-byte pieces per output pixel
   constexpr bool HAS_MASK = MODE != THIN_PHASE;  // (the forward DecoderBlock has no ReLU mask)
   constexpr int MASKB = HAS_MASK ? STAGEB : 0;   // the patch of the mask tensor, by DMA like the halo (no VGPR round trip)
-  constexpr int NM = STAGEB / 1024 / 4;          // mask DMA instructions per wave
+  constexpr int NM = STAGEB / 1024 / NW;         // mask DMA instructions per wave
   static_assert(STAGEB == 32768 && STAGEB <= HALOB, "output patch image fits a halo buffer");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NB * HALOB + MASKB + NINSTR * 64 * 2];
@@ -124,12 +128,13 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave & 3, half = wave >> 2;  // role: 3x3 row group | PHASE output parity | DG4 cout group; half: which 2 of its 4 sub-tiles
   const int hi = lane >> 5, l31 = lane & 31;
 
   // ---- DMA lane constants (independent of the patch): halo row R = RI*ii + lane/CPR holds source pixel (R / HALO_W,
   //      R % HALO_W) of the halo; LDS position pp = lane % CPR receives channel piece pp ^ swz(R) (the swizzle lives on the
   //      SOURCE address: the DMA image is lane-linear).  swz: 64-byte rows (R >> 2) & 3, 256-byte rows R & 15.
-  for (int e = tid; e < NINSTR * 64; e += 256) {
+  for (int e = tid; e < NINSTR * 64; e += 64 * NW) {
     const int ii = e >> 6, l = e & 63;
     const int R = RI * ii + l / CPR, pp = l % CPR;
     const int f = CPR == 4 ? ((R >> 2) & 3) : (R & 15);
@@ -141,8 +146,8 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   {
     const bf16_t* wbase;
     if (MODE == THIN_33) wbase = p.wgt + (long)l31 * NTAP * CIN;                       // [cout][tap][cin]
-    else if (MODE == THIN_PHASE) wbase = p.wgt + ((long)wave * 32 + l31) * NTAP * CIN;  // [phase = wave][cout][tap][cin]
-    else wbase = p.wgt + ((long)wave * 32 + l31) * NTAP * CIN;                          // [cout = 32*wave + ..][tap][cin]
+    else if (MODE == THIN_PHASE) wbase = p.wgt + ((long)role * 32 + l31) * NTAP * CIN;  // [phase = role][cout][tap][cin]
+    else wbase = p.wgt + ((long)role * 32 + l31) * NTAP * CIN;                          // [cout = 32*role + ..][tap][cin]
 #pragma unroll
     for (int f = 0; f < NF; ++f) wf[f] = *reinterpret_cast<const u32x4*>(wbase + (f / KS) * CIN + (f % KS) * 16 + 8 * hi);
   }
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   // range, zeros into a slot nobody reads: no branch between the MFMAs (a diamond there makes hipcc keep two copies of the
   // accumulators) and the same DMA count in every wave and iteration (the counted waits rely on it).
   auto issue_piece = [&](int j, int slot, const Where& w) __attribute__((always_inline)) {
-    const int ii = wave + 4 * j;  // wave-uniform
+    const int ii = wave + NW * j;  // wave-uniform
     const int c = dtab[ii * 64 + lane];
     const int hy0 = MODE == THIN_DG4 ? 2 * w.by0 - 1 : w.by0 - 1, hx0 = MODE == THIN_DG4 ? 2 * w.bx0 - 1 : w.bx0 - 1;
     const int sy = hy0 + (c >> 10), sx = hx0 + ((c >> 4) & 63);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
   };
   // Mask piece j of this wave for the patch being computed: the output-shaped patch of `mask`, linear rows (OROWB bytes each)
   auto issue_mask = [&](int j, const Where& w) __attribute__((always_inline)) {
-    const int ii = wave + 4 * j;
+    const int ii = wave + NW * j;
     const int byte = ii * 1024 + lane * 16;
     const int row = byte / OROWB, inrow = byte - row * OROWB;
     const int oy = (MODE == THIN_PHASE ? 2 : 1) * w.by0 + row, ox = (MODE == THIN_PHASE ? 2 : 1) * w.bx0 + inrow / (COUT * 2);
@@ -191,28 +196,33 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
     tc_dma16(rsrc_mask, lds0 + NB * HALOB + ii * 1024, voff);
   };
 
-  // ---- fragment addressing: sub-tile t of this wave, lane pixel (sy, sx) on the patch; halo row of tap (r, s) = baseR + r*HALO_W + s
-  int baseR[4];
+  // ---- fragment addressing: sub-tile u = 2*half + t of this wave's role, lane pixel on the patch; halo row of tap (r, s) = baseR + r*HALO_W + s
+  int baseR[ST];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (MODE == THIN_33) baseR[t] = (4 * wave + t) * G::HALO_W + l31;
-    else if (MODE == THIN_PHASE) baseR[t] = (2 * t + (l31 >> 4) + (wave >> 1)) * G::HALO_W + (l31 & 15) + (wave & 1);
-    else baseR[t] = (2 * (2 * t + (l31 >> 4))) * G::HALO_W + 2 * (l31 & 15);
+  for (int t = 0; t < ST; ++t) {
+    const int u = ST * half + t;
+    if (MODE == THIN_33) baseR[t] = (4 * role + u) * G::HALO_W + l31;
+    else if (MODE == THIN_PHASE) baseR[t] = (2 * u + (l31 >> 4) + (role >> 1)) * G::HALO_W + (l31 & 15) + (role & 1);
+    else baseR[t] = (2 * (2 * u + (l31 >> 4))) * G::HALO_W + 2 * (l31 & 15);
   }
-  // ---- staging addressing: where this lane's 4 consecutive couts (registers 4g .. 4g+3) of sub-tile t go
-  int sbase[4];  // byte offset of the pixel in the staged patch image
-  int sswz[4];   // its swizzle key
+  // ---- staging addressing: where this lane's 4 consecutive couts (registers 4g .. 4g+3) of sub-tile t go.  The staged
+  //      image is the output patch, rows of OROWB bytes; in PHASE mode a row holds its even columns first, then the odd ones
+  //      (a wave writes one parity: consecutive lanes then sit 64 bytes apart instead of 128, which halves the bank conflicts
+  //      of the 8-byte writes); the write-out undoes it.
+  int sbase[ST];  // byte offset of the pixel in the staged patch image
+  int sswz[ST];   // its swizzle key
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < ST; ++t) {
+    const int u = ST * half + t;
     int row, col;
     if (MODE == THIN_33) {
-      row = 4 * wave + t;
+      row = 4 * role + u;
       col = l31;
     } else if (MODE == THIN_PHASE) {
-      row = 2 * (2 * t + (l31 >> 4)) + (wave >> 1);
-      col = 2 * (l31 & 15) + (wave & 1);
+      row = 2 * (2 * u + (l31 >> 4)) + (role >> 1);
+      col = 16 * (role & 1) + (l31 & 15);  // staged position of output column 2*(l31 & 15) + (role & 1)
     } else {
-      row = 2 * t + (l31 >> 4);
+      row = 2 * u + (l31 >> 4);
       col = l31 & 15;
     }
     sbase[t] = row * OROWB + col * COUT * 2;
@@ -242,47 +252,59 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
       for (int j = 0; j < NM; ++j) issue_mask(j, cur);  // needed one compute phase from now; older than this iteration's halo pieces
     }
 
-    f32x16 acc[4];
+    f32x16 acc[ST];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < ST; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     unsigned char* H = smem + slot * HALOB;
-    constexpr int NMMA = NF * 4;
+    // (opaque to the optimiser on purpose: the NTAP x KS x ST fragment addresses below are loop-invariant per lane, and hipcc
+    // would hoist all of them -- up to 64 registers next to the 128 weight registers -- out of the patch loop and spill;
+    // recomputed per patch they are two VALU instructions per read)
+#pragma unroll
+    for (int t = 0; t < ST; ++t) asm volatile("" : "+v"(baseR[t]));
+    constexpr int NG = NTAP * KS;  // fragment groups: one (tap, k-step) = ST pixel fragments against one weight fragment
+    constexpr int NMMA = NG * ST;
     constexpr int PSTEP = NMMA / (2 * NJ) >= 1 ? NMMA / (2 * NJ) : 1;  // halo i+2's DMA pieces between the MFMAs, front-loaded
-#pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      constexpr int TW = MODE == THIN_33 ? 3 : (MODE == THIN_PHASE ? 2 : 4);
+    constexpr int TW = MODE == THIN_33 ? 3 : (MODE == THIN_PHASE ? 2 : 4);
+    // fragments of group g+1 are requested BEFORE the MFMAs of group g (the DMA statements between the MFMAs are asm with a
+    // memory clobber: hipcc does not hoist LDS reads across them, so the prefetch is spelled out)
+    auto read_group = [&](int g, u32x4 (&a)[ST]) __attribute__((always_inline)) {
+      const int tap = g / KS, ks = g % KS;
       const int toff = (tap / TW) * G::HALO_W + (tap % TW);
-      int rowoff[4], f[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < ST; ++t) {
         const int R = baseR[t] + toff;
-        rowoff[t] = R * ROWB;
-        f[t] = CPR == 4 ? ((R >> 2) & 3) : (R & 15);
+        const int f = CPR == 4 ? ((R >> 2) & 3) : (R & 15);
+        a[t] = *reinterpret_cast<const u32x4*>(H + R * ROWB + (((2 * ks + hi) ^ f) * 16));
       }
+    };
+    u32x4 a[2][ST];
+    read_group(0, a[0]);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        u32x4 a[4];
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) read_group(g + 1, a[(g + 1) & 1]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const u32x4*>(H + rowoff[t] + (((2 * ks + hi) ^ f[t]) * 16));
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int q = (tap * KS + ks) * 4 + t;  // MFMA index within the patch (compile-time after unrolling)
-          if (q % PSTEP == 0 && q / PSTEP < NJ) issue_piece(q / PSTEP, slot2, nn);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[tap * KS + ks]), __builtin_bit_cast(bf16x8, a[t]),
-                                                           acc[t], 0, 0, 0);
-        }
+      for (int t = 0; t < ST; ++t) {
+        const int q = g * ST + t;  // MFMA index within the patch (compile-time after unrolling)
+        if (q % PSTEP == 0 && q / PSTEP < NJ) issue_piece(q / PSTEP, slot2, nn);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[g]), __builtin_bit_cast(bf16x8, a[g & 1][t]), acc[t], 0, 0, 0);
       }
     }
 #pragma unroll
     for (int j = (NMMA + PSTEP - 1) / PSTEP; j < NJ; ++j) issue_piece(j, slot2, nn);
+    if (p.relu) {  // (uniform) ReLU on the fp32 accumulators: 16 v_max per sub-tile instead of unpack / compare / select per stored bf16
+#pragma unroll
+      for (int t = 0; t < ST; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+    }
 
     __syncthreads();  // barrier B: every wave is done reading this halo -- its slot becomes the output staging area
     // ---- stage: D[i = cout][j = pixel], lane holds couts (r&3) + 8*(r>>2) + 4*hi of pixel l31 -> 8-byte groups of 4 couts
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < ST; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 v;
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
         v[1] = (bf16_t)acc[t][4 * g + 1];
         v[2] = (bf16_t)acc[t][4 * g + 2];
         v[3] = (bf16_t)acc[t][4 * g + 3];
-        const int piece = (MODE == THIN_DG4 ? 4 * wave : 0) + g;  // logical 16-byte piece of the pixel (8 couts)
+        const int piece = (MODE == THIN_DG4 ? 4 * role : 0) + g;  // logical 16-byte piece of the pixel (8 couts)
         *reinterpret_cast<bf16x4*>(H + sbase[t] + ((piece ^ sswz[t]) * 16) + hi * 8) = v;
       }
     // All but this iteration's NJ halo pieces (halo i+2) have landed: halo i+1 (issued an iteration ago), this patch's
@@ -302,26 +324,27 @@ __global__ __launch_bounds__(256, 1) void conv_thin_bf16(const ThinConvArgs p) {
     // ---- write out: the staged patch is OUT_ROWS rows of OROWB contiguous output bytes
     const int oy0 = (MODE == THIN_PHASE ? 2 : 1) * cur.by0, ox0 = (MODE == THIN_PHASE ? 2 : 1) * cur.bx0;
     constexpr int PPR = OROWB / 16;  // pieces per patch row
-#pragma unroll
-    for (int k = 0; k < STAGEB / 16 / 256; ++k) {
-      const int e = tid + 256 * k;
+#pragma unroll 1
+    for (int k = 0; k < STAGEB / 16 / (64 * NW); ++k) {
+      const int e = tid + 64 * NW * k;
       const int row = e / PPR, within = e - row * PPR;
-      const int px = within / OPP, pp = within - px * OPP;
-      const int piece = pp ^ (OPP == 4 ? ((px >> 1) & 3) : (px & 15));  // logical piece stored at position pp
+      const int px = within / OPP, pp = within - px * OPP;          // output column of the patch row, position inside the pixel
+      const int spx = MODE == THIN_PHASE ? 16 * (px & 1) + (px >> 1) : px;  // where that column was staged
+      const int piece = pp ^ (OPP == 4 ? ((spx >> 1) & 3) : (spx & 15));    // logical piece stored at position pp of it
       const int oy = oy0 + row, ox = ox0 + px;
       if (oy < p.Ho && ox < p.Wo) {
         const long o = (((long)cur.n * p.Ho + oy) * p.Wo + ox) * COUT + piece * 8;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(H + row * OROWB + within * 16);
-        if (p.relu) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(H + row * OROWB + (spx * OPP + pp) * 16);
+        if (HAS_MASK && p.mask) {  // zero where the mask value is <= 0 (or NaN): bf16 sign bit set or magnitude zero, on the raw bits
+          const u32x4 z = *reinterpret_cast<const u32x4*>(maskbuf + row * OROWB + (px * OPP + piece) * 16);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = (float)v[c] > 0.f ? v[c] : (bf16_t)0.f;
+          for (int c = 0; c < 4; ++c) {
+            const unsigned int lo = z[c] & 0xFFFFu, hi16 = z[c] >> 16;
+            const unsigned int keep = ((lo - 1u) < 0x7F80u ? 0x0000FFFFu : 0u) | ((hi16 - 1u) < 0x7F80u ? 0xFFFF0000u : 0u);
+            v[c] &= keep;
+          }
         }
-        if (HAS_MASK && p.mask) {
-          const bf16x8 z = *reinterpret_cast<const bf16x8*>(maskbuf + row * OROWB + (px * OPP + piece) * 16);
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = (float)z[c] > 0.f ? v[c] : (bf16_t)0.f;
-        }
-        *reinterpret_cast<bf16x8*>(p.out + o) = v;
+        *reinterpret_cast<u32x4*>(p.out + o) = v;
       }
     }
     patch += gridDim.x;
@@ -365,10 +388,10 @@ int rs_conv_thin_bf16_launch(int mode, const void* src, const void* wgt, const v
   const long total = (long)a.ppi * N;
   if (total >= (1L << 31)) return RS_EINVAL;
   a.total = (int)total;
-  const int grid = a.total < 256 ? a.total : 256;  // persistent: one block per CU
+  const int grid = a.total < 256 ? a.total : 256;  // persistent: one 8-wave block per CU
   hipStream_t s = (hipStream_t)stream;
-  if (mode == THIN_33) conv_thin_bf16<THIN_33><<<grid, 256, 0, s>>>(a);
-  else if (mode == THIN_PHASE) conv_thin_bf16<THIN_PHASE><<<grid, 256, 0, s>>>(a);
-  else conv_thin_bf16<THIN_DG4><<<grid, 256, 0, s>>>(a);
+  if (mode == THIN_33) conv_thin_bf16<THIN_33><<<grid, 512, 0, s>>>(a);
+  else if (mode == THIN_PHASE) conv_thin_bf16<THIN_PHASE><<<grid, 512, 0, s>>>(a);
+  else conv_thin_bf16<THIN_DG4><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }

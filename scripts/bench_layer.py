@@ -5,6 +5,7 @@ usage: python scripts/bench_layer.py [--variants "auto 128x128/64 256x128/128 ..
 SPEC = dtype:form:N,C1[+C2],H,W,Cout[,k,stride,pad]
   dtype  f32 | bf16
   form   conv   plain convolution, eval epilogue (scale/shift + ReLU; "+res" adds the residual: Bottleneck conv3)
+         relu   plain convolution with only a ReLU ("+mask": only a ReLU mask): ConvRelu / its data gradient
          stats  train-mode forward: raw output + fused BatchNorm partial sums
          bwd    data gradient into a BatchNorm: ReLU mask + bn_y statistics (+res)
          phase  DecoderBlock in phase form on cat[C1, C2] at source size H x W (k/stride/pad ignored)
@@ -70,12 +71,13 @@ for spec in a.specs:
     elif form == "dg4":
         xs = rot((n, 2 * h, 2 * w, c1), dt, n * 4 * h * w * c1 * es)
         wt = (torch.randn(cout, 4, 4, c1, device=dev) * 0.02).to(dt)
-        fn = lambda x: ops.conv2d(x, wt, stride=2, pad=1, out_hw=(h, w))
+        zm = torch.randn(n, h, w, cout, device=dev).to(dt) if opt == "mask" else None
+        fn = lambda x: ops.conv2d(x, wt, stride=2, pad=1, out_hw=(h, w), relu_mask=zm)
         def name():
             nm = ops.conv_tile_name(ops.conv_desc(xs[0], wt, stride=2, pad=1, out_hw=(h, w)), es == 2)
             return nm if nm.startswith("conv_thin") else nm.replace("<", "<dgrad4x4,")
         flops = 2.0 * n * h * w * cout * c1 * 16
-        nbytes = es * (n * 4 * h * w * c1 + n * h * w * cout)
+        nbytes = es * (n * 4 * h * w * c1 + (2 if opt == "mask" else 1) * n * h * w * cout)
     else:
         ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
         xs = rot((n, h, w, c1), dt, n * h * w * c1 * es)
@@ -87,6 +89,10 @@ for spec in a.specs:
             r = torch.randn(*outshape, device=dev).to(dt) if res else None
             extra = 1 if res else 0
             fn = lambda x: ops.conv2d(x, wt, stride=st, pad=pad, scale=sc, shift=sh, residual=r, relu=True)
+        elif form == "relu":
+            z = torch.randn(*outshape, device=dev).to(dt) if opt == "mask" else None
+            extra = 1 if z is not None else 0
+            fn = lambda x: ops.conv2d(x, wt, stride=st, pad=pad, relu=z is None, relu_mask=z)
         elif form == "stats":
             fn = lambda x: ops.conv2d_bnstats(x, wt, stride=st, pad=pad)
         elif form == "bwd":

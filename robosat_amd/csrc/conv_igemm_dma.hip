@@ -162,6 +162,11 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats
     // it wins: +22 % on dec2's 4x4/s2 data gradient, 64 -> 768 at 64^2 x 32 -- profiles/r02/layer_sweep.txt)
     if (d->Cout % 256 == 0 && nk128 >= ((phase4 || d->kh > 1) ? 16 : 32) && rs_cdiv(mrows, 256) * (d->Cout / 256) * nph >= tu.min256) return T256x256;
   }
+  // fp32, K <= 64 (two 128-byte chunks: layer1's 64 -> 256 conv3 / downsample): a block is all prologue + epilogue, the
+  // launch is output-bandwidth bound, and twice as many half-width blocks overlap those phases better: +9 % measured
+  // (profiles/r02/layer_sweep.txt, f32:conv+res:16,64,128,128,256).  bf16 measured no gain.
+  if (es == 4 && !stats && !phase4 && (long)d->kh * d->kw * (d->C1 + d->C2) <= 64 && d->Cout % 64 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 64) >= want)
+    return T128x64;
   if (d->Cout % 128 == 0 && (long)rs_cdiv(M, 128) * (d->Cout / 128) >= want) return T128x128;
   // ragged last N tile (weight rows past Cout read as zeros through the buffer bound, the epilogue skips their columns):
   // worth it when <= 1/5 of the MFMAs are padding -- Cout = 320, the data gradient of the 256 + 64 concat, runs the
@@ -475,7 +480,9 @@ extern "C" int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const vo
 
 extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
-  return rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[pick_tile(d)]);
+  // (with fused statistics the tile choice does not depend on the element size: every es-specific rule of pick_tile is
+  // switched off by `stats`, so this answer holds for the fp32 and the bf16 launch alike)
+  return rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[pick_tile(d, false, 4, true)]);
 }
 
 extern "C" int rs_conv2d_dgrad_bnstats_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight,

@@ -121,10 +121,13 @@ def test_dispatcher_choices_for_the_benchmark_layers():
         tile, rowb = ctypes.c_int(0), ctypes.c_int(0)
         assert lib.rs_conv2d_config(ctypes.byref(d), es, phase, ctypes.byref(tile), ctypes.byref(rowb)) == 0
         name = (lib.rs_conv2d_tile_name_bf16 if es == 2 else lib.rs_conv2d_tile_name)(tile.value).decode()
+        if "<" not in name:
+            return "thin", rowb.value
         return name[name.index("<") + 1:-1], rowb.value
 
     fp32 = [  # predict bs 16, fp32 (es 4)
-        ((16, 128, 128, 64, 0, 0, 1, 1, 0, 128, 128, 256, 4), ("128x128", 64)),      # layer1 conv3: short K
+        ((16, 128, 128, 64, 0, 0, 1, 1, 0, 128, 128, 256, 4), ("128x64", 64)),       # layer1 conv3: K = 64, output bound
+        ((16, 64, 64, 128, 0, 0, 1, 1, 0, 64, 64, 512, 4), ("128x128", 64)),         # layer2 conv3: short K
         ((16, 32, 32, 256, 0, 0, 1, 1, 0, 32, 32, 1024, 4), ("128x128", 64)),        # layer3 conv3: nk128 = 8
         ((16, 32, 32, 1024, 0, 0, 1, 1, 0, 32, 32, 256, 4), ("128x64", 128)),        # layer3 conv1: long K, small grid
         ((16, 16, 16, 512, 0, 0, 3, 1, 1, 16, 16, 512, 4), ("64x64", 128)),          # layer4 conv2
@@ -139,6 +142,10 @@ def test_dispatcher_choices_for_the_benchmark_layers():
         ((32, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 2, 1), ("128x128", 128)),# dec3, phase form
         ((32, 256, 256, 128, 0, 0, 4, 2, 1, 128, 128, 320, 2), ("128x128", 128)),    # dec3 data gradient: ragged N (320)
         ((32, 16, 16, 2048, 256, 1, 3, 1, 1, 32, 32, 256, 2, 1), ("128x128", 128)),  # dec0: too few blocks for 256x256
+        ((32, 128, 128, 64, 0, 0, 4, 2, 1, 64, 64, 768, 2), ("256x256", 128)),       # dec2 data gradient: 16 chunks, 1536 blocks
+        ((32, 512, 512, 32, 0, 0, 3, 1, 1, 512, 512, 32, 2), ("thin", 64)),          # dec5: all-taps kernel (conv_thin_bf16.hip)
+        ((32, 256, 256, 128, 0, 1, 3, 1, 1, 512, 512, 32, 2, 1), ("thin", 256)),     # dec4, phase form: all-taps kernel
+        ((32, 512, 512, 32, 0, 0, 4, 2, 1, 256, 256, 128, 2), ("thin", 64)),         # dec4 data gradient: all-taps kernel
     ]
     for args, want in fp32 + bf16:
         assert cfg(*args) == want, (args, cfg(*args), want)

@@ -47,11 +47,13 @@ def tiles_from_csv(path):
                 yield Tile(*(int(v) for v in row))
 
 
-def buffer_tile_image(tile, tiles, overlap, tile_size, nodata=0):
+def buffer_tile_image(tile, tiles, overlap, tile_size, nodata=0, opener=None):
     """The tile's RGB image with an ``overlap``-pixel border taken from its 8 neighbours (``nodata`` where a
     neighbour is missing): size ``tile_size + 2*overlap`` squared (reference tiles.py:162-227).
 
-    ``tiles`` is a mapping ``Tile -> path`` (or an iterable of pairs)."""
+    ``tiles`` is a mapping ``Tile -> path`` (or an iterable of pairs).  ``opener(path)`` returns the decoded RGB image
+    (default: ``Image.open(path).convert("RGB")``); ``BufferedSlippyMapDirectory`` passes a small LRU cache here, because
+    the composite of every tile decodes nine files and neighbouring tiles share six of them."""
 
     store = tiles if isinstance(tiles, dict) else dict(tiles)
     size = tile_size + 2 * overlap
@@ -70,7 +72,7 @@ def buffer_tile_image(tile, tiles, overlap, tile_size, nodata=0):
             (tx, sx, w), (ty, sy, h) = span[dx], span[dy]
             if w == 0 or h == 0:
                 continue
-            piece = Image.open(path).convert("RGB")
+            piece = Image.open(path).convert("RGB") if opener is None else opener(path)
             if dx == 0 and dy == 0:
                 composite.paste(piece, box=(tx, ty))
             else:

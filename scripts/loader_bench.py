@@ -1,6 +1,8 @@
 """Loader-inclusive throughput of the tools (measurement; SURVEY.md section 7 "report both"): `rs predict` over a real
 slippy-map directory of decoded-from-disk tiles, and `rs train` for one epoch with the host loader (PIL transforms in
-DataLoader workers) and with the device-side augmentation (decoded-tile cache in HBM).  Prints one JSON line per case.
+DataLoader workers) and with the device-side augmentation (decoded-tile cache in HBM).  Every case runs the whole tool
+twice, on a quarter of the tiles and on all of them: `steady_tiles_per_s` = the extra tiles over the extra seconds, i.e.
+without interpreter / model start-up and the checkpoint write.  Prints one JSON line per case.
 
 usage: python scripts/loader_bench.py [--tiles 512] [--size 512] [--workers 16] [--batch 16]"""
 import argparse
@@ -20,11 +22,11 @@ import torch
 from PIL import Image
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--tiles", type=int, default=512)
+ap.add_argument("--tiles", type=int, default=1024)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--workers", type=int, default=16)
 ap.add_argument("--batch", type=int, default=16)
-ap.add_argument("--train-tiles", type=int, default=256)
+ap.add_argument("--train-tiles", type=int, default=1024)
 a = ap.parse_args()
 
 
@@ -72,22 +74,46 @@ with tempfile.TemporaryDirectory() as tmp:
     ck = os.path.join(tmp, "ck.pth")
     torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in net.state_dict().items()}}, ck)
 
-    tiles_dir = os.path.join(ds_root, "validation", "images")
+    def subset(split, count, name):
+        """A dataset root holding the first `count` tiles of `split` (symlinks) -- the quarter-size run."""
+        root = os.path.join(tmp, name)
+        for kind in ("images", "labels"):
+            src = os.path.join(ds_root, split, kind)
+            files = sorted(os.path.join(d, f) for d, _, fs in os.walk(src) for f in fs)[:count]
+            for f in files:
+                dst = os.path.join(root, split, kind, os.path.relpath(f, src))
+                os.makedirs(os.path.dirname(dst), exist_ok=True)
+                os.symlink(f, dst)
+        return root
+
+    small = subset("validation", a.tiles // 4, "ds_small")
+    subset("training", a.train_tiles // 4, "ds_small")
+
     for workers in (0, a.workers):
-        dt = rs(["predict", "--batch_size", str(a.batch), "--checkpoint", ck, "--overlap", "32", "--tile_size", str(a.size), "--workers", str(workers),
-                 "--model", model_toml, "--dataset", ds_toml, tiles_dir, os.path.join(tmp, "probs{}".format(workers))])
+        times = []
+        for root, n in ((small, a.tiles // 4), (ds_root, a.tiles)):
+            times.append(rs(["predict", "--batch_size", str(a.batch), "--checkpoint", ck, "--overlap", "32", "--tile_size", str(a.size), "--workers",
+                             str(workers), "--model", model_toml, "--dataset", ds_toml, os.path.join(root, "validation", "images"),
+                             os.path.join(tmp, "probs{}_{}".format(workers, n))]))
+        steady = (a.tiles - a.tiles // 4) / max(1e-9, times[1] - times[0])
         print(json.dumps({"case": "rs predict, {} JPEG tiles of {}^2 from disk, overlap 32 (9-tile composites), PNG out, bs {}, {} loader workers".format(
-            a.tiles, a.size, a.batch, workers), "tiles_per_s": round(a.tiles / dt, 1), "wall_s": round(dt, 2),
-            "note": "wall time of the whole tool: interpreter + model start-up (~6 s) included"}), flush=True)
+            a.tiles, a.size, a.batch, workers), "steady_tiles_per_s": round(steady, 1), "wall_s": [round(t, 2) for t in times],
+            "tiles": [a.tiles // 4, a.tiles]}), flush=True)
 
     for dtype, aug in (("fp32", False), ("bf16", False), ("bf16", True)):
-        cfg = load_config(model_toml)
-        cfg["model"]["compute_dtype"] = dtype
-        cfg["model"]["device_augment"] = aug
-        cfg["common"]["checkpoint"] = os.path.join(tmp, "pth_{}_{}".format(dtype, int(aug)))
-        save_config(cfg, model_toml)
-        dt = rs(["train", "--model", model_toml, "--dataset", ds_toml, "--workers", str(a.workers)])
-        n = a.train_tiles + a.tiles  # one training epoch + one validation pass
-        print(json.dumps({"case": "rs train 1 epoch, {} + {} tiles of {}^2, bs {}, {}, {}".format(
+        times = []
+        for root, n in ((small, (a.train_tiles + a.tiles) // 4), (ds_root, a.train_tiles + a.tiles)):
+            cfg = load_config(model_toml)
+            cfg["model"]["compute_dtype"] = dtype
+            cfg["model"]["device_augment"] = aug
+            cfg["common"]["checkpoint"] = os.path.join(tmp, "pth_{}_{}_{}".format(dtype, int(aug), n))
+            save_config(cfg, model_toml)
+            dcfg = load_config(ds_toml)
+            dcfg["common"]["dataset"] = root
+            save_config(dcfg, ds_toml)
+            times.append(rs(["train", "--model", model_toml, "--dataset", ds_toml, "--workers", str(a.workers)]))
+        n_all, n_small = a.train_tiles + a.tiles, (a.train_tiles + a.tiles) // 4
+        steady = (n_all - n_small) / max(1e-9, times[1] - times[0])
+        print(json.dumps({"case": "rs train 1 epoch (train + validation pass), {} + {} tiles of {}^2, bs {}, {}, {}".format(
             a.train_tiles, a.tiles, a.size, a.batch, dtype, "device-side augmentation (tile cache in HBM)" if aug else "{} DataLoader workers (PIL)".format(a.workers)),
-            "tiles_per_s": round(n / dt, 1), "wall_s": round(dt, 2), "note": "whole tool incl. start-up, validation pass and the 457 MB checkpoint write"}), flush=True)
+            "steady_tiles_per_s": round(steady, 1), "wall_s": [round(t, 2) for t in times], "tiles": [n_small, n_all]}), flush=True)

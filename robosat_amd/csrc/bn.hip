@@ -249,6 +249,129 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
   if (dmasked) rs_st4(dmasked + i * 4, g);
 }
 
+// ---- streaming forms of the two apply passes (round 2) -------------------------------------------------------------------
+// One thread = 8 consecutive channels (one 16-byte access in bf16, two in fp32), a block-iteration = 2048 consecutive
+// elements.  When C divides 2048 a thread meets the SAME 8 channels in every iteration, so its per-channel coefficients
+// live in registers for the whole launch; a block issues the loads of kBnIter iterations before the first use (4-8 requests
+// of 16 bytes in flight per lane instead of 1-2 of 8 bytes).  Other channel counts use the 4-channel kernels above.
+constexpr int kBnIter = 4;
+
+struct BnRawB { bf16x8 v; };
+struct BnRawF { f32x4 a, b; };
+__device__ __forceinline__ BnRawB bn_ld8(const bf16_t* p) { return {__builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p))}; }
+__device__ __forceinline__ BnRawF bn_ld8(const float* p) {
+  return {__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)), __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + 1)};
+}
+__device__ __forceinline__ float bn_get(const BnRawB& r, int e) { return (float)r.v[e]; }
+__device__ __forceinline__ float bn_get(const BnRawF& r, int e) { return e < 4 ? r.a[e] : r.b[e - 4]; }
+__device__ __forceinline__ void bn_st8(bf16_t* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+__device__ __forceinline__ void bn_st8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] = v[e], b[e] = v[4 + e];
+  *reinterpret_cast<f32x4*>(p) = a;
+  *(reinterpret_cast<f32x4*>(p) + 1) = b;
+}
+
+template <typename T, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_stream_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ res,
+                                                              T* __restrict__ out, long total, int C, int relu) {
+  const int c0 = (threadIdx.x * 8) & (C - 1);  // (C divides 2048: a power of two)
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[e] = scale[c0 + e], sh[e] = shift[c0 + e];
+  const long base = (long)blockIdx.x * (kBnIter * 2048) + threadIdx.x * 8;
+  decltype(bn_ld8(y)) v[kBnIter], r[kBnIter];
+#pragma unroll
+  for (int it = 0; it < kBnIter; ++it) {
+    const long i = base + it * 2048;
+    if (i < total) {
+      v[it] = bn_ld8(y + i);
+      if (RES) r[it] = bn_ld8(res + i);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kBnIter; ++it) {
+    const long i = base + it * 2048;
+    if (i < total) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = bn_get(v[it], e) * sc[e] + sh[e];
+        if (RES) t += bn_get(r[it], e);
+        o[e] = relu ? fmaxf(t, 0.f) : t;
+      }
+      bn_st8(out + i, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                                  const float* __restrict__ mean, const float* __restrict__ coef,
+                                                                  T* __restrict__ dy, long total, int C) {
+  const int c0 = (threadIdx.x * 8) & (C - 1);
+  float mu[8], k1[8], k2[8], k3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mu[e] = mean[c0 + e], k1[e] = coef[c0 + e], k2[e] = coef[C + c0 + e], k3[e] = coef[2 * C + c0 + e];
+  const long base = (long)blockIdx.x * (kBnIter * 2048) + threadIdx.x * 8;
+  decltype(bn_ld8(y)) gv[kBnIter], yv[kBnIter];
+#pragma unroll
+  for (int it = 0; it < kBnIter; ++it) {
+    const long i = base + it * 2048;
+    if (i < total) {
+      gv[it] = bn_ld8(g + i);
+      yv[it] = bn_ld8(y + i);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kBnIter; ++it) {
+    const long i = base + it * 2048;
+    if (i < total) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = k1[e] * bn_get(gv[it], e) - k2[e] - k3[e] * (bn_get(yv[it], e) - mu[e]);
+      bn_st8(dy + i, o);
+    }
+  }
+}
+
+inline bool bn_streamable(long M, int C) {
+  static const bool on = [] { const char* e = getenv("RS_BN_STREAM"); return !e || atoi(e) != 0; }();  // TEMP A/B knob
+  return on && C >= 8 && C <= 2048 && (2048 % C) == 0 && ((M * C) % 8) == 0;
+}
+
+template <typename T>
+void bn_apply_launch(const T* y, const float* scale, const float* shift, const T* res, T* out, long M, int C, int relu,
+                     hipStream_t s) {
+  const long total = M * C;
+  if (bn_streamable(M, C)) {
+    const int grid = rs_cdiv(total, kBnIter * 2048L);
+    if (res)
+      bn_apply_stream_kernel<T, true><<<grid, 256, 0, s>>>(y, scale, shift, res, out, total, C, relu);
+    else
+      bn_apply_stream_kernel<T, false><<<grid, 256, 0, s>>>(y, scale, shift, res, out, total, C, relu);
+    return;
+  }
+  bn_apply_kernel<T><<<rs_cdiv(total / 4, 256), 256, 0, s>>>(y, scale, shift, res, out, total / 4, C / 4, relu);
+}
+
+template <typename T>
+void bn_bwd_apply_launch(const T* g, const T* y, const float* mean, const float* coef, T* dy, long M, int C, hipStream_t s) {
+  const long total = M * C;
+  if (bn_streamable(M, C)) {
+    bn_bwd_apply_stream_kernel<T><<<rs_cdiv(total, kBnIter * 2048L), 256, 0, s>>>(g, y, mean, coef, dy, total, C);
+    return;
+  }
+  bn_bwd_apply_kernel<T><<<rs_cdiv(total / 4, 256), 256, 0, s>>>(g, nullptr, y, mean, coef, dy, nullptr, total / 4, C / 4);
+}
+
 template <typename T>
 int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const float* gamma, const float* beta, float* mean,
                      float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
@@ -351,16 +474,13 @@ extern "C" int rs_bn_finalize_stats(const float* partial, long rows, long M, int
 extern "C" int rs_bn_apply_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                               int dtype, long M, int C, int relu, rs_stream_t stream) {
   if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
-  const long total4 = M * (C / 4);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RS_F32)
-    bn_apply_kernel<float><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const float*>(y), scale, shift,
-                                                                reinterpret_cast<const float*>(residual),
-                                                                reinterpret_cast<float*>(out), total4, C / 4, relu);
+    bn_apply_launch(reinterpret_cast<const float*>(y), scale, shift, reinterpret_cast<const float*>(residual),
+                    reinterpret_cast<float*>(out), M, C, relu, s);
   else if (dtype == RS_BF16)
-    bn_apply_kernel<bf16_t><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(y), scale, shift,
-                                                                 reinterpret_cast<const bf16_t*>(residual),
-                                                                 reinterpret_cast<bf16_t*>(out), total4, C / 4, relu);
+    bn_apply_launch(reinterpret_cast<const bf16_t*>(y), scale, shift, reinterpret_cast<const bf16_t*>(residual),
+                    reinterpret_cast<bf16_t*>(out), M, C, relu, s);
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();
@@ -406,15 +526,12 @@ extern "C" int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const fl
   slices = (int)((rows + rps - 1) / rps);
   bn_partial_reduce_kernel<<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2);
   bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, gamma, invstd, dgamma, dbeta, coef);
-  const long total4 = M * (C / 4);
   if (dtype == RS_F32)
-    bn_bwd_apply_kernel<float><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const float*>(g), nullptr,
-                                                                    reinterpret_cast<const float*>(y), mean, coef,
-                                                                    reinterpret_cast<float*>(dy), nullptr, total4, C / 4);
+    bn_bwd_apply_launch(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(y), mean, coef,
+                        reinterpret_cast<float*>(dy), M, C, s);
   else if (dtype == RS_BF16)
-    bn_bwd_apply_kernel<bf16_t><<<rs_cdiv(total4, 256), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(g), nullptr,
-                                                                     reinterpret_cast<const bf16_t*>(y), mean, coef,
-                                                                     reinterpret_cast<bf16_t*>(dy), nullptr, total4, C / 4);
+    bn_bwd_apply_launch(reinterpret_cast<const bf16_t*>(g), reinterpret_cast<const bf16_t*>(y), mean, coef,
+                        reinterpret_cast<bf16_t*>(dy), M, C, s);
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();

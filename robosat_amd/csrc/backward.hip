@@ -190,6 +190,93 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const T* __restrict__ x,
     partial[(long)blockIdx.x * npairs + pair] = (red[pair] + red[npairs + pair]) + (red[2 * npairs + pair] + red[3 * npairs + pair]);
 }
 
+// The model's own shape, Cin = 32 and C <= 4 classes: one thread = one pixel per tile, the pixel's 32 channels and C
+// logit gradients come straight into registers as 16-byte / coalesced 4-byte loads (the next tile's are requested before
+// this tile's arithmetic), dx leaves as 16-byte stores, and the thread's own dW / db contributions accumulate in registers
+// over all its tiles; waves, then blocks, are combined in a fixed order (same partial layout as the general kernel).
+template <int C, typename T>
+__global__ __launch_bounds__(256) void final_bwd_px32_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ dl, T* __restrict__ dx,
+                                                             float* __restrict__ partial, long P, long HW, long ntiles,
+                                                             int relu_mask) {
+  constexpr int NP = C * 33;
+  __shared__ __attribute__((aligned(16))) float ws[C * 32];
+  __shared__ float red[4 * NP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int f = tid; f < C * 32; f += 256) ws[f] = w[f];
+  __syncthreads();
+  float aw[C][32], ab[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    ab[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) aw[c][k] = 0.f;
+  }
+  float xv[32], g[C];
+  auto fetch = [&](long tile, float (&xr)[32], float (&gr)[C]) {
+    const long pix = tile * 256 + tid;
+    if (pix < P) {
+      rs_ld_row32(x + pix * 32, xr);
+      const long n = pix / HW, hw = pix - n * HW;
+#pragma unroll
+      for (int c = 0; c < C; ++c) gr[c] = dl[(n * C + c) * HW + hw];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) xr[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) gr[c] = 0.f;
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile, xv, g);
+  while (tile < ntiles) {
+    float xn[32], gn[C];
+    const long next = tile + gridDim.x;
+    if (next < ntiles) fetch(next, xn, gn);
+    const long pix = tile * 256 + tid;
+    float o[32];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + c * 32 + k4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[c], wv[e], acc[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[k4 * 4 + e] = (relu_mask && !(xv[k4 * 4 + e] > 0.f)) ? 0.f : acc[e];
+    }
+    if (pix < P) rs_st_row32(dx + pix * 32, o);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      ab[c] += g[c];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) aw[c][k] = fmaf(g[c], xv[k], aw[c][k]);
+    }
+    if (next < ntiles) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) xv[k] = xn[k];
+#pragma unroll
+      for (int c = 0; c < C; ++c) g[c] = gn[c];
+    }
+    tile = next;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float v = rs_wave_sum(aw[c][k]);
+      if (lane == 0) red[wave * NP + c * 33 + k] = v;
+    }
+    const float v = rs_wave_sum(ab[c]);
+    if (lane == 0) red[wave * NP + c * 33 + 32] = v;
+  }
+  __syncthreads();
+  for (int pair = tid; pair < NP; pair += 256)
+    partial[(long)blockIdx.x * NP + pair] = (red[pair] + red[NP + pair]) + (red[2 * NP + pair] + red[3 * NP + pair]);
+}
+
 // one block per (c,k) pair: sums the per-block partials in fp64
 __global__ __launch_bounds__(256) void final_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                                  int Cin, float* __restrict__ dw, float* __restrict__ db) {
@@ -218,6 +305,13 @@ int launch_final_bwd(const T* x, const float* w, const float* dl, T* dx, float* 
   const long ntiles = (P + 255) / 256;
   const int grid = ntiles < kFinalBwdMaxBlocks ? (int)ntiles : kFinalBwdMaxBlocks;
   const int npairs = C * (Cin + 1);
+  if constexpr (C <= 4) {
+    if (Cin == 32) {
+      final_bwd_px32_kernel<C, T><<<grid, 256, 0, s>>>(x, w, dl, dx, partial, P, HW, ntiles, relu_mask);
+      final_bwd_finalize_kernel<<<npairs, 256, 0, s>>>(partial, grid, C, Cin, dw, db);
+      return RS_LAUNCH_RESULT();
+    }
+  }
   const size_t smem = (size_t)(256 * (Cin + 1) + C * 256 + C * Cin + 4 * npairs) * sizeof(float);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_bwd_kernel<C, T>),

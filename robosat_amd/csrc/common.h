@@ -24,6 +24,44 @@ __device__ __forceinline__ void rs_st4(bf16_t* p, f32x4 v) {
 __device__ __forceinline__ float rs_ld1(const float* p) { return *p; }
 __device__ __forceinline__ float rs_ld1(const bf16_t* p) { return (float)*p; }
 
+// One pixel's 32 channels into fp32 registers: 16-byte loads issued together (4 in bf16, 8 in fp32).
+__device__ __forceinline__ void rs_ld_row32(const bf16_t* p, float (&v)[32]) {
+  bf16x8 t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const bf16x8*>(p + j * 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[j * 8 + e] = (float)t[j][e];
+}
+__device__ __forceinline__ void rs_ld_row32(const float* p, float (&v)[32]) {
+  f32x4 t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const f32x4*>(p + j * 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[j * 4 + e] = t[j][e];
+}
+__device__ __forceinline__ void rs_st_row32(bf16_t* p, const float (&v)[32]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[j * 8 + e];
+    *reinterpret_cast<bf16x8*>(p + j * 8) = t;
+  }
+}
+__device__ __forceinline__ void rs_st_row32(float* p, const float (&v)[32]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = v[j * 4 + e];
+    *reinterpret_cast<f32x4*>(p + j * 4) = t;
+  }
+}
+
 #define RS_LAUNCH_RESULT() ((int)hipGetLastError())
 
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; speed only, never

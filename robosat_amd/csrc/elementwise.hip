@@ -86,6 +86,56 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
   shift[c] = beta[c] - mean[c] * sc;
 }
 
+// What happens to a pixel's C logits (shared by the two forms of the kernel below): optional softmax, then fp32 NCHW logits /
+// probabilities, or the quantised probability bytes of `rs predict`, or the argmax byte of `rs serve`.
+template <int C>
+__device__ __forceinline__ void final_epilogue(float (&acc)[C], long pix, long HW, int softmax, const double* __restrict__ anchors,
+                                               uint8_t* __restrict__ qout, float* __restrict__ out, int Wimg, int ov) {
+  if (softmax) {
+    float mx = acc[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, acc[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      acc[c] = expf(acc[c] - mx);
+      sum += acc[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = acc[c] / sum;
+  }
+  const long n = pix / HW, hw = pix - n * HW;
+  if (softmax == 2) {  // un-buffer crop + np.digitize of every non-background class: C - 1 bytes per pixel
+    if (C < 2) return;
+    const int Himg = (int)(HW / Wimg);
+    const int yy = (int)(hw / Wimg), xx = (int)(hw - (long)yy * Wimg);
+    const int S_h = Himg - 2 * ov, S_w = Wimg - 2 * ov;
+    if (yy < ov || yy >= Himg - ov || xx < ov || xx >= Wimg - ov) return;
+    uint8_t* qo = qout + ((n * S_h + (yy - ov)) * (long)S_w + (xx - ov)) * (C - 1);
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+      const double pf = (double)acc[c];
+      int q = (int)(pf * 255.0);  // anchors[i] ~ i/255: first guess, then settle on the exact table (anchors ascending)
+      q = q < 0 ? 0 : (q > 255 ? 255 : q);
+      while (q < 255 && anchors[q + 1] <= pf) ++q;
+      while (q >= 0 && anchors[q] > pf) --q;
+      qo[c - 1] = (uint8_t)((q + 1) & 0xff);  // bins are 1-based; 256 wraps to 0
+    }
+    return;
+  }
+  if (softmax == 3) {  // class index of the first maximum logit (np.argmax over axis 0), one byte per pixel
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < C; ++c)
+      if (acc[c] > acc[best]) best = c;
+    qout[pix] = (uint8_t)best;
+    return;
+  }
+  float* o = out + n * C * HW + hw;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c * HW] = acc[c];
+}
+
 // self.final (+ optional softmax): 256 pixels per block.  The block's [256][Cin] slab is read with fully coalesced
 // 16-byte loads into LDS (row stride Cin+1: conflict-free per-pixel reads), then one thread owns one pixel, keeps
 // the C class sums in registers and writes C coalesced NCHW planes.
@@ -132,54 +182,50 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const T* __restrict_
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) acc[c] += ws[C * Cin + c];
-  if (softmax) {
-    float mx = acc[0];
+  final_epilogue<C>(acc, pix, HW, softmax, anchors, qout, out, Wimg, ov);
+}
+
+// The model's own shape, Cin = 32 (unet.py:108: num_filters = 32): one thread = one pixel, its 32 channels arrive as 16-byte
+// loads issued together (4 in bf16, 8 in fp32) straight into registers -- no LDS transposition of the activations; the
+// C x 32 weights sit in LDS and are read as broadcasts.  Same multiply-add order as the general kernel above.
+template <int C, typename T>
+__global__ __launch_bounds__(256) void final_conv1x1_px32_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ out, long P,
+                                                                 long HW, int softmax, const double* __restrict__ anchors,
+                                                                 uint8_t* __restrict__ qout, int Wimg, int ov) {
+  __shared__ __attribute__((aligned(16))) float ws[C * 32 + C];
+  const int tid = threadIdx.x;
+  for (int f = tid; f < C * 32; f += 256) ws[f] = w[f];
+  if (tid < C) ws[C * 32 + tid] = bias ? bias[tid] : 0.f;
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + tid;
+  if (pix >= P) return;
+  float xv[32];
+  rs_ld_row32(x + pix * 32, xv);
+  float acc[C];
 #pragma unroll
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, acc[c]);
-    float sum = 0.f;
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int k4 = 0; k4 < 8; ++k4) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      acc[c] = expf(acc[c] - mx);
-      sum += acc[c];
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + c * 32 + k4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c] = fmaf(xv[k4 * 4 + e], wv[e], acc[c]);
     }
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = acc[c] / sum;
   }
-  const long n = pix / HW, hw = pix - n * HW;
-  if (softmax == 2) {  // un-buffer crop + np.digitize of every non-background class: C - 1 bytes per pixel
-    if (C < 2) return;
-    const int Himg = (int)(HW / Wimg);
-    const int yy = (int)(hw / Wimg), xx = (int)(hw - (long)yy * Wimg);
-    const int S_h = Himg - 2 * ov, S_w = Wimg - 2 * ov;
-    if (yy < ov || yy >= Himg - ov || xx < ov || xx >= Wimg - ov) return;
-    uint8_t* qo = qout + ((n * S_h + (yy - ov)) * (long)S_w + (xx - ov)) * (C - 1);
 #pragma unroll
-    for (int c = 1; c < C; ++c) {
-      const double pf = (double)acc[c];
-      int q = (int)(pf * 255.0);  // anchors[i] ~ i/255: first guess, then settle on the exact table (anchors ascending)
-      q = q < 0 ? 0 : (q > 255 ? 255 : q);
-      while (q < 255 && anchors[q + 1] <= pf) ++q;
-      while (q >= 0 && anchors[q] > pf) --q;
-      qo[c - 1] = (uint8_t)((q + 1) & 0xff);  // bins are 1-based; 256 wraps to 0
-    }
-    return;
-  }
-  if (softmax == 3) {  // class index of the first maximum logit (np.argmax over axis 0), one byte per pixel
-    int best = 0;
-#pragma unroll
-    for (int c = 1; c < C; ++c)
-      if (acc[c] > acc[best]) best = c;
-    qout[pix] = (uint8_t)best;
-    return;
-  }
-  float* o = out + n * C * HW + hw;
-#pragma unroll
-  for (int c = 0; c < C; ++c) o[c * HW] = acc[c];
+  for (int c = 0; c < C; ++c) acc[c] += ws[C * 32 + c];
+  final_epilogue<C>(acc, pix, HW, softmax, anchors, qout, out, Wimg, ov);
 }
 
 template <int C, typename T>
 int launch_final(const T* x, const float* w, const float* bias, float* out, long P, long HW, int Cin, int softmax,
                  hipStream_t s, const double* anchors = nullptr, uint8_t* qout = nullptr, int Wimg = 0, int ov = 0) {
+  if (Cin == 32) {
+    final_conv1x1_px32_kernel<C, T><<<rs_cdiv(P, 256), 256, 0, s>>>(x, w, bias, out, P, HW, softmax, anchors, qout, Wimg, ov);
+    return RS_LAUNCH_RESULT();
+  }
   const size_t smem = (size_t)(256 * (Cin + 1) + C * Cin + C) * sizeof(float);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&final_conv1x1_kernel<C, T>),

@@ -271,7 +271,7 @@ def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
         crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=torch.ones(args.classes)),
                 "Focal": lambda: losses.FocalLoss2d(weight=torch.ones(args.classes)),
                 "Lovasz": lambda: losses.LovaszLoss2d()}[args.loss]().to(device)
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)  # (as `rs train` builds it on a GPU)
         if dist:
             from robosat_amd import parallel
 

@@ -8,6 +8,8 @@
 //
 // Reductions: stage 1 writes per-row-split partial sums in fp64 (one thread accumulates its rows in fp64, the
 // block combines its row lanes through LDS), stage 2 combines the splits -- deterministic, no atomics.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -132,15 +134,22 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y
 }
 
 // Stage 2: 16 channels x 16 split lanes per block; lane l sums splits l, l+16, ... in fp64, LDS tree over the lanes.
-template <typename P>
+// SC1: the rows were published inside this launch by blocks on other XCDs (sc1 write-through stores): read them with
+// agent-scope loads, which bypass this XCD's non-coherent L2 lines.
+template <typename P, bool SC1 = false>
 __device__ __forceinline__ void bn_reduce_splits(const P* __restrict__ part, int R, int C, int c, int lane, bool ok,
                                                  double& s0, double& s1) {
   __shared__ double red[2][16][17];
   double a = 0, b = 0;
   if (ok) {
     for (int r = lane; r < R; r += 16) {
-      a += (double)part[((long)r * 2) * C + c];
-      b += (double)part[((long)r * 2 + 1) * C + c];
+      if (SC1) {
+        a += (double)__hip_atomic_load(part + ((long)r * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += (double)__hip_atomic_load(part + ((long)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a += (double)part[((long)r * 2) * C + c];
+        b += (double)part[((long)r * 2 + 1) * C + c];
+      }
     }
   }
   const int cl = threadIdx.x & 15;
@@ -158,48 +167,66 @@ __device__ __forceinline__ void bn_reduce_splits(const P* __restrict__ part, int
   }
 }
 
-template <typename P>
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(
-    const P* __restrict__ part, int R, long M, int C, float eps, float momentum, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ running_mean, float* __restrict__ running_var,
-    long long* __restrict__ num_batches_tracked) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+struct BnStatsOut {
+  float eps, momentum;
+  const float *gamma, *beta;
+  float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
+  long long* num_batches_tracked;
+};
+
+// channel group `cg` (16 channels) of the forward finalize, by one whole block: R partial rows [r][2][C] -> statistics
+template <typename P, bool SC1 = false>
+__device__ __forceinline__ void bn_stats_finalize_body(const P* __restrict__ part, int R, long M, int C, int cg,
+                                                       const BnStatsOut& o) {
+  const int c = cg * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  if (cg == 0 && threadIdx.x == 0 && o.num_batches_tracked) *o.num_batches_tracked += 1;
   double s, ss;
-  bn_reduce_splits(part, R, C, c, lane, c < C, s, ss);
+  bn_reduce_splits<P, SC1>(part, R, C, c, lane, c < C, s, ss);
   if (c >= C || lane != 0) return;
   const double mu = s / (double)M;
   double var = ss / (double)M - mu * mu;
   if (var < 0) var = 0;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  mean[c] = (float)mu;
-  invstd[c] = is;
-  const float sc = gamma[c] * is;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)mu * sc;
-  if (running_mean) {
+  const float is = (float)(1.0 / sqrt(var + (double)o.eps));
+  o.mean[c] = (float)mu;
+  o.invstd[c] = is;
+  const float sc = o.gamma[c] * is;
+  o.scale[c] = sc;
+  o.shift[c] = o.beta[c] - (float)mu * sc;
+  if (o.running_mean) {
     const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    o.running_mean[c] = (1.f - o.momentum) * o.running_mean[c] + o.momentum * (float)mu;
+    o.running_var[c] = (1.f - o.momentum) * o.running_var[c] + o.momentum * (float)unbiased;
   }
 }
 
+template <typename P>
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const P* __restrict__ part, int R, long M, int C, BnStatsOut o) {
+  bn_stats_finalize_body(part, R, M, C, blockIdx.x, o);
+}
+
 // coef[0][c] = k1 = gamma*invstd, coef[1][c] = k2 = k1*sum(g)/M, coef[2][c] = k3 = k1*invstd*sum(g*xhat)/M
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int R, long M, int C,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+struct BnBwdOut {
+  const float *gamma, *invstd;
+  float *dgamma, *dbeta, *coef;
+};
+
+template <bool SC1 = false>
+__device__ __forceinline__ void bn_bwd_finalize_body(const double* __restrict__ part, int R, long M, int C, int cg,
+                                                     const BnBwdOut& o) {
+  const int c = cg * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
   double s0, s1;
-  bn_reduce_splits(part, R, C, c, lane, c < C, s0, s1);
+  bn_reduce_splits<double, SC1>(part, R, C, c, lane, c < C, s0, s1);
   if (c >= C || lane != 0) return;
-  dbeta[c] = (float)s0;
-  dgamma[c] = (float)s1;
-  const double k1 = (double)gamma[c] * (double)invstd[c];
-  coef[c] = (float)k1;
-  coef[C + c] = (float)(k1 * s0 / (double)M);
-  coef[2 * C + c] = (float)(k1 * (double)invstd[c] * s1 / (double)M);
+  o.dbeta[c] = (float)s0;
+  o.dgamma[c] = (float)s1;
+  const double k1 = (double)o.gamma[c] * (double)o.invstd[c];
+  o.coef[c] = (float)k1;
+  o.coef[C + c] = (float)(k1 * s0 / (double)M);
+  o.coef[2 * C + c] = (float)(k1 * (double)o.invstd[c] * s1 / (double)M);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int R, long M, int C, BnBwdOut o) {
+  bn_bwd_finalize_body(part, R, M, C, blockIdx.x, o);
 }
 
 // out = relu?( y * scale[c] + shift[c] (+ residual) )
@@ -343,8 +370,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(const T* __res
 }
 
 inline bool bn_streamable(long M, int C) {
-  static const bool on = [] { const char* e = getenv("RS_BN_STREAM"); return !e || atoi(e) != 0; }();  // TEMP A/B knob
-  return on && C >= 8 && C <= 2048 && (2048 % C) == 0 && ((M * C) % 8) == 0;
+  return C >= 8 && C <= 2048 && (2048 % C) == 0 && ((M * C) % 8) == 0;
 }
 
 template <typename T>
@@ -380,9 +406,8 @@ int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const
   double* part = reinterpret_cast<double*>(workspace);
   bn_partial_kernel<0, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
                                                           g.rows_per_split);
-  bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, eps, momentum, gamma, beta, mean, invstd,
-                                                                   scale, shift, running_mean, running_var,
-                                                                   num_batches_tracked);
+  const BnStatsOut o = {eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, num_batches_tracked};
+  bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, o);
   return RS_LAUNCH_RESULT();
 }
 
@@ -394,7 +419,8 @@ int bn_bwd_t(const T* dz, const T* zmask, const T* y, const float* mean, const f
   float* coef = reinterpret_cast<float*>(part + (long)g.R * 2 * C);  // 3*C floats behind the partials
   bn_partial_kernel<1, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb,
                                                           g.rows_per_split);
-  bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, gamma, invstd, dgamma, dbeta, coef);
+  const BnBwdOut o = {gamma, invstd, dgamma, dbeta, coef};
+  bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, o);
   const long total4 = M * (C / 4);
   bn_bwd_apply_kernel<T><<<rs_cdiv(total4, 256), 256, 0, s>>>(dz, zmask, y, mean, coef, dy, dmasked, total4, C / 4);
   return RS_LAUNCH_RESULT();
@@ -427,19 +453,55 @@ extern "C" int rs_bn_train_stats(const float* y, long M, int C, float eps, float
                               running_var, num_batches_tracked, workspace, stream);
 }
 
-// First level for many conv-epilogue partial rows: slice s of the rows -> one fp64 partial row [s][2][C]
-__global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __restrict__ part, int R, int C, int rows_per_slice,
-                                                                double* __restrict__ out) {
+// Many conv-epilogue partial rows -> statistics in ONE launch (round 2: was reduce + finalize, 71 + 71 launches of ~5 us on
+// the critical path of a step).  Level 1: block (cg, sl) sums slice sl of the rows for channel group cg into one fp64 row
+// [sl][2][C].  The block that arrives LAST at its channel group's counter then sums the <= 64 slice rows in slice order
+// (deterministic, whoever it is) and finalizes.  Counters: zero at module load, every launch leaves its set at zero; 16 sets in
+// rotation so that launches in flight on different streams never share one.
+__device__ unsigned int g_bn_arrivals[16 * 128];
+
+struct BnFinOut {
+  BnStatsOut st;
+  BnBwdOut bw;
+};
+
+template <int MODE>  // 0: forward statistics, 1: backward coefficients
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __restrict__ part, int R, int C, int rows_per_slice,
+                                                                 double* __restrict__ out, long M, int set, BnFinOut o) {
+  __shared__ int is_last;
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
   const int r0 = blockIdx.y * rows_per_slice;
   int r1 = r0 + rows_per_slice;
   if (r1 > R) r1 = R;
   double s0, s1;
   bn_reduce_splits(part + (long)r0 * 2 * C, r1 - r0, C, c, lane, c < C, s0, s1);
+  // Publishing a slice row across XCDs without flushing an L2 that is full of the producing convolution's output: the row goes
+  // out as write-through (sc1) 8-byte stores, every wave waits for its stores, then ONE relaxed device-scope arrival per block;
+  // the last arriver reads the rows back with sc1 loads (platform guide, in-launch split-K reduction recipe).
   if (c < C && lane == 0) {
-    out[((long)blockIdx.y * 2) * C + c] = s0;
-    out[((long)blockIdx.y * 2 + 1) * C + c] = s1;
+    __hip_atomic_store(out + ((long)blockIdx.y * 2) * C + c, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + ((long)blockIdx.y * 2 + 1) * C + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (set < 0) return;  // (more channel groups than counters: the host launches the finalize kernel behind this one)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* ctr = g_bn_arrivals + set * 128 + blockIdx.x;
+    const unsigned int before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = before == gridDim.y - 1;
+    if (is_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all arrivals of this launch have happened)
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (MODE == 0)
+    bn_stats_finalize_body<double, true>(out, (int)gridDim.y, M, C, blockIdx.x, o.st);
+  else
+    bn_bwd_finalize_body<true>(out, (int)gridDim.y, M, C, blockIdx.x, o.bw);
+}
+
+static int bn_next_counter_set() {
+  static std::atomic<unsigned int> seq{0};
+  return (int)(seq.fetch_add(1) & 15u);
 }
 
 // Finalize from the per-tile fp32 partial sums the convolution epilogue wrote (rs_conv2d_fwd_bnstats_dt): replaces the
@@ -459,15 +521,16 @@ extern "C" int rs_bn_finalize_stats(const float* partial, long rows, long M, int
     const int rps = (int)((rows + slices - 1) / slices);
     slices = (int)((rows + rps - 1) / rps);
     double* part2 = reinterpret_cast<double*>(workspace);
-    bn_partial_reduce_kernel<<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2);
-    bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, eps, momentum, gamma, beta, mean,
-                                                                     invstd, scale, shift, running_mean, running_var,
-                                                                     num_batches_tracked);
+    BnFinOut o = {};
+    o.st = {eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, num_batches_tracked};
+    const bool merged = C <= 2048;
+    bn_reduce_finalize_kernel<0><<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2, M,
+                                                                              merged ? bn_next_counter_set() : -1, o);
+    if (!merged) bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, o.st);
     return RS_LAUNCH_RESULT();
   }
-  bn_stats_finalize_kernel<float><<<rs_cdiv(C, 16), 256, 0, s>>>(partial, (int)rows, M, C, eps, momentum, gamma, beta, mean,
-                                                                  invstd, scale, shift, running_mean, running_var,
-                                                                  num_batches_tracked);
+  const BnStatsOut o = {eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, num_batches_tracked};
+  bn_stats_finalize_kernel<float><<<rs_cdiv(C, 16), 256, 0, s>>>(partial, (int)rows, M, C, o);
   return RS_LAUNCH_RESULT();
 }
 
@@ -524,8 +587,12 @@ extern "C" int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const fl
   if (slices > 64) slices = 64;
   const int rps = (int)((rows + slices - 1) / slices);
   slices = (int)((rows + rps - 1) / rps);
-  bn_partial_reduce_kernel<<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2);
-  bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, gamma, invstd, dgamma, dbeta, coef);
+  BnFinOut o = {};
+  o.bw = {gamma, invstd, dgamma, dbeta, coef};
+  const bool merged = C <= 2048;
+  bn_reduce_finalize_kernel<1><<<dim3(rs_cdiv(C, 16), slices), 256, 0, s>>>(partial, (int)rows, C, rps, part2, M,
+                                                                            merged ? bn_next_counter_set() : -1, o);
+  if (!merged) bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, o.bw);
   if (dtype == RS_F32)
     bn_bwd_apply_launch(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(y), mean, coef,
                         reinterpret_cast<float*>(dy), M, C, s);

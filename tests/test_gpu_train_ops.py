@@ -141,6 +141,48 @@ def test_batchnorm_train(c, hw, res, relu):
         close(nchw(gm), resid.grad, what="residual grad")
 
 
+@pytest.mark.parametrize("rows,c", [(8, 64), (300, 64), (1000, 256), (4097, 128), (700, 4096)],
+                         ids=["one_slice", "few_slices", "two_level", "64_slices", "no_counters"])
+def test_batchnorm_from_tile_partials(rows, c):
+    """The one-launch reduce + finalize (last-arriving block finalizes; C > 2048 falls back to two launches) against a
+    float64 evaluation of the same per-tile partial sums: forward statistics (torch.nn.BatchNorm2d train mode) and the
+    backward coefficients, twice in a row so that a counter left dirty by the first launch would show."""
+    from robosat_amd import ops
+
+    m = rows * 128
+    g = torch.Generator().manual_seed(rows + c)
+    partial = torch.stack([torch.randn(rows, c, generator=g) * 5 + 3, torch.rand(rows, c, generator=g) * 300 + 200], 1)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    p64 = partial.double().sum(0)
+    mu = p64[0] / m
+    var = (p64[1] / m - mu * mu).clamp_min(0)
+    inv = 1 / torch.sqrt(var + 1e-5)
+    for _ in range(2):
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        mean, invstd, scale, shift = ops.bn_finalize_stats(partial.to(DEV), m, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm, rv, nbt)
+        close(mean.cpu().double(), mu, 1e-6, "mean")
+        close(invstd.cpu().double(), inv, 1e-6, "invstd")
+        close(scale.cpu().double(), gamma.double() * inv, 1e-6, "scale")
+        close(shift.cpu().double(), beta.double() - mu * gamma.double() * inv, 1e-5, "shift")
+        close(rm.cpu().double(), 0.1 * mu, 1e-6, "running_mean")
+        close(rv.cpu().double(), 0.9 + 0.1 * var * m / (m - 1), 1e-6, "running_var")
+        assert int(nbt) == 1
+    # backward: dy = k1*g - k2 - k3*(y - mean) with k1 = gamma*invstd, k2 = k1*sum(g)/M, k3 = k1*invstd*sum(g*xhat)/M
+    hw = 16
+    gd, yd = torch.randn(1, hw, hw, c, generator=g).to(DEV), torch.randn(1, hw, hw, c, generator=g).to(DEV)
+    mean_d, inv_d = torch.randn(c, generator=g).to(DEV), (torch.rand(c, generator=g) + 0.5).to(DEV)
+    for _ in range(2):
+        dy, dgamma, dbeta = ops.bn_bwd_from_partials(gd, yd, mean_d, inv_d, gamma.to(DEV), partial.to(DEV))
+        close(dbeta.cpu().double(), p64[0], 1e-6, "dbeta")
+        close(dgamma.cpu().double(), p64[1], 1e-6, "dgamma")
+        # (the coefficients divide by M = pixels of g, here hw*hw: the partial sums are synthetic, the formula is what is checked)
+        mm = hw * hw
+        k1 = gamma.double() * inv_d.cpu().double()
+        want = k1 * gd.cpu().double() - k1 * p64[0] / mm - k1 * inv_d.cpu().double() * p64[1] / mm * (yd.cpu().double() - mean_d.cpu().double())
+        close(dy.cpu().double(), want, 1e-5, "dy")
+
+
 @pytest.mark.parametrize("k,s,p", [(3, 2, 1), (2, 2, 0)])
 def test_maxpool_backward(k, s, p):
     from robosat_amd import ops

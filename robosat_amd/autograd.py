@@ -140,6 +140,9 @@ def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
 
 
 def _forward(net, x, tape):
+    from .unet import _bump_generation
+
+    _bump_generation()  # a training forward re-derives every compute copy of the weights (see unet._GENERATION)
     r = net.resnet
     t = tape.t
     dt = net.compute_dtype  # fp32 or bf16 activations (the image is cast on upload)

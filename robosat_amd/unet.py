@@ -54,7 +54,7 @@ class _Conv(nn.Module):
         w = w if w.is_contiguous() else w.contiguous()
         if dtype == torch.float32:
             return w
-        key = (self.weight.data_ptr(), self.weight._version)
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0])
         c = getattr(self, "_bf16", None)
         if c is None or c[0] != key:
             c = (key, ops.cast_bf16(w))
@@ -66,7 +66,7 @@ class _Conv(nn.Module):
         the current parameter version if there is one, else packed now (``rs_pack_dgrad_weight[_bf16]``)."""
 
         c = getattr(self, "_dgrad", None)
-        if dtype == torch.bfloat16 and c is not None and c[0] == (self.weight.data_ptr(), self.weight._version):
+        if dtype == torch.bfloat16 and c is not None and c[0] == (self.weight.data_ptr(), self.weight._version, _GENERATION[0]):
             return c[1]
         return ops.pack_dgrad_weight(self.krsc(), dtype)
 
@@ -74,7 +74,7 @@ class _Conv(nn.Module):
         """The four parity-specific 2x2 filters of this 3x3 convolution behind a nearest-x2 upsample (DecoderBlock),
         packed on the device from the fp32 master and cached until the parameter is modified."""
 
-        key = (self.weight.data_ptr(), self.weight._version, dtype)
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0], dtype)
         c = getattr(self, "_phase", None)
         if c is None or c[0] != key:
             c = (key, ops.pack_phase_weight(self.krsc(), dtype))
@@ -83,6 +83,19 @@ class _Conv(nn.Module):
 
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(self.cin, self.cout, self.k, self.stride, self.padding)
+
+
+# Derived tensors (bf16 casts, packed filters, folded BatchNorm, captured graphs) are cached per (data_ptr, _version) of their
+# sources AND the generation below.  torch's version counters catch ordinary in-place updates (Adam's default multi-tensor
+# step, load_state_dict, copy_), but not every writer bumps them -- ``torch.optim.Adam(fused=True)`` does not -- so the
+# generation moves whenever stale copies could otherwise survive: at every training forward (the weights are re-derived once
+# per step anyway) and at every ``train()`` / ``eval()`` switch (validation after fused steps).  ``UNet.invalidate_caches()``
+# is the explicit form for anything else that writes through ``.data``.
+_GENERATION = [0]
+
+
+def _bump_generation():
+    _GENERATION[0] += 1
 
 
 class _BatchNorm(nn.Module):
@@ -102,7 +115,7 @@ class _BatchNorm(nn.Module):
         """Eval-mode scale/shift for the conv epilogue; cached until a parameter or buffer is modified."""
 
         ts = (self.weight, self.bias, self.running_mean, self.running_var)
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (_GENERATION[0],)
         if self._folded is None or self._folded[0] != key:
             scale, shift = ops.bn_fold(self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var, self.eps)
             self._folded = (key, scale, shift)
@@ -264,6 +277,19 @@ class UNet(nn.Module):
                 m._folded = None
         return out
 
+    def invalidate_caches(self):
+        """Drop every derived copy of the parameters / buffers (bf16 casts, packed filters, folded BatchNorm, captured
+        graphs).  Needed only after a write torch's version counters do not see (e.g. through ``.data``); optimizer steps
+        -- fused ones included --, ``load_state_dict`` and ``train()`` / ``eval()`` switches are handled."""
+
+        _bump_generation()
+        self.__dict__.pop("_graphs", None)
+        return self
+
+    def train(self, mode=True):
+        self.invalidate_caches()
+        return super().train(mode)
+
     def _blocks(self):
         r = self.resnet
         return [list(r.layer1), list(r.layer2), list(r.layer3), list(r.layer4)]
@@ -279,7 +305,7 @@ class UNet(nn.Module):
             for blk in layer:
                 convs += [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
         convs.append(self.dec5.block)
-        keys = [(c.weight.data_ptr(), c.weight._version) for c in convs]
+        keys = [(c.weight.data_ptr(), c.weight._version, _GENERATION[0]) for c in convs]
         st = getattr(self, "_wprep", None)
         if st is not None and st[1] == keys:
             return
@@ -305,7 +331,8 @@ class UNet(nn.Module):
         ``load_state_dict``) drops the stale graphs.  Returns a fresh tensor (the graph's static output is reused)."""
 
         sig = (kind, tuple(x.shape), x.dtype, x.device, self.compute_dtype,
-               tuple(t._version for t in self._state_tensors()), tuple(t.data_ptr() for t in self._state_tensors()[:4]))
+               tuple(t._version for t in self._state_tensors()), tuple(t.data_ptr() for t in self._state_tensors()[:4]),
+               _GENERATION[0])
         cache = self.__dict__.setdefault("_graphs", {})
         entry = cache.get(sig)
         if entry is None:

@@ -62,3 +62,48 @@ def test_train_step_matches_reference_golden(golden_dir, loss_name):
                 assert int(got) == int(want), key
             else:
                 assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), key
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_optimizer_updates_that_bypass_version_counters_are_seen(dtype):
+    """``torch.optim.Adam(fused=True)`` (what ``rs train`` uses on the GPU) rewrites the parameters without bumping their
+    version counters; the derived copies the kernels read (bf16 casts, packed phase filters, folded BatchNorm, captured
+    graphs) must follow all the same.  Three steps with the fused and with the default optimizer from one initial state
+    give the same losses, and the eval-mode output afterwards is the oracle's on the trained state dict."""
+    from robosat_amd import losses
+    from robosat_amd.unet import UNet
+
+    x = seeded.synthetic_images(2, 3, 64, 64, 5).to(DEV)
+    t = seeded.synthetic_targets(2, 2, 64, 64, 5).to(DEV)
+    init = seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 5)
+    runs = {}
+    for fused in (False, True):
+        net = UNet(2, pretrained=False, compute_dtype=dtype)
+        net.load_state_dict(init)
+        net = net.to(DEV)
+        net.eval()
+        before = net.predict_probs(x).cpu()  # (fills the eval-mode caches that must not survive the steps)
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=fused)
+        crit = losses.CrossEntropyLoss2d(weight=torch.tensor([1.0, 2.0])).to(DEV)
+        ls = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = crit(net(x), t)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss))
+        net.eval()
+        after = net.predict_probs(x).cpu()
+        ref = R.UNetRef(2)
+        ref.load_state_dict({k: v.detach().float().cpu() for k, v in net.state_dict().items()})
+        ref.eval()
+        want = R.predict_probs(ref, x.cpu())
+        tol = 1e-3 if dtype == "fp32" else 3e-2
+        assert float((after - want).abs().max()) <= tol, (fused, float((after - want).abs().max()))
+        assert float((after - before).abs().max()) > 1e-3  # the steps did move the output
+        runs[fused] = ls
+    print(runs)
+    assert runs[True][0] == pytest.approx(runs[False][0], rel=1e-5)
+    for a, b in zip(runs[True], runs[False]):  # later losses see the updates: a stale weight copy shows here
+        assert a == pytest.approx(b, rel=2e-2 if dtype == "bf16" else 2e-3)

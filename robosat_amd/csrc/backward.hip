@@ -7,21 +7,23 @@
 namespace {
 
 // d/dx of F.max_pool2d (unet.py:125,132) in gather form: every input element sums the gradients of the windows that
-// selected it (the forward kernel recorded the winning tap per window, first maximum as torch).
-template <typename TY, typename TX>
+// selected it (the forward kernel recorded the winning tap per window, first maximum as torch).  V = 4 or 8 channels per thread.
+template <typename TY, typename TX, int V>
 __global__ void maxpool_bwd_kernel(const TY* __restrict__ dy, const uint8_t* __restrict__ amax, TX* __restrict__ dx,
-                                   int H, int W, int C4, int k, int stride, int pad, int Ho, int Wo, long total,
+                                   int H, int W, int CV, int k, int stride, int pad, int Ho, int Wo, long total,
                                    int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % C4);
-  long pix = i / C4;
+  const int c = (int)(i % CV);
+  long pix = i / CV;
   const int ix = (int)(pix % W);
   pix /= W;
   const int iy = (int)(pix % H);
   const long n = pix / H;
-  f32x4 g = {0.f, 0.f, 0.f, 0.f};
-  if (accumulate) g = rs_ld4(dx + i * 4);
+  rs_vecf<V> g;
+#pragma unroll
+  for (int e = 0; e < V; ++e) g.v[e] = 0.f;
+  if (accumulate) g = rs_ldv<V>(dx + i * V);
   int ny = iy + pad - (k - 1), nx = ix + pad - (k - 1);
   const int oy0 = ny <= 0 ? 0 : (ny + stride - 1) / stride;
   const int ox0 = nx <= 0 ? 0 : (nx + stride - 1) / stride;
@@ -33,15 +35,17 @@ __global__ void maxpool_bwd_kernel(const TY* __restrict__ dy, const uint8_t* __r
     for (int ox = ox0; ox <= ox1; ++ox) {
       const int s = ix + pad - ox * stride;
       const uint32_t tap = (uint32_t)(r * k + s);
-      const long o = ((n * Ho + oy) * Wo + ox) * (long)C4 + c;
-      const uint32_t sel = *reinterpret_cast<const uint32_t*>(amax + o * 4);
-      const f32x4 v = rs_ld4(dy + o * 4);
+      const long o = ((n * Ho + oy) * Wo + ox) * (long)CV + c;
+      uint32_t sel[V / 4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (((sel >> (8 * e)) & 0xffu) == tap) g[e] += v[e];
+      for (int h = 0; h < V / 4; ++h) sel[h] = *reinterpret_cast<const uint32_t*>(amax + o * V + 4 * h);
+      const rs_vecf<V> v = rs_ldv<V>(dy + o * V);
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (((sel[e / 4] >> (8 * (e & 3))) & 0xffu) == tap) g.v[e] += v.v[e];
     }
   }
-  rs_st4(dx + i * 4, g);
+  rs_stv<V>(dx + i * V, g);
 }
 
 // d/dx of F.interpolate(scale_factor=2, mode="nearest") (unet.py:73) followed by the split of torch.cat
@@ -341,9 +345,14 @@ int dispatch_final_bwd(const T* x, const float* w, const float* dl, T* dx, float
 template <typename TY, typename TX>
 int launch_maxpool_bwd(const void* dy, const uint8_t* argmax, void* dx, int H, int W, int C, int k, int stride, int pad,
                        int Ho, int Wo, long total, int accumulate, hipStream_t s) {
-  maxpool_bwd_kernel<TY, TX><<<rs_cdiv(total, 256), 256, 0, s>>>(reinterpret_cast<const TY*>(dy), argmax,
-                                                                 reinterpret_cast<TX*>(dx), H, W, C / 4, k, stride, pad, Ho,
-                                                                 Wo, total, accumulate);
+  if ((C & 7) == 0)
+    maxpool_bwd_kernel<TY, TX, 8><<<rs_cdiv(total / 2, 256), 256, 0, s>>>(reinterpret_cast<const TY*>(dy), argmax,
+                                                                          reinterpret_cast<TX*>(dx), H, W, C / 8, k, stride, pad,
+                                                                          Ho, Wo, total / 2, accumulate);
+  else
+    maxpool_bwd_kernel<TY, TX, 4><<<rs_cdiv(total, 256), 256, 0, s>>>(reinterpret_cast<const TY*>(dy), argmax,
+                                                                      reinterpret_cast<TX*>(dx), H, W, C / 4, k, stride, pad, Ho,
+                                                                      Wo, total, accumulate);
   return RS_LAUNCH_RESULT();
 }
 

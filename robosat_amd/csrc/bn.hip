@@ -25,9 +25,9 @@ struct Geometry {
   long rows_per_split;
 };
 
-Geometry geometry(long M, int C) {
+Geometry geometry(long M, int C, int V = 4) {
   Geometry g;
-  g.Q = C / 4;
+  g.Q = C / V;
   g.qb = g.Q < 256 ? g.Q : 256;
   g.rpb = 256 / g.qb;
   g.gx = rs_cdiv(g.Q, g.qb);
@@ -45,88 +45,89 @@ Geometry geometry(long M, int C) {
 
 // MODE 0: s0 = sum y,  s1 = sum y^2                       (forward statistics)
 // MODE 1: s0 = sum g,  s1 = sum g * (y - mean) * invstd     (backward; g = dz * (z > 0) when zmask != null)
-template <int MODE, typename T>
+// A thread owns V channels of the row lanes rl, rl + rpb, ...; U rows per trip: all loads of a trip are issued before the
+// fp64 accumulation consumes them.
+template <int MODE, typename T, int V>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y, const T* __restrict__ dz,
                                                          const T* __restrict__ zmask, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, double* __restrict__ part,
                                                          long M, int C, int qb, int rpb, long rows_per_split) {
-  __shared__ double red[256 * 8];
+  __shared__ double red[256 * 2 * V];
   const int tid = threadIdx.x;
-  const int Q = C >> 2;
+  const int Q = C / V;
   const int ql = tid % qb, rl = tid / qb;
   const int q = blockIdx.x * qb + ql;
   const long r0 = (long)blockIdx.y * rows_per_split;
   long r1 = r0 + rows_per_split;
   if (r1 > M) r1 = M;
-  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  double s0[V], s1[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s0[e] = 0, s1[e] = 0;
   const bool active = (q < Q) && (rl < rpb);
   if (active) {
-    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
-    if (MODE == 1) {
-      mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
-      is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
-    }
-    // 4 rows per trip: all loads of a trip are issued before the fp64 accumulation consumes them
-    constexpr int U = 4;
+    float mu[V], is[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) mu[e] = MODE == 1 ? mean[q * V + e] : 0.f, is[e] = MODE == 1 ? invstd[q * V + e] : 0.f;
+    constexpr int U = V == 8 ? 2 : 4;
     const long step = (long)rpb * U;
     for (long rb = r0 + rl; rb < r1; rb += step) {
-      f32x4 v[U], g[U], z[U];
+      rs_vecf<V> v[U], g[U], z[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long r = rb + (long)u * rpb;
         const bool in = r < r1;
-        const long o = (in ? r : rb) * C + q * 4;
-        v[u] = rs_ld4(y + o);
+        const long o = (in ? r : rb) * C + q * V;
+        v[u] = rs_ldv<V>(y + o);
         if (MODE == 1) {
-          g[u] = rs_ld4(dz + o);
-          if (zmask) z[u] = rs_ld4(zmask + o);
+          g[u] = rs_ldv<V>(dz + o);
+          if (zmask) z[u] = rs_ldv<V>(zmask + o);
         }
         if (!in) {
-          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (MODE == 1) g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < V; ++e) v[u].v[e] = 0.f, g[u].v[e] = 0.f;
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (MODE == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s0[e] += (double)v[u][e];
-            s1[e] += (double)v[u][e] * (double)v[u][e];
+          for (int e = 0; e < V; ++e) {
+            s0[e] += (double)v[u].v[e];
+            s1[e] += (double)v[u].v[e] * (double)v[u].v[e];
           }
         } else {
           if (zmask) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[u][e] = z[u][e] > 0.f ? g[u][e] : 0.f;
+            for (int e = 0; e < V; ++e) g[u].v[e] = z[u].v[e] > 0.f ? g[u].v[e] : 0.f;
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s0[e] += (double)g[u][e];
-            s1[e] += (double)g[u][e] * (double)((v[u][e] - mu[e]) * is[e]);
+          for (int e = 0; e < V; ++e) {
+            s0[e] += (double)g[u].v[e];
+            s1[e] += (double)g[u].v[e] * (double)((v[u].v[e] - mu[e]) * is[e]);
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    red[tid * 8 + e] = s0[e];
-    red[tid * 8 + 4 + e] = s1[e];
+  for (int e = 0; e < V; ++e) {
+    red[tid * 2 * V + e] = s0[e];
+    red[tid * 2 * V + V + e] = s1[e];
   }
   __syncthreads();
   if (active && rl == 0) {
     for (int g = 1; g < rpb; ++g) {
-      const double* o = red + (g * qb + ql) * 8;
+      const double* o = red + (g * qb + ql) * 2 * V;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < V; ++e) {
         s0[e] += o[e];
-        s1[e] += o[4 + e];
+        s1[e] += o[V + e];
       }
     }
-    double* p0 = part + ((long)blockIdx.y * 2) * C + q * 4;
+    double* p0 = part + ((long)blockIdx.y * 2) * C + q * V;
     double* p1 = p0 + C;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < V; ++e) {
       p0[e] = s0[e];
       p1[e] = s1[e];
     }
@@ -339,32 +340,41 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const T* __restric
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(const T* __restrict__ g, const T* __restrict__ y,
-                                                                  const float* __restrict__ mean, const float* __restrict__ coef,
-                                                                  T* __restrict__ dy, long total, int C) {
+// MASK: g = dz * (z > 0) first;  DM: that g is also stored (the gradient of the residual branch)
+template <typename T, bool MASK, bool DM>
+__global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(const T* __restrict__ g, const T* __restrict__ zmask,
+                                                                  const T* __restrict__ y, const float* __restrict__ mean,
+                                                                  const float* __restrict__ coef, T* __restrict__ dy,
+                                                                  T* __restrict__ dmasked, long total, int C) {
+  constexpr int IT = MASK ? 2 : kBnIter;  // (three operands per iteration when masked: same number of loads in flight)
   const int c0 = (threadIdx.x * 8) & (C - 1);
   float mu[8], k1[8], k2[8], k3[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) mu[e] = mean[c0 + e], k1[e] = coef[c0 + e], k2[e] = coef[C + c0 + e], k3[e] = coef[2 * C + c0 + e];
-  const long base = (long)blockIdx.x * (kBnIter * 2048) + threadIdx.x * 8;
-  decltype(bn_ld8(y)) gv[kBnIter], yv[kBnIter];
+  const long base = (long)blockIdx.x * (IT * 2048) + threadIdx.x * 8;
+  decltype(bn_ld8(y)) gv[IT], yv[IT], zv[IT];
 #pragma unroll
-  for (int it = 0; it < kBnIter; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const long i = base + it * 2048;
     if (i < total) {
       gv[it] = bn_ld8(g + i);
       yv[it] = bn_ld8(y + i);
+      if (MASK) zv[it] = bn_ld8(zmask + i);
     }
   }
 #pragma unroll
-  for (int it = 0; it < kBnIter; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const long i = base + it * 2048;
     if (i < total) {
-      float o[8];
+      float o[8], gm[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = k1[e] * bn_get(gv[it], e) - k2[e] - k3[e] * (bn_get(yv[it], e) - mu[e]);
+      for (int e = 0; e < 8; ++e) {
+        gm[e] = bn_get(gv[it], e);
+        if (MASK) gm[e] = bn_get(zv[it], e) > 0.f ? gm[e] : 0.f;
+        o[e] = k1[e] * gm[e] - k2[e] - k3[e] * (bn_get(yv[it], e) - mu[e]);
+      }
       bn_st8(dy + i, o);
+      if (DM) bn_st8(dmasked + i, gm);
     }
   }
 }
@@ -389,23 +399,37 @@ void bn_apply_launch(const T* y, const float* scale, const float* shift, const T
 }
 
 template <typename T>
-void bn_bwd_apply_launch(const T* g, const T* y, const float* mean, const float* coef, T* dy, long M, int C, hipStream_t s) {
+void bn_bwd_apply_launch(const T* g, const T* zmask, const T* y, const float* mean, const float* coef, T* dy, T* dmasked, long M,
+                         int C, hipStream_t s) {
   const long total = M * C;
   if (bn_streamable(M, C)) {
-    bn_bwd_apply_stream_kernel<T><<<rs_cdiv(total, kBnIter * 2048L), 256, 0, s>>>(g, y, mean, coef, dy, total, C);
+    const int grid = rs_cdiv(total, (zmask ? 2 : kBnIter) * 2048L);
+    if (zmask && dmasked)
+      bn_bwd_apply_stream_kernel<T, true, true><<<grid, 256, 0, s>>>(g, zmask, y, mean, coef, dy, dmasked, total, C);
+    else if (zmask)
+      bn_bwd_apply_stream_kernel<T, true, false><<<grid, 256, 0, s>>>(g, zmask, y, mean, coef, dy, nullptr, total, C);
+    else if (dmasked)
+      bn_bwd_apply_stream_kernel<T, false, true><<<grid, 256, 0, s>>>(g, nullptr, y, mean, coef, dy, dmasked, total, C);
+    else
+      bn_bwd_apply_stream_kernel<T, false, false><<<grid, 256, 0, s>>>(g, nullptr, y, mean, coef, dy, nullptr, total, C);
     return;
   }
-  bn_bwd_apply_kernel<T><<<rs_cdiv(total / 4, 256), 256, 0, s>>>(g, nullptr, y, mean, coef, dy, nullptr, total / 4, C / 4);
+  bn_bwd_apply_kernel<T><<<rs_cdiv(total / 4, 256), 256, 0, s>>>(g, zmask, y, mean, coef, dy, dmasked, total / 4, C / 4);
 }
 
 template <typename T>
 int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const float* gamma, const float* beta, float* mean,
                      float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
                      long long* num_batches_tracked, void* workspace, hipStream_t s) {
-  const Geometry g = geometry(M, C);
+  const int V = (C % 8) == 0 ? 8 : 4;
+  const Geometry g = geometry(M, C, V);
   double* part = reinterpret_cast<double*>(workspace);
-  bn_partial_kernel<0, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
-                                                          g.rows_per_split);
+  if (V == 8)
+    bn_partial_kernel<0, T, 8><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
+                                                               g.rows_per_split);
+  else
+    bn_partial_kernel<0, T, 4><<<dim3(g.gx, g.R), 256, 0, s>>>(y, nullptr, nullptr, nullptr, nullptr, part, M, C, g.qb, g.rpb,
+                                                               g.rows_per_split);
   const BnStatsOut o = {eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, num_batches_tracked};
   bn_stats_finalize_kernel<double><<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, o);
   return RS_LAUNCH_RESULT();
@@ -414,15 +438,19 @@ int bn_train_stats_t(const T* y, long M, int C, float eps, float momentum, const
 template <typename T>
 int bn_bwd_t(const T* dz, const T* zmask, const T* y, const float* mean, const float* invstd, const float* gamma, T* dy,
              T* dmasked, float* dgamma, float* dbeta, long M, int C, void* workspace, hipStream_t s) {
-  const Geometry g = geometry(M, C);
+  const int V = (C % 8) == 0 ? 8 : 4;
+  const Geometry g = geometry(M, C, V);
   double* part = reinterpret_cast<double*>(workspace);
   float* coef = reinterpret_cast<float*>(part + (long)g.R * 2 * C);  // 3*C floats behind the partials
-  bn_partial_kernel<1, T><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb,
-                                                          g.rows_per_split);
+  if (V == 8)
+    bn_partial_kernel<1, T, 8><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb,
+                                                               g.rows_per_split);
+  else
+    bn_partial_kernel<1, T, 4><<<dim3(g.gx, g.R), 256, 0, s>>>(y, dz, zmask, mean, invstd, part, M, C, g.qb, g.rpb,
+                                                               g.rows_per_split);
   const BnBwdOut o = {gamma, invstd, dgamma, dbeta, coef};
   bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part, g.R, M, C, o);
-  const long total4 = M * (C / 4);
-  bn_bwd_apply_kernel<T><<<rs_cdiv(total4, 256), 256, 0, s>>>(dz, zmask, y, mean, coef, dy, dmasked, total4, C / 4);
+  bn_bwd_apply_launch(dz, zmask, y, mean, coef, dy, dmasked, M, C, s);
   return RS_LAUNCH_RESULT();
 }
 
@@ -594,11 +622,11 @@ extern "C" int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const fl
                                                                             merged ? bn_next_counter_set() : -1, o);
   if (!merged) bn_bwd_finalize_kernel<<<rs_cdiv(C, 16), 256, 0, s>>>(part2, slices, M, C, o.bw);
   if (dtype == RS_F32)
-    bn_bwd_apply_launch(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(y), mean, coef,
-                        reinterpret_cast<float*>(dy), M, C, s);
+    bn_bwd_apply_launch<float>(reinterpret_cast<const float*>(g), nullptr, reinterpret_cast<const float*>(y), mean, coef,
+                               reinterpret_cast<float*>(dy), nullptr, M, C, s);
   else if (dtype == RS_BF16)
-    bn_bwd_apply_launch(reinterpret_cast<const bf16_t*>(g), reinterpret_cast<const bf16_t*>(y), mean, coef,
-                        reinterpret_cast<bf16_t*>(dy), M, C, s);
+    bn_bwd_apply_launch<bf16_t>(reinterpret_cast<const bf16_t*>(g), nullptr, reinterpret_cast<const bf16_t*>(y), mean, coef,
+                                reinterpret_cast<bf16_t*>(dy), nullptr, M, C, s);
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();
@@ -612,6 +640,6 @@ extern "C" int rs_bn_bwd(const float* dz, const float* zmask, const float* y, co
 
 extern "C" long rs_bn_workspace_bytes(long M, int C) {
   if (M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
-  const Geometry g = geometry(M, C);
-  return (long)g.R * 2 * C * (long)sizeof(double);
+  const Geometry g4 = geometry(M, C, 4), g8 = geometry(M, C, 8);  // (either vector width may run)
+  return (long)(g4.R > g8.R ? g4.R : g8.R) * 2 * C * (long)sizeof(double);
 }

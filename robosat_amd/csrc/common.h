@@ -24,6 +24,44 @@ __device__ __forceinline__ void rs_st4(bf16_t* p, f32x4 v) {
 __device__ __forceinline__ float rs_ld1(const float* p) { return *p; }
 __device__ __forceinline__ float rs_ld1(const bf16_t* p) { return (float)*p; }
 
+// V = 4 or 8 consecutive activations as fp32 (V = 8: one 16-byte access in bf16, two in fp32).
+template <int V>
+struct rs_vecf {
+  float v[V];
+};
+template <int V, typename T>
+__device__ __forceinline__ rs_vecf<V> rs_ldv(const T* p) {
+  rs_vecf<V> r;
+  if constexpr (V == 4) {
+    const f32x4 t = rs_ld4(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = t[e];
+  } else if constexpr (sizeof(T) == 2) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = (float)t[e];
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *(reinterpret_cast<const f32x4*>(p) + 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = a[e], r.v[4 + e] = b[e];
+  }
+  return r;
+}
+template <int V, typename T>
+__device__ __forceinline__ void rs_stv(T* p, const rs_vecf<V>& r) {
+  if constexpr (V == 4) {
+    rs_st4(p, f32x4{r.v[0], r.v[1], r.v[2], r.v[3]});
+  } else if constexpr (sizeof(T) == 2) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)r.v[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  } else {
+    *reinterpret_cast<f32x4*>(p) = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+    *(reinterpret_cast<f32x4*>(p) + 1) = f32x4{r.v[4], r.v[5], r.v[6], r.v[7]};
+  }
+}
+
 // One pixel's 32 channels into fp32 registers: 16-byte loads issued together (4 in bf16, 8 in fp32).
 __device__ __forceinline__ void rs_ld_row32(const bf16_t* p, float (&v)[32]) {
   bf16x8 t[4];

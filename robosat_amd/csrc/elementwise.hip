@@ -34,22 +34,25 @@ __global__ void u8_to_nhwc4_norm_kernel(const uint8_t* __restrict__ img, float* 
   *reinterpret_cast<f32x4*>(y + i * 4) = v;
 }
 
-// F.max_pool2d on NHWC, 4 channels per thread.  Window scanned row-major with a strict '>' so the FIRST maximum
-// wins, as torch's max_pool2d_with_indices does; padding is -inf (never selected when any tap is valid).
-template <typename TI, typename TO>
+// F.max_pool2d on NHWC, V = 4 or 8 channels per thread (8 when C % 8 == 0: 16-byte accesses in bf16).  Window scanned
+// row-major with a strict '>' so the FIRST maximum wins, as torch's max_pool2d_with_indices does; padding is -inf (never
+// selected when any tap is valid).  One byte per output element records the winning tap for the backward.
+template <typename TI, typename TO, int V>
 __global__ void maxpool_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y, uint8_t* __restrict__ amax, int H,
-                                    int W, int C4, int k, int stride, int pad, int Ho, int Wo, long total) {
+                                    int W, int CV, int k, int stride, int pad, int Ho, int Wo, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % C4);
-  long pix = i / C4;
+  const int c = (int)(i % CV);
+  long pix = i / CV;
   const int ox = (int)(pix % Wo);
   pix /= Wo;
   const int oy = (int)(pix % Ho);
   const long n = pix / Ho;
   const float ninf = -__builtin_huge_valf();
-  f32x4 best = {ninf, ninf, ninf, ninf};
-  int bi[4] = {0, 0, 0, 0};
+  rs_vecf<V> best;
+  int bi[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) best.v[e] = ninf, bi[e] = 0;
   bool first = true;
   for (int r = 0; r < k; ++r) {
     const int iy = oy * stride - pad + r;
@@ -57,22 +60,26 @@ __global__ void maxpool_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y
     for (int s = 0; s < k; ++s) {
       const int ix = ox * stride - pad + s;
       if ((unsigned)ix >= (unsigned)W) continue;
-      const f32x4 v = rs_ld4(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
+      const rs_vecf<V> v = rs_ldv<V>(x + (((n * H + iy) * W + ix) * (long)CV + c) * V);
       const int tap = r * k + s;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (first || v[e] > best[e] || v[e] != v[e]) {  // torch: (val > maxval) || isnan(val)
-          best[e] = v[e];
+      for (int e = 0; e < V; ++e) {
+        if (first || v.v[e] > best.v[e] || v.v[e] != v.v[e]) {  // torch: (val > maxval) || isnan(val)
+          best.v[e] = v.v[e];
           bi[e] = tap;
         }
       }
       first = false;
     }
   }
-  rs_st4(y + i * 4, best);
+  rs_stv<V>(y + i * V, best);
   if (amax) {
-    const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-    *reinterpret_cast<uint32_t*>(amax + i * 4) = packed;
+#pragma unroll
+    for (int h = 0; h < V / 4; ++h) {
+      const uint32_t packed = (uint32_t)bi[4 * h] | ((uint32_t)bi[4 * h + 1] << 8) | ((uint32_t)bi[4 * h + 2] << 16) |
+                              ((uint32_t)bi[4 * h + 3] << 24);
+      *reinterpret_cast<uint32_t*>(amax + i * V + 4 * h) = packed;
+    }
   }
 }
 
@@ -254,8 +261,12 @@ int dispatch_final(const T* x, const float* w, const float* bias, float* out, lo
 template <typename TI, typename TO>
 int launch_maxpool(const void* x, void* y, uint8_t* argmax, int H, int W, int C, int k, int stride, int pad, int Ho,
                    int Wo, long total, hipStream_t s) {
-  maxpool_nhwc_kernel<TI, TO><<<rs_cdiv(total, 256), 256, 0, s>>>(reinterpret_cast<const TI*>(x), reinterpret_cast<TO*>(y),
-                                                                  argmax, H, W, C / 4, k, stride, pad, Ho, Wo, total);
+  if ((C & 7) == 0)
+    maxpool_nhwc_kernel<TI, TO, 8><<<rs_cdiv(total / 2, 256), 256, 0, s>>>(reinterpret_cast<const TI*>(x), reinterpret_cast<TO*>(y),
+                                                                           argmax, H, W, C / 8, k, stride, pad, Ho, Wo, total / 2);
+  else
+    maxpool_nhwc_kernel<TI, TO, 4><<<rs_cdiv(total, 256), 256, 0, s>>>(reinterpret_cast<const TI*>(x), reinterpret_cast<TO*>(y),
+                                                                       argmax, H, W, C / 4, k, stride, pad, Ho, Wo, total);
   return RS_LAUNCH_RESULT();
 }
 

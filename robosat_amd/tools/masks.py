@@ -17,7 +17,7 @@ import torch
 from PIL import Image
 from tqdm import tqdm
 
-from robosat_amd import ops
+from robosat_amd import ops, png
 from robosat_amd.colors import make_palette
 from robosat_amd.tiles import tiles_from_slippy_map
 
@@ -83,10 +83,8 @@ def main(args):
         palette = make_palette(*names)
         for tileset, mask in zip(group, masks):
             x, y, z = tileset[0][0]
-            out = Image.fromarray(mask, mode="P")
-            out.putpalette(palette)
             os.makedirs(os.path.join(args.masks, str(z), str(x)), exist_ok=True)
-            out.save(os.path.join(args.masks, str(z), str(x), str(y) + ".png"), optimize=True)
+            png.write_png(os.path.join(args.masks, str(z), str(x), str(y) + ".png"), mask.astype(np.uint8), "P", palette)
 
 
 def softvote(probs, axis=0, weights=None):

@@ -10,15 +10,15 @@ no collective."""
 import argparse
 import os
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
-from PIL import Image
 from torch.utils.data import DataLoader
 from tqdm import tqdm
 
-from robosat_amd import launch
+from robosat_amd import launch, png
 from robosat_amd.colors import continuous_palette_for_color
 from robosat_amd.config import load_config
 from robosat_amd.datasets import BufferedSlippyMapDirectory
@@ -117,21 +117,34 @@ def main(args):
                         batch_sampler=RankBatchSampler(len(directory), args.batch_size, rank, world))
     palette = continuous_palette_for_color("pink", 256)
 
-    # PNG encoding (optimize=True: ~10 ms per 512^2 tile) would cap the tool near 100 tiles/s on the thread that drives
-    # the GPU; a small pool encodes and writes while the next batch computes (PIL's encoder releases the GIL).  Same files.
+    # PNG encoding costs 3-10 ms per 512^2 tile: a pool encodes and writes while the next batches compute.  Pillow's encoder
+    # holds the GIL while it deflates (a thread pool then encodes ONE tile at a time: ~50 tiles/s); robosat_amd.png goes
+    # through zlib.compress, which does not.  Same mode, pixels and palette as the reference's files (predict.py:105-113).
     def write_png(q, x, y, z):
-        if num_classes == 2:
-            out = Image.fromarray(q, mode="P")
-            out.putpalette(palette)
-        else:
-            out = Image.fromarray(q, mode={2: "LA", 3: "RGB", 4: "RGBA"}[num_classes - 1])
         os.makedirs(os.path.join(args.probs, str(z), str(x)), exist_ok=True)
-        out.save(os.path.join(args.probs, str(z), str(x), str(y) + ".png"), optimize=True)
+        path = os.path.join(args.probs, str(z), str(x), str(y) + ".png")
+        if num_classes == 2:
+            png.write_png(path, q, "P", palette)
+        else:
+            png.write_png(path, q, {2: "LA", 3: "RGB", 4: "RGBA"}[num_classes - 1])
 
     writers = ThreadPoolExecutor(max_workers=int(os.environ.get("ROBOSAT_PNG_THREADS", "8")))
     pending = []
 
+    # ROBOSAT_TIMING=1: where the wall time of the loop went (waiting for the loader / device work incl. the copy back /
+    # waiting for the PNG writers), one line on stderr at the end
+    timing = os.environ.get("ROBOSAT_TIMING", "0") == "1"
+    spent = {"loader": 0.0, "device": 0.0, "writers": 0.0}
+    mark = time.perf_counter()
+
+    def lap(key):
+        nonlocal mark
+        now = time.perf_counter()
+        spent[key] += now - mark
+        mark = now
+
     for images, tiles in tqdm(loader, desc="Eval", unit="batch", ascii=True, disable=rank != 0):
+        lap("loader")
         if host_pipeline:
             probs = net.predict_probs(images.to(device, non_blocking=True)).cpu().numpy()
             quantized = []
@@ -142,13 +155,19 @@ def main(args):
                 quantized.append(q.squeeze() if num_classes == 2 else np.ascontiguousarray(q.transpose(1, 2, 0)))
         else:
             quantized = net.predict_quantized(images.to(device, non_blocking=True), overlap=args.overlap, mean=mean, std=std).cpu().numpy()
+        lap("device")
 
         for tile, q in zip(tiles, quantized):
             x, y, z = list(map(int, tile))
             pending.append(writers.submit(write_png, np.ascontiguousarray(q), x, y, z))
         while len(pending) > 256:  # bounded backlog
             pending.pop(0).result()
+        lap("writers")
 
     for job in pending:
         job.result()  # (re-raises a failed write)
     writers.shutdown()
+    lap("writers")
+    if timing:
+        print("rs predict rank {}: {} tiles; seconds waiting for the loader {:.2f}, on the device path {:.2f}, for the PNG writers {:.2f}".format(
+            rank, len(directory), spent["loader"], spent["device"], spent["writers"]), file=sys.stderr)

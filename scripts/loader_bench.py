@@ -27,6 +27,7 @@ ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--workers", type=int, default=16)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--train-tiles", type=int, default=1024)
+ap.add_argument("--only", choices=["predict", "train"], default=None)
 a = ap.parse_args()
 
 
@@ -36,10 +37,14 @@ def rs(args, env=None):
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
     e.setdefault("ROBOSAT_GPUS", "1")
     t0 = time.perf_counter()
+    e["ROBOSAT_TIMING"] = "1"
     r = subprocess.run([sys.executable, "-m", "robosat_amd.tools"] + args, env=e, capture_output=True, text=True)
     dt = time.perf_counter() - t0
     if r.returncode != 0:
         raise SystemExit(r.stdout[-2000:] + r.stderr[-2000:])
+    for line in r.stderr.splitlines():
+        if line.startswith("rs predict rank"):
+            print("#", line, flush=True)
     return dt
 
 
@@ -89,7 +94,7 @@ with tempfile.TemporaryDirectory() as tmp:
     small = subset("validation", a.tiles // 4, "ds_small")
     subset("training", a.train_tiles // 4, "ds_small")
 
-    for workers in (0, a.workers):
+    for workers in (() if a.only == "train" else (0, a.workers)):
         times = []
         for root, n in ((small, a.tiles // 4), (ds_root, a.tiles)):
             times.append(rs(["predict", "--batch_size", str(a.batch), "--checkpoint", ck, "--overlap", "32", "--tile_size", str(a.size), "--workers",
@@ -100,7 +105,7 @@ with tempfile.TemporaryDirectory() as tmp:
             a.tiles, a.size, a.batch, workers), "steady_tiles_per_s": round(steady, 1), "wall_s": [round(t, 2) for t in times],
             "tiles": [a.tiles // 4, a.tiles]}), flush=True)
 
-    for dtype, aug in (("fp32", False), ("bf16", False), ("bf16", True)):
+    for dtype, aug in (() if a.only == "predict" else (("fp32", False), ("bf16", False), ("bf16", True))):
         times = []
         for root, n in ((small, (a.train_tiles + a.tiles) // 4), (ds_root, a.train_tiles + a.tiles)):
             cfg = load_config(model_toml)

@@ -73,3 +73,32 @@ def test_augment_restatement_is_the_dihedral_group():
     three, _ = T.augment(img, msk, [1, 0, 0, 0], mean, std)
     assert np.array_equal(three, np.rot90(base, 3, axes=(1, 2)))
     assert np.array_equal(four, np.rot90(base[:, :, ::-1], 3, axes=(1, 2)))
+
+
+@pytest.mark.parametrize("mode,shape", [("P", (37, 53)), ("LA", (16, 16, 2)), ("RGB", (33, 20, 3)), ("RGBA", (8, 64, 4)), ("L", (5, 7))])
+def test_png_writer_round_trips_through_pillow(tmp_path, mode, shape):
+    """robosat_amd.png (the GIL-free writer `rs predict` / `rs masks` use) against Pillow, the reader of the reference's tools
+    (masks.py:48, serve, compare): same mode, same pixels, same palette as `Image.fromarray(...).putpalette(...).save()`."""
+    from PIL import Image
+
+    from robosat_amd import png
+    from robosat_amd.colors import continuous_palette_for_color
+
+    rng = np.random.default_rng(len(mode) + shape[0])
+    a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    palette = continuous_palette_for_color("pink", 256) if mode == "P" else None
+    path = str(tmp_path / "t.png")
+    png.write_png(path, a, mode, palette)
+    got = Image.open(path)
+    assert got.mode == mode and got.size == (shape[1], shape[0])
+    assert np.array_equal(np.array(got), a)
+    if mode == "P":
+        ref = Image.fromarray(a, mode="P")
+        ref.putpalette(palette)
+        ref.save(str(tmp_path / "ref.png"), optimize=True)
+        want = Image.open(str(tmp_path / "ref.png"))
+        assert np.array_equal(np.array(want), np.array(got))
+        assert want.getpalette()[:768] == got.getpalette()[:768] == list(palette)
+        assert np.array_equal(np.array(want.convert("RGB")), np.array(got.convert("RGB")))
+    with pytest.raises(ValueError):
+        png.encode_png(a, "RGB" if mode != "RGB" else "LA")

@@ -103,45 +103,106 @@ class BufferedSlippyMapDirectory(_TileDirectory):
         return probs[:, o:probs.shape[1] - o, o:probs.shape[2] - o]
 
 
-class DecodedTileCache:
-    """Every (image, mask) tile of a training / validation split decoded ONCE into uint8 tensors in HBM (SURVEY.md section
-    8f, N4).  What is cached is the output of the DETERMINISTIC head of the reference's transform chain -- mode
-    conversion, resize, centre crop (tools/train.py:250-253) -- i.e. exactly the pixels the random flips / rotations and
-    ``ToTensor`` + ``Normalize`` start from.  A 512x512 RGB tile + its mask is 1 MiB: 100 000 tiles fit the MI355X's 288 GB
-    with room to spare, and an epoch then costs no PNG/JPEG decode at all."""
+def draw_flip_rotations():
+    """The four draws of the random part of the reference's training transform (tools/train.py:254-257:
+    ``JointRandomHorizontalFlip(0.5)`` then three ``JointRandomRotation(0.5, 90)``), in its order, from Python's ``random``
+    as it does -- as ONE op code (flip + 2 * quarter turns) for ``rs_augment_tiles`` instead of four PIL transposes."""
+    import random
 
-    def __init__(self, image_dirs, label_dir, size, device, head_transform=None):
-        import numpy as np
-        from PIL import Image
+    flip = random.random() < 0.5
+    turns = sum(random.random() < 0.5 for _ in range(3))
+    return int(flip) + 2 * turns
 
+
+class UnaugmentedTiles(torch.utils.data.Dataset):
+    """Items ``(image uint8 [S,S,C], mask uint8 [S,S], op code, tiles)``: the DETERMINISTIC head of the reference's transform
+    chain -- mode conversion, resize, centre crop (tools/train.py:250-253) -- done on the host (in a DataLoader worker), i.e.
+    exactly the pixels its random flips / rotations and ``ToTensor`` + ``Normalize`` start from.  With ``draw=True`` the four
+    random numbers of the random part are drawn right here, where the reference's chain draws them (same worker, same order),
+    and travel as an op code; the transposes, ``ToTensor`` and ``Normalize`` then run on the device (``rs_augment_tiles``).
+    A tile crosses the DataLoader's queues and PCIe as 1 MiB of bytes instead of 5 MiB of floats + int64 labels."""
+
+    def __init__(self, image_dirs, label_dir, size, draw):
+        super().__init__()
         from .transforms import CenterCrop, ConvertImageMode, Resize
 
         self.source = SlippyMapTilesConcatenation(image_dirs, label_dir, joint_transform=None)
         target = (size, size)
-        to_image = [ConvertImageMode("RGB"), Resize(target, Image.BILINEAR), CenterCrop(target)]
-        to_mask = [ConvertImageMode("P"), Resize(target, Image.NEAREST), CenterCrop(target)]
-        images, masks, self.tiles = [], [], []
-        for i in range(len(self.source.target)):
-            tiles_and_images = [ds[i] for ds in self.source.inputs]
-            mask, mask_tile = self.source.target[i]
-            assert all(tile == mask_tile for _, tile in tiles_and_images), "image tile is the same as label tile"
-            planes = []
-            for image, _ in tiles_and_images:
-                for fn in to_image:
-                    image = fn(image)
-                planes.append(np.asarray(image, dtype=np.uint8))
-            for fn in to_mask:
-                mask = fn(mask)
-            images.append(np.concatenate(planes, axis=2))
-            masks.append(np.asarray(mask, dtype=np.uint8))
-            self.tiles.append(mask_tile)
+        self.to_image = [ConvertImageMode("RGB"), Resize(target, Image.BILINEAR), CenterCrop(target)]
+        self.to_mask = [ConvertImageMode("P"), Resize(target, Image.NEAREST), CenterCrop(target)]
+        self.draw = draw
+
+    def __len__(self):
+        return len(self.source)
+
+    def __getitem__(self, i):
+        import numpy as np
+
+        tiles_and_images = [ds[i] for ds in self.source.inputs]
+        mask, mask_tile = self.source.target[i]
+        assert all(tile == mask_tile for _, tile in tiles_and_images), "image tile is the same as label tile"
+        planes = []
+        for image, _ in tiles_and_images:
+            for fn in self.to_image:
+                image = fn(image)
+            planes.append(np.asarray(image, dtype=np.uint8))
+        for fn in self.to_mask:
+            mask = fn(mask)
+        image = torch.from_numpy(np.ascontiguousarray(np.concatenate(planes, axis=2)))
+        mask = torch.from_numpy(np.array(mask, dtype=np.uint8))
+        code = draw_flip_rotations() if self.draw else 0
+        return image, mask, code, [tile for _, tile in tiles_and_images]
+
+
+class DecodedTileCache:
+    """Every (image, mask) tile of a training / validation split decoded ONCE into uint8 tensors in HBM (SURVEY.md section
+    8f, N4): the items of ``UnaugmentedTiles`` (decoded by ``workers`` DataLoader processes).  A 512x512 RGB tile + its
+    mask is 1 MiB: 100 000 tiles fit the MI355X's 288 GB with room to spare, and an epoch then costs no PNG/JPEG decode at all."""
+
+    def __init__(self, image_dirs, label_dir, size, device, workers=0):
+        source = UnaugmentedTiles(image_dirs, label_dir, size, draw=False)
+        images, masks = [], []
+        for image, mask, _, _ in torch.utils.data.DataLoader(source, batch_size=64, num_workers=workers):
+            images.append(image.to(device, non_blocking=True))
+            masks.append(mask.to(device, non_blocking=True))
+        self.tiles = [tile for tile, _ in source.source.target.tiles]
         self.size = size
-        self.images = torch.from_numpy(np.stack(images)).to(device)  # [T, S, S, C] uint8
-        self.masks = torch.from_numpy(np.stack(masks)).to(device)    # [T, S, S] uint8
+        self.images = torch.cat(images)  # [T, S, S, C] uint8
+        self.masks = torch.cat(masks)    # [T, S, S] uint8
         self.device = device
 
     def __len__(self):
         return len(self.tiles)
+
+
+class HostDecodeLoader:
+    """The reference's training / validation ``DataLoader`` (tools/train.py:262-274) with its transform chain split where
+    it stops being deterministic: ``workers`` processes decode, convert, resize, crop and DRAW (``UnaugmentedTiles``); flip /
+    rot90 / ``ToTensor`` / ``Normalize`` run in one kernel on the device.  Yields what the reference's loader yields --
+    ``(images [N,C,S,S] fp32 normalised, masks [N,S,S] int64, tiles)`` -- already on the device; same augmentation
+    distribution, same seeded draws per worker as the host chain, bit-equal tensors (tests/test_gpu_tools.py)."""
+
+    def __init__(self, image_dirs, label_dir, size, batch_sampler, workers, device, mean, std):
+        self.dataset = UnaugmentedTiles(image_dirs, label_dir, size, draw=True)
+        self.loader = torch.utils.data.DataLoader(self.dataset, num_workers=workers, pin_memory=True, batch_sampler=batch_sampler)
+        self.device, self.mean, self.std = device, list(mean), list(std)
+        self.batch_sampler = batch_sampler  # (``set_epoch`` of the sharded sampler is reached through it, as on a DataLoader)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        from . import ops
+
+        for images, masks, codes, tiles in self.loader:
+            images = images.to(self.device, non_blocking=True)
+            masks = masks.to(self.device, non_blocking=True)
+            n, channels = images.shape[0], images.shape[3]
+            mean, std = (self.mean * channels)[:channels], (self.std * channels)[:channels]
+            index = torch.arange(n, dtype=torch.int32, device=self.device)
+            op = codes.to(torch.int32).to(self.device, non_blocking=True)
+            out, om = ops.augment_tiles(images, masks, index, op, mean, std)
+            yield out, om, tiles
 
 
 class DeviceAugmentLoader:
@@ -158,13 +219,7 @@ class DeviceAugmentLoader:
     def __len__(self):
         return len(self.batch_sampler)
 
-    @staticmethod
-    def draw_op():
-        import random
-
-        flip = random.random() < 0.5
-        turns = sum(random.random() < 0.5 for _ in range(3))
-        return int(flip) + 2 * turns
+    draw_op = staticmethod(draw_flip_rotations)
 
     def __iter__(self):
         from . import ops

@@ -105,20 +105,26 @@ with tempfile.TemporaryDirectory() as tmp:
             a.tiles, a.size, a.batch, workers), "steady_tiles_per_s": round(steady, 1), "wall_s": [round(t, 2) for t in times],
             "tiles": [a.tiles // 4, a.tiles]}), flush=True)
 
-    for dtype, aug in (() if a.only == "predict" else (("fp32", False), ("bf16", False), ("bf16", True))):
+    cases = [("fp32", "host", 1), ("bf16", "host", 1), ("fp32", "split", 1), ("bf16", "split", 1), ("bf16", "cache", 1), ("bf16", "cache", 3)]
+    for dtype, feed, epochs in (() if a.only == "predict" else cases):
         times = []
         for root, n in ((small, (a.train_tiles + a.tiles) // 4), (ds_root, a.train_tiles + a.tiles)):
             cfg = load_config(model_toml)
             cfg["model"]["compute_dtype"] = dtype
-            cfg["model"]["device_augment"] = aug
-            cfg["common"]["checkpoint"] = os.path.join(tmp, "pth_{}_{}_{}".format(dtype, int(aug), n))
+            cfg["model"]["device_augment"] = feed == "cache"
+            cfg["opt"]["epochs"] = epochs
+            cfg["common"]["checkpoint"] = os.path.join(tmp, "pth_{}_{}_{}_{}".format(dtype, feed, epochs, n))
             save_config(cfg, model_toml)
             dcfg = load_config(ds_toml)
             dcfg["common"]["dataset"] = root
             save_config(dcfg, ds_toml)
-            times.append(rs(["train", "--model", model_toml, "--dataset", ds_toml, "--workers", str(a.workers)]))
-        n_all, n_small = a.train_tiles + a.tiles, (a.train_tiles + a.tiles) // 4
+            times.append(rs(["train", "--model", model_toml, "--dataset", ds_toml, "--workers", str(a.workers)],
+                            env={"ROBOSAT_TRAIN_HOST_PIPELINE": "1" if feed == "host" else "0"}))
+        n_all, n_small = (a.train_tiles + a.tiles) * epochs, (a.train_tiles + a.tiles) // 4 * epochs
         steady = (n_all - n_small) / max(1e-9, times[1] - times[0])
-        print(json.dumps({"case": "rs train 1 epoch (train + validation pass), {} + {} tiles of {}^2, bs {}, {}, {}".format(
-            a.train_tiles, a.tiles, a.size, a.batch, dtype, "device-side augmentation (tile cache in HBM)" if aug else "{} DataLoader workers (PIL)".format(a.workers)),
-            "steady_tiles_per_s": round(steady, 1), "wall_s": [round(t, 2) for t in times], "tiles": [n_small, n_all]}), flush=True)
+        what = {"host": "the reference's whole transform chain in {} DataLoader workers (PIL, fp32 tensors)".format(a.workers),
+                "split": "default: {} workers decode/resize/crop + draw, the device flips/rotates/normalises".format(a.workers),
+                "cache": "device_augment: tiles decoded once ({} workers) into HBM, augmented on the device".format(a.workers)}[feed]
+        print(json.dumps({"case": "rs train {} epoch(s) (train + validation pass each), {} + {} tiles of {}^2, bs {}, {}, {}".format(
+            epochs, a.train_tiles, a.tiles, a.size, a.batch, dtype, what),
+            "steady_tiles_per_s": round(steady, 1), "wall_s": [round(t, 2) for t in times], "tile_passes": [n_small, n_all]}), flush=True)

@@ -91,3 +91,47 @@ def test_buffered_predict_tiles_match_reference(tmp_path):
         assert torch.equal(a_img, b_img), b_tile
     probs = np.random.default_rng(0).random((2, 320, 320)).astype(np.float32)
     assert np.array_equal(ours.unbuffer(probs), ref.unbuffer(probs)) and ours.unbuffer(probs).shape == (2, 256, 256)
+
+
+def test_split_chain_items_match_reference(tmp_path):
+    """The default `rs train` loader splits the reference's chain (train.py:248-260) where it stops being deterministic: the
+    worker does mode conversion / resize / crop and DRAWS (robosat_amd.datasets.UnaugmentedTiles), the device does the
+    transposes + ToTensor + Normalize (rs_augment_tiles; here its CPU statement oracle/tools_ref.augment).  Same seed ->
+    bit-equal items to the reference's own dataset + transform classes, and the same number of draws consumed."""
+    rd, rt = _reference_modules()
+    from oracle import tools_ref as T
+    from robosat_amd import datasets as md
+
+    size = 96
+    root = synth.make_dataset(str(tmp_path / "ds"), n_train=8, n_val=2, size=128, seed=12)
+    img, lab = os.path.join(root, "training", "images"), os.path.join(root, "training", "labels")
+    chain = rt.JointCompose([
+        rt.JointTransform(rt.ConvertImageMode("RGB"), rt.ConvertImageMode("P")),
+        rt.JointTransform(rt.Resize((size, size), 2), rt.Resize((size, size), 0)),
+        rt.JointTransform(rt.CenterCrop((size, size)), rt.CenterCrop((size, size))),
+        rt.JointRandomHorizontalFlip(0.5),
+        rt.JointRandomRotation(0.5, 90),
+        rt.JointRandomRotation(0.5, 90),
+        rt.JointRandomRotation(0.5, 90),
+        rt.JointTransform(rt.ImageToTensor(), rt.MaskToTensor()),
+        rt.JointTransform(rt.Normalize(mean=MEAN, std=STD), None),
+    ])
+    ref = rd.SlippyMapTilesConcatenation([img], lab, chain)
+    ours = md.UnaugmentedTiles([img], lab, size, draw=True)
+    assert len(ours) == len(ref) == 8
+    seen = set()
+    for i in range(len(ref)):
+        random.seed(300 + i)
+        b_img, b_mask, b_tiles = ref[i]
+        after_ref = random.random()
+        random.seed(300 + i)
+        u8, m8, code, tiles = ours[i]
+        after_ours = random.random()
+        assert after_ref == after_ours  # four draws each: the streams stay aligned for the next item
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (size, size, 3) and m8.dtype == torch.uint8
+        assert [tuple(t) for t in tiles] == [tuple(t) for t in b_tiles]
+        draws = [0.0 if code & 1 else 1.0] + [0.0] * (code >> 1) + [1.0] * (3 - (code >> 1))
+        a_img, a_mask = T.augment(u8.numpy(), m8.numpy(), draws, MEAN, STD)
+        assert np.array_equal(a_img, b_img.numpy()) and np.array_equal(a_mask, b_mask.numpy()), (i, code)
+        seen.add(code)
+    assert len(seen) >= 4  # (the seeds exercise several elements of the flip / rotation group)

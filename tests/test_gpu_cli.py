@@ -75,6 +75,36 @@ def test_rs_train_then_predict(tmp_path):
     assert worst <= 1
 
 
+def test_rs_train_several_epochs_then_resume(tmp_path):
+    """Checkpoints are written every epoch while training goes on (the saved optimizer state must be a copy: the fused Adam's
+    step counters live on the device, the file carries them on the host like a stock Adam's), and `--resume` continues from
+    one (reference tools/train.py:85-92,143-147)."""
+    from robosat_amd.config import load_config, save_config
+    from robosat_amd.tools import train as train_tool
+
+    tmp = str(tmp_path)
+    ds_root = synth.make_dataset(os.path.join(tmp, "ds"), n_train=8, n_val=4, size=256)
+    ckdir = os.path.join(tmp, "pth")
+    model_toml, ds_toml = synth.write_configs(tmp, ds_root, ckdir, loss="CrossEntropy", batch_size=2, image_size=256, epochs=2)
+    train_tool.main(argparse.Namespace(model=model_toml, dataset=ds_toml, checkpoint=None, resume=False, workers=0))
+    ck2 = os.path.join(ckdir, "checkpoint-00002-of-00002.pth")
+    ck = torch.load(ck2, map_location="cpu")
+    steps = {float(st["step"]) for st in ck["optimizer"]["state"].values()}
+    assert steps == {8.0} and ck["epoch"] == 2  # 2 epochs x (8 tiles / batch 2)
+    assert all(st["step"].device.type == "cpu" for st in ck["optimizer"]["state"].values())
+    assert int(ck["state_dict"]["module.resnet.bn1.num_batches_tracked"]) == 8
+
+    cfg = load_config(model_toml)
+    cfg["opt"]["epochs"] = 3
+    save_config(cfg, model_toml)
+    train_tool.main(argparse.Namespace(model=model_toml, dataset=ds_toml, checkpoint=ck2, resume=True, workers=0))
+    ck3 = torch.load(os.path.join(ckdir, "checkpoint-00003-of-00003.pth"), map_location="cpu")
+    assert ck3["epoch"] == 3 and {float(st["step"]) for st in ck3["optimizer"]["state"].values()} == {12.0}
+    assert int(ck3["state_dict"]["module.resnet.bn1.num_batches_tracked"]) == 12
+    log = open(os.path.join(ckdir, "log")).read()
+    assert "Epoch: 3/3" in log and "Epoch: 1/3" not in log
+
+
 def test_device_side_predict_pipeline_is_bit_identical_to_host_steps(tmp_path):
     """N1: uint8 tiles in, quantised bytes out, all on the device, must reproduce the bytes of the
     reference's host-side steps -- ToTensor + Normalize (fp32), softmax, unbuffer, np.digitize -- exactly."""

@@ -250,6 +250,34 @@ def test_device_augment_loader_reproduces_the_host_loader(tmp_path):
             assert [tuple(int(v) for v in t[0]) for t in gt] == [tuple(int(v[i]) for v in wt[0]) for i in range(len(gt))]
 
 
+@pytest.mark.parametrize("workers", [0, 2])
+def test_split_loader_reproduces_the_host_loader(tmp_path, workers):
+    """The default `rs train` loaders (workers decode + draw, the device augments: HostDecodeLoader) against the reference-style
+    host chain (ROBOSAT_TRAIN_HOST_PIPELINE=1), batch for batch, bit for bit -- with DataLoader workers too (each worker's
+    `random` is seeded from torch's generator: same torch seed, same draws)."""
+    from robosat_amd.tools.train import get_dataset_loaders, get_split_loaders
+
+    ds_root = synth.make_dataset(str(tmp_path / "ds"), n_train=10, n_val=4, size=160, seed=5)
+    model = {"common": {"image_size": 128, "batch_size": 2}}
+    dataset = {"common": {"dataset": ds_root}}
+    host_train, host_val = get_dataset_loaders(model, dataset, workers)
+    host = []
+    for k, loader in enumerate((host_train, host_val)):
+        random.seed(321 + k)
+        torch.manual_seed(77 + k)
+        host.append([(im.clone(), mk.clone(), tl) for im, mk, tl in loader])
+    split_train, split_val = get_split_loaders(model, dataset, workers, torch.device(DEV))
+    for k, (loader, want) in enumerate(zip((split_train, split_val), host)):
+        random.seed(321 + k)
+        torch.manual_seed(77 + k)
+        got = list(loader)
+        assert len(got) == len(want) == len(loader)
+        for (gi, gm, gt), (wi, wm, wt) in zip(got, want):
+            assert gi.is_cuda and gm.is_cuda and gi.dtype == torch.float32 and gm.dtype == torch.int64
+            assert torch.equal(gi.cpu(), wi) and torch.equal(gm.cpu(), wm)
+            assert [[int(v) for v in c] for c in gt[0]] == [[int(v) for v in c] for c in wt[0]]
+
+
 def test_rs_train_with_device_augment(tmp_path):
     """``[model] device_augment = true``: one epoch end to end, same artifacts."""
     from robosat_amd.config import load_config, save_config

@@ -321,6 +321,17 @@ int rs_conv2d_dgrad_bnstats_dt(const rs_conv_desc* d, int dtype, const void* dy,
 int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const float* mean, const float* invstd, const float* gamma,
                                void* dy, float* dgamma, float* dbeta, const float* partial, long rows, int dtype, long M,
                                int C, void* workspace, rs_stream_t stream);
+/* The ReLU mask as one bit per element (round 2).  autograd's ReLU backward (threshold_backward on the block output of
+ * torchvision's Bottleneck, `out = relu(bn3(...) + identity)`) only needs the SIGN of z; the data-gradient epilogue of a
+ * bottleneck's conv1 moves four Cout-wide operands (g out, residual gradient, bn_y, z) and is HBM-bound.
+ * rs_bn_apply_bits_dt = rs_bn_apply_dt that also writes `bits` (M*C/8 bytes; bit e of byte i: element 8*i + e of `out` is > 0;
+ * C must divide 2048, else RS_EINVAL); rs_conv2d_dgrad_bnstats_bits_dt = rs_conv2d_dgrad_bnstats_dt reading those bits
+ * instead of z (Cout % 8 == 0).  Same results bit for bit. */
+int rs_bn_apply_bits_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                        unsigned char* bits, int dtype, long M, int C, int relu, rs_stream_t stream);
+int rs_conv2d_dgrad_bnstats_bits_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight, const void* residual,
+                                    const unsigned char* relu_mask_bits, const void* bn_y, const float* bn_mean,
+                                    const float* bn_invstd, void* out, float* stats_partial, rs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Device-side input / output of `rs predict`: only bytes cross PCIe.

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 14
+ABI_VERSION = 15
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -97,6 +97,8 @@ SIGNATURES = {
     "rs_cat_split_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_conv2d_dgrad_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),
     "rs_bn_bwd_from_partials_dt": (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, c_long, c_int, P, P]),
+    "rs_bn_apply_bits_dt": (c_int, [P, P, P, P, P, P, c_int, c_long, c_int, c_int, P]),
+    "rs_conv2d_dgrad_bnstats_bits_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),
     "rs_nchw_to_nhwc4_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "rs_pack_stem_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "rs_stem_conv_fwd_bf16": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -115,9 +115,11 @@ class _Tape:
         self.t = {}
 
 
-def _bn_train(bn, y, residual=None, relu=True, partial=None):
+def _bn_train(bn, y, residual=None, relu=True, partial=None, want_bits=False):
     """Train-mode BatchNorm (+ residual, ReLU).  ``partial``: the statistics' partial sums when the producing convolution
-    already reduced them in its epilogue (``ops.conv2d_bnstats``) -- otherwise a read pass over ``y`` computes them."""
+    already reduced them in its epilogue (``ops.conv2d_bnstats``) -- otherwise a read pass over ``y`` computes them.
+    ``want_bits``: also returns z's ReLU mask as one bit per element (None where the layer's width has no bit form): what the
+    data-gradient epilogue that ends at this layer reads instead of z itself."""
 
     if partial is None:
         mean, invstd, scale, shift = ops.bn_train_stats(
@@ -127,16 +129,23 @@ def _bn_train(bn, y, residual=None, relu=True, partial=None):
             partial, y.numel() // y.shape[-1], bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean,
             bn.running_var, bn.num_batches_tracked)
     bn._folded = None
+    if want_bits:
+        if relu and ops.bn_bits_ok(y.shape[-1]):
+            z, bits = ops.bn_apply(y, scale, shift, residual=residual, relu=relu, want_bits=True)
+        else:
+            z, bits = ops.bn_apply(y, scale, shift, residual=residual, relu=relu), None
+        return z, (mean, invstd), bits
     z = ops.bn_apply(y, scale, shift, residual=residual, relu=relu)
     return z, (mean, invstd)
 
 
 def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
-    """conv -> train-mode BatchNorm (-> + residual -> ReLU) with the statistics fused into the convolution."""
+    """conv -> train-mode BatchNorm (-> + residual -> ReLU) with the statistics fused into the convolution: returns
+    (y, z, (mean, invstd), ReLU mask bits of z or None)."""
 
     y, partial = ops.conv2d_bnstats(src, w, stride=stride, pad=pad)
-    z, st = _bn_train(bn, y, residual=residual, relu=relu, partial=partial)
-    return y, z, st
+    z, st, bits = _bn_train(bn, y, residual=residual, relu=relu, partial=partial, want_bits=True)
+    return y, z, st, bits
 
 
 def _forward(net, x, tape):
@@ -163,14 +172,14 @@ def _forward(net, x, tape):
     for layer in net._blocks():
         for blk in layer:
             rec = {"blk": blk, "h": h}
-            y1, z1, rec["st1"] = _conv_bn(blk.bn1, h, blk.conv1.krsc(dt))
-            y2, z2, rec["st2"] = _conv_bn(blk.bn2, z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1)
+            y1, z1, rec["st1"], rec["b1"] = _conv_bn(blk.bn1, h, blk.conv1.krsc(dt))
+            y2, z2, rec["st2"], rec["b2"] = _conv_bn(blk.bn2, z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1)
             if blk.downsample is not None:
-                yd, idt, rec["std"] = _conv_bn(blk.downsample[1], h, blk.downsample[0].krsc(dt), stride=blk.stride, relu=False)
+                yd, idt, rec["std"], _ = _conv_bn(blk.downsample[1], h, blk.downsample[0].krsc(dt), stride=blk.stride, relu=False)
                 rec["yd"] = yd
             else:
                 idt = h
-            y3, z3, rec["st3"] = _conv_bn(blk.bn3, z2, blk.conv3.krsc(dt), residual=idt, relu=True)
+            y3, z3, rec["st3"], rec["b3"] = _conv_bn(blk.bn3, z2, blk.conv3.krsc(dt), residual=idt, relu=True)
             rec.update(y1=y1, z1=z1, y2=y2, z2=z2, y3=y3, z3=z3)
             tape.blocks.append(rec)
             h = z3
@@ -261,12 +270,14 @@ def _backward(net, tape, dlogits, arena):
     skip_grad = {id(r.layer2[0]): g_enc1, id(r.layer3[0]): g_enc2, id(r.layer4[0]): g_enc3}
     layer_heads = {id(r.layer1[0]), id(r.layer2[0]), id(r.layer3[0]), id(r.layer4[0])}
 
-    def dgrad_into_bn(dy, conv, out_hw, y, st, z, residual=None):
-        """Gradient at the OUTPUT of a BatchNorm+ReLU (z) from the convolution that consumed z, with the ReLU mask and
-        BatchNorm's two backward reductions done in the convolution's epilogue: returns (g, partial)."""
+    def dgrad_into_bn(dy, conv, out_hw, y, st, z, bits, residual=None):
+        """Gradient at the OUTPUT of a BatchNorm+ReLU (z) from the convolution that consumed z, with the ReLU mask (z's sign:
+        its bit form when the forward wrote one) and BatchNorm's two backward reductions done in the convolution's
+        epilogue: returns (g, partial)."""
         wd = conv.dgrad_weight(dy.dtype)
         return ops.conv2d_dgrad_bnstats(dy, wd, out_hw, y, st[0], st[1], ups=2 if conv.stride == 2 else 0,
-                                        pad=conv.k - 1 - conv.padding, residual=residual, relu_mask=z)
+                                        pad=conv.k - 1 - conv.padding, residual=residual,
+                                        relu_mask=z if bits is None else None, relu_mask_bits=bits)
 
     g_partial = None  # partial sums riding with g when a fused dgrad produced it
     blocks = tape.blocks
@@ -284,14 +295,14 @@ def _backward(net, tape, dlogits, arena):
         del g
         w3 = arena.conv(blk.conv3)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy3, rec["z2"], 1, 1, out=w3), dy3, rec["z2"])
-        g2, p2 = dgrad_into_bn(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]), rec["y2"], rec["st2"], rec["z2"])
+        g2, p2 = dgrad_into_bn(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]), rec["y2"], rec["st2"], rec["z2"], rec["b2"])
         del dy3
         dy2, _, _ = ops.bn_bwd_from_partials(g2, rec["y2"], rec["st2"][0], rec["st2"][1], blk.bn2.weight.detach(), p2,
                                              **bn_grads(blk.bn2))
         del g2
         w2 = arena.conv(blk.conv2)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=w2), dy2, rec["z1"])
-        g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"])
+        g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"], rec["b1"])
         del dy2
         dy1, _, _ = ops.bn_bwd_from_partials(g1, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), p1,
                                              **bn_grads(blk.bn1))
@@ -311,7 +322,7 @@ def _backward(net, tape, dlogits, arena):
             res = gm
         if bi > 0:  # h is the previous bottleneck's z3 = relu(bn3(y3) + identity): fuse its mask + reductions
             prev = blocks[bi - 1]
-            g, g_partial = dgrad_into_bn(dy1, blk.conv1, hw_in, prev["y3"], prev["st3"], prev["z3"], residual=res)
+            g, g_partial = dgrad_into_bn(dy1, blk.conv1, hw_in, prev["y3"], prev["st3"], prev["z3"], prev["b3"], residual=res)
         else:  # h is the stem's pooled output
             g, g_partial = _dgrad(dy1, blk.conv1, hw_in, residual=res), None
         del dy1, res, gm

@@ -309,7 +309,8 @@ __device__ __forceinline__ void bn_st8(float* p, const float (&v)[8]) {
 template <typename T, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const T* __restrict__ res,
-                                                              T* __restrict__ out, long total, int C, int relu) {
+                                                              T* __restrict__ out, unsigned char* __restrict__ bits, long total,
+                                                              int C, int relu) {
   const int c0 = (threadIdx.x * 8) & (C - 1);  // (C divides 2048: a power of two)
   float sc[8], sh[8];
 #pragma unroll
@@ -336,6 +337,12 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const T* __restric
         o[e] = relu ? fmaxf(t, 0.f) : t;
       }
       bn_st8(out + i, o);
+      if (bits) {  // the ReLU mask the backward needs, one bit per element: (stored value > 0)
+        unsigned int b = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b |= ((float)(T)o[e] > 0.f ? 1u : 0u) << e;
+        bits[i >> 3] = (unsigned char)b;
+      }
     }
   }
 }
@@ -384,18 +391,20 @@ inline bool bn_streamable(long M, int C) {
 }
 
 template <typename T>
-void bn_apply_launch(const T* y, const float* scale, const float* shift, const T* res, T* out, long M, int C, int relu,
-                     hipStream_t s) {
+int bn_apply_launch(const T* y, const float* scale, const float* shift, const T* res, T* out, unsigned char* bits, long M, int C,
+                    int relu, hipStream_t s) {
   const long total = M * C;
   if (bn_streamable(M, C)) {
     const int grid = rs_cdiv(total, kBnIter * 2048L);
     if (res)
-      bn_apply_stream_kernel<T, true><<<grid, 256, 0, s>>>(y, scale, shift, res, out, total, C, relu);
+      bn_apply_stream_kernel<T, true><<<grid, 256, 0, s>>>(y, scale, shift, res, out, bits, total, C, relu);
     else
-      bn_apply_stream_kernel<T, false><<<grid, 256, 0, s>>>(y, scale, shift, res, out, total, C, relu);
-    return;
+      bn_apply_stream_kernel<T, false><<<grid, 256, 0, s>>>(y, scale, shift, res, out, bits, total, C, relu);
+    return RS_LAUNCH_RESULT();
   }
+  if (bits) return RS_EINVAL;  // (the bit mask comes from the streaming form only)
   bn_apply_kernel<T><<<rs_cdiv(total / 4, 256), 256, 0, s>>>(y, scale, shift, res, out, total / 4, C / 4, relu);
+  return RS_LAUNCH_RESULT();
 }
 
 template <typename T>
@@ -562,19 +571,25 @@ extern "C" int rs_bn_finalize_stats(const float* partial, long rows, long M, int
   return RS_LAUNCH_RESULT();
 }
 
-extern "C" int rs_bn_apply_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,
-                              int dtype, long M, int C, int relu, rs_stream_t stream) {
+// rs_bn_apply_dt that also writes the ReLU mask of `out` as one bit per element (`bits`: M*C/8 bytes; bit e of byte i = element
+// 8*i + e is > 0) -- what the data-gradient epilogues read instead of `out` itself (rs_conv2d_dgrad_bnstats_bits_dt).  Needs a
+// channel count that divides 2048 (every BatchNorm of the ResNet-50 encoder); RS_EINVAL otherwise.
+extern "C" int rs_bn_apply_bits_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                                   unsigned char* bits, int dtype, long M, int C, int relu, rs_stream_t stream) {
   if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RS_F32)
-    bn_apply_launch(reinterpret_cast<const float*>(y), scale, shift, reinterpret_cast<const float*>(residual),
-                    reinterpret_cast<float*>(out), M, C, relu, s);
-  else if (dtype == RS_BF16)
-    bn_apply_launch(reinterpret_cast<const bf16_t*>(y), scale, shift, reinterpret_cast<const bf16_t*>(residual),
-                    reinterpret_cast<bf16_t*>(out), M, C, relu, s);
-  else
-    return RS_EINVAL;
-  return RS_LAUNCH_RESULT();
+    return bn_apply_launch(reinterpret_cast<const float*>(y), scale, shift, reinterpret_cast<const float*>(residual),
+                           reinterpret_cast<float*>(out), bits, M, C, relu, s);
+  if (dtype == RS_BF16)
+    return bn_apply_launch(reinterpret_cast<const bf16_t*>(y), scale, shift, reinterpret_cast<const bf16_t*>(residual),
+                           reinterpret_cast<bf16_t*>(out), bits, M, C, relu, s);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_bn_apply_dt(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                              int dtype, long M, int C, int relu, rs_stream_t stream) {
+  return rs_bn_apply_bits_dt(y, scale, shift, residual, out, nullptr, dtype, M, C, relu, stream);
 }
 
 extern "C" int rs_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out,

@@ -234,8 +234,9 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
              float* stats = nullptr, const void* bn_y = nullptr, const float* bn_mean = nullptr,
              const float* bn_invstd = nullptr, bool phase4 = false, void* out2 = nullptr, const void* mask2 = nullptr,
-             int csplit = 0) {
+             int csplit = 0, const unsigned char* mask_bits = nullptr) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
+  if (mask_bits && (relu_mask || !bn_y || (d->Cout & 7))) return RS_EINVAL;  // (bits: data gradients into a BatchNorm only)
   if (out2 && (csplit <= 0 || csplit >= d->Cout || residual || stats)) return RS_EINVAL;
   if (phase4 && (!phase_ok(d) || stats)) return RS_EINVAL;
   if (d->C2 > 0 && !src2) return RS_EINVAL;
@@ -260,6 +261,7 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.bn_y = reinterpret_cast<const T*>(bn_y);
   a.bn_mean = bn_mean;
   a.bn_invstd = bn_invstd;
+  a.mask_bits = mask_bits;
   a.out2 = reinterpret_cast<T*>(out2);
   a.mask2 = reinterpret_cast<const T*>(mask2);
   a.csplit = csplit;
@@ -496,6 +498,20 @@ extern "C" int rs_conv2d_dgrad_bnstats_dt(const rs_conv_desc* d, int dtype, cons
   if (dtype == RS_BF16)
     return conv_fwd<bf16_t>(d, dy, nullptr, weight, nullptr, nullptr, residual, relu_mask, out, stream, stats_partial, bn_y,
                             bn_mean, bn_invstd);
+  return RS_EINVAL;
+}
+
+extern "C" int rs_conv2d_dgrad_bnstats_bits_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight,
+                                               const void* residual, const unsigned char* relu_mask_bits, const void* bn_y,
+                                               const float* bn_mean, const float* bn_invstd, void* out, float* stats_partial,
+                                               rs_stream_t stream) {
+  if (!stats_partial || !bn_y || !bn_mean || !bn_invstd || !relu_mask_bits || (d && d->C2 != 0)) return RS_EINVAL;
+  if (dtype == RS_F32)
+    return conv_fwd<float>(d, dy, nullptr, weight, nullptr, nullptr, residual, nullptr, out, stream, stats_partial, bn_y, bn_mean,
+                           bn_invstd, false, nullptr, nullptr, 0, relu_mask_bits);
+  if (dtype == RS_BF16)
+    return conv_fwd<bf16_t>(d, dy, nullptr, weight, nullptr, nullptr, residual, nullptr, out, stream, stats_partial, bn_y, bn_mean,
+                            bn_invstd, false, nullptr, nullptr, 0, relu_mask_bits);
   return RS_EINVAL;
 }
 

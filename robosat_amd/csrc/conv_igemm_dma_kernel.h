@@ -33,6 +33,10 @@ struct ConvArgsT {
   const T* bn_y;
   const float* bn_mean;
   const float* bn_invstd;
+  // optional, instead of `mask` in those launches: the ReLU mask as one BIT per element (bit e of byte i covers element
+  // 8*i + e of the [M][Cout] tensor; rs_bn_apply_bits_dt writes it next to z).  The epilogue of a bottleneck's conv1 data
+  // gradient moves four Cout-wide operands; the mask as bits is a sixteenth of one of them.
+  const unsigned char* mask_bits;
   // optional second destination (the torch.cat split of a decoder data gradient): couts [0, csplit) go to `out` (row
   // stride csplit, `mask`), couts [csplit, Cout) to `out2` (row stride Cout - csplit, `mask2`); csplit % BN == 0
   T* out2;
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
   constexpr int G = (ES == 4 && EPI == EPI_BWD) ? 1 : 2;  // (up to 3 tensors x G x 4 registers of loads in flight per thread)
   static_assert(NIT * RPI == WGM * 32 && NIT % G == 0, "row groups tile the pass");
   const bool has_res = EPI != EPI_STATS && p.res != nullptr, has_mask = EPI != EPI_STATS && maskp != nullptr;
+  const bool has_bits = EPI == EPI_BWD && p.mask_bits != nullptr;
   constexpr bool has_bny = EPI == EPI_BWD;
   auto load_group = [&](int tm, int g0, long (&o)[G], bool (&ok)[G], u32x4 (&rr_)[G], u32x4 (&rm_)[G], u32x4 (&ry_)[G])
       __attribute__((always_inline)) {
@@ -463,6 +468,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     if (has_mask) {
 #pragma unroll
       for (int i = 0; i < G; ++i) rm_[i] = *reinterpret_cast<const u32x4*>(maskp + o[i]);
+    }
+    if constexpr (EPI == EPI_BWD) {
+      if (has_bits) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) rm_[i][0] = p.mask_bits[o[i] >> 3];
+      }
     }
     if constexpr (has_bny) {
 #pragma unroll
@@ -507,6 +518,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
         unpack(rm_[i], z);
 #pragma unroll
         for (int e = 0; e < EPP; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
+      }
+      if constexpr (EPI == EPI_BWD) {
+        if (has_bits) {
+          const unsigned int bits = EPP == 8 ? rm_[i][0] : (rm_[i][0] >> (o[i] & 4));  // (fp32 pieces are 4 elements: a nibble)
+#pragma unroll
+          for (int e = 0; e < EPP; ++e) v[e] = ((bits >> e) & 1u) ? v[e] : 0.f;
+        }
       }
       if (ok[i]) Piece<T>::store(outp + o[i], v);
       if constexpr (EPI != EPI_EVAL) {

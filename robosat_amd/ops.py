@@ -150,10 +150,12 @@ def conv2d_bnstats(src1, weight, src2=None, ups=0, stride=1, pad=0):
     return out, partial
 
 
-def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0, residual=None, relu_mask=None):
+def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0, residual=None, relu_mask=None,
+                         relu_mask_bits=None):
     """Data-gradient convolution whose output g is the gradient at a BatchNorm+ReLU output: ``rs_conv2d_fwd`` semantics
     (``wd`` = packed dgrad weights, optional residual, relu_mask = z) + per-tile partial sums of BatchNorm's two backward
-    reductions (``rs_conv2d_dgrad_bnstats_dt``).  Returns (g, partial [tiles,2,C])."""
+    reductions (``rs_conv2d_dgrad_bnstats_dt``).  ``relu_mask_bits`` (from ``bn_apply(..., want_bits=True)``) replaces
+    ``relu_mask`` by one bit per element (``rs_conv2d_dgrad_bnstats_bits_dt``).  Returns (g, partial [tiles,2,C])."""
 
     d = conv_desc(dy, wd, None, ups, 1, pad, False, 0, out_hw)
     act = dy.dtype
@@ -167,16 +169,25 @@ def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0,
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.rs_conv2d_dgrad_bnstats_dt(
-        ctypes.byref(d), _dt(dy), _dev(dy, "dy", act), _dev(wd, "weight", act), _dev(residual, "residual", act),
-        _dev(relu_mask, "relu_mask", act), _dev(bn_y, "bn_y", act), _dev(bn_mean, "bn_mean"), _dev(bn_invstd, "bn_invstd"),
-        _dev(out, "out", act), _dev(partial, "partial"), _stream())
-    check(rc, "rs_conv2d_dgrad_bnstats_dt")
+    if relu_mask_bits is not None:
+        assert relu_mask_bits.numel() * 8 == out.numel(), "one mask bit per output element"
+        rc = lib.rs_conv2d_dgrad_bnstats_bits_dt(
+            ctypes.byref(d), _dt(dy), _dev(dy, "dy", act), _dev(wd, "weight", act), _dev(residual, "residual", act),
+            _dev(relu_mask_bits, "relu_mask_bits", torch.uint8), _dev(bn_y, "bn_y", act), _dev(bn_mean, "bn_mean"),
+            _dev(bn_invstd, "bn_invstd"), _dev(out, "out", act), _dev(partial, "partial"), _stream())
+        check(rc, "rs_conv2d_dgrad_bnstats_bits_dt")
+    else:
+        rc = lib.rs_conv2d_dgrad_bnstats_dt(
+            ctypes.byref(d), _dt(dy), _dev(dy, "dy", act), _dev(wd, "weight", act), _dev(residual, "residual", act),
+            _dev(relu_mask, "relu_mask", act), _dev(bn_y, "bn_y", act), _dev(bn_mean, "bn_mean"), _dev(bn_invstd, "bn_invstd"),
+            _dev(out, "out", act), _dev(partial, "partial"), _stream())
+        check(rc, "rs_conv2d_dgrad_bnstats_dt")
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
         _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                        conv_bytes(d, 2 if bf else 4, 1 + (residual is not None) + (relu_mask is not None)))
+                        conv_bytes(d, 2 if bf else 4, 1 + (residual is not None) + (relu_mask is not None))
+                        + (out.numel() // 8 if relu_mask_bits is not None else 0))
     return out, partial
 
 
@@ -629,14 +640,24 @@ def bn_train_stats(y, gamma, beta, eps, momentum, running_mean=None, running_var
     return mean, invstd, scale, shift
 
 
-def bn_apply(y, scale, shift, residual=None, relu=False):
+def bn_bits_ok(c):
+    """Channel counts for which ``bn_apply(..., want_bits=True)`` is available (the streaming form: C divides 2048)."""
+
+    return 8 <= c <= 2048 and 2048 % c == 0
+
+
+def bn_apply(y, scale, shift, residual=None, relu=False, want_bits=False):
+    """z = relu?(y * scale + shift (+ residual)).  ``want_bits``: returns (z, bits) with the ReLU mask of z as one bit per
+    element (uint8 [numel/8]; bit e of byte i: element 8*i + e is > 0) for ``conv2d_dgrad_bnstats(relu_mask_bits=...)``."""
+
     c = y.shape[-1]
     out = torch.empty_like(y)
-    rc = _lib.lib().rs_bn_apply_dt(_dev(y, "y", y.dtype), _dev(scale, "scale"), _dev(shift, "shift"),
-                                   _dev(residual, "residual", y.dtype), _dev(out, "out", y.dtype), _dt(y), y.numel() // c, c,
-                                   int(relu), _stream())
-    check(rc, "rs_bn_apply")
-    return out
+    bits = torch.empty(y.numel() // 8, device=y.device, dtype=torch.uint8) if want_bits else None
+    rc = _lib.lib().rs_bn_apply_bits_dt(_dev(y, "y", y.dtype), _dev(scale, "scale"), _dev(shift, "shift"),
+                                        _dev(residual, "residual", y.dtype), _dev(out, "out", y.dtype),
+                                        _dev(bits, "bits", torch.uint8), _dt(y), y.numel() // c, c, int(relu), _stream())
+    check(rc, "rs_bn_apply_bits_dt")
+    return (out, bits) if want_bits else out
 
 
 def bn_bwd(dz, zmask, y, mean, invstd, gamma, want_masked=False, dgamma=None, dbeta=None):

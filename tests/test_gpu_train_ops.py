@@ -326,3 +326,37 @@ def test_decoder_dgrad_phase_form(c1, c2, cout, h, w, dtype):
                 return  # csplit not a multiple of the tile's cout width for this shape
             close(nchw(e1.float()), a.grad * (m1 > 0), tol, "fused d skip")
             close(nchw(e2.float()), b.grad * (m2 > 0), tol, "fused d prev")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 64, 24, 20, 256, 1, 0), (3, 128, 16, 16, 128, 3, 1), (1, 512, 9, 7, 2048, 1, 0)],
+                         ids=["conv1_dgrad_128x128", "conv2_dgrad", "ragged_rows"])
+def test_relu_mask_as_bits(case, dtype):
+    """The ReLU mask of a BatchNorm output as one bit per element: `bn_apply(want_bits=True)` writes exactly (z > 0), and the
+    data-gradient epilogue reading the bits (rs_conv2d_dgrad_bnstats_bits_dt) returns, bit for bit, what it returns reading z
+    (rs_conv2d_dgrad_bnstats_dt) -- output and both BatchNorm partial sums."""
+    from robosat_amd import ops
+
+    n, cin, h, w, cout, k, pad = case
+    y = rnd(n, h, w, cout, seed=31).to(DEV).to(dtype)
+    res = rnd(n, h, w, cout, seed=32).to(DEV).to(dtype)
+    scale, shift = (torch.rand(cout) + 0.5).to(DEV), (rnd(cout, seed=33) * 0.3).to(DEV)
+    z, bits = ops.bn_apply(y, scale, shift, residual=res, relu=True, want_bits=True)
+    z_plain = ops.bn_apply(y, scale, shift, residual=res, relu=True)
+    assert torch.equal(z, z_plain)
+    want = (z.float() > 0).reshape(-1, 8).to(torch.uint8)
+    want = (want << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert 0.2 < float((z > 0).float().mean()) < 0.8
+
+    dy = (rnd(n, h, w, cin, seed=34) * 0.1).to(DEV).to(dtype)
+    wd = (rnd(cout, k, k, cin, seed=35) * 0.05).to(DEV).to(dtype)  # (already in data-gradient layout: any weights do)
+    bn_y = rnd(n, h, w, cout, seed=36).to(DEV).to(dtype)
+    mean, inv = rnd(cout, seed=37).to(DEV), (torch.rand(cout) + 0.5).to(DEV)
+    rgrad = rnd(n, h, w, cout, seed=38).to(DEV).to(dtype)
+    g0, p0 = ops.conv2d_dgrad_bnstats(dy, wd, (h, w), bn_y, mean, inv, pad=pad, residual=rgrad, relu_mask=z)
+    g1, p1 = ops.conv2d_dgrad_bnstats(dy, wd, (h, w), bn_y, mean, inv, pad=pad, residual=rgrad, relu_mask_bits=bits)
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert float((g1 == 0).float().mean()) > 0.2  # the mask did something
+    with pytest.raises(Exception):
+        ops.bn_apply(y[..., :24].contiguous(), scale[:24], shift[:24], relu=True, want_bits=True)  # 24 does not divide 2048

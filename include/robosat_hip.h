@@ -218,6 +218,7 @@ const char* rs_conv2d_tile_name_bf16(int tile);
 /* rs_conv2d_wgrad with bf16 dy / sources; dw is fp32 KRSC (the optimizer's master gradient). */
 long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d);
 int rs_conv2d_wgrad_bf16_form(const rs_conv_desc* d); /* 0 tap-per-block, 1 all-taps thin kernel, 2 phase form (4/9 MACs) */
+int rs_conv2d_wgrad_bf16_tile(const rs_conv_desc* d); /* (couts << 16) | (cins of a second per-source launch << 8) | cins of the tile; 0 = thin kernel */
 int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, const rs_bf16* src1, const rs_bf16* src2, float* dw,
                          void* workspace, rs_stream_t stream);
 

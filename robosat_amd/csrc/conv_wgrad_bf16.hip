@@ -445,6 +445,17 @@ extern "C" int rs_conv2d_wgrad_bf16_form(const rs_conv_desc* d) {
   return phase_ok(d) ? 2 : 0;
 }
 
+// The tile rs_conv2d_wgrad_bf16 launches for `d` (for per-symbol reports: the kernel is instantiated per tile), as
+// (couts << 16) | cins of the first launch, | (cins of the second source's launch) << 8 when the two concat sources run
+// separate launches; 0 for the all-taps thin kernel.
+extern "C" int rs_conv2d_wgrad_bf16_tile(const rs_conv_desc* d) {
+  if (!valid(d)) return RS_EINVAL;
+  int tb = 0, ts = 0;
+  if (rs_wgrad_thin_plan(d, &tb, &ts)) return 0;
+  const Plan pl = plan(d);
+  return (pl.bmo << 16) | (pl.bno2 << 8) | pl.bno;
+}
+
 extern "C" long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
   int tb = 0, tslices = 0;

@@ -442,6 +442,22 @@ def stem_conv_bf16(x4, w_packed, scale=None, shift=None, relu=False):
     return out
 
 
+def wgrad_kernel_name(d, form=None):
+    """The bf16 weight-gradient kernel ``rs_conv2d_wgrad_bf16`` launches for ``d``, named like its instantiation (rocprofv3
+    shows ``conv_wgrad_bf16<128, 128, 2, 2, 64, false>`` for ``conv_wgrad_bf16<128x128>``; ``phase`` = the last flag)."""
+
+    lib = _lib.lib()
+    if form is None:
+        form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d))
+    if form == 1:
+        return "conv_wgrad_thin_bf16"
+    t = lib.rs_conv2d_wgrad_bf16_tile(ctypes.byref(d))
+    if t <= 0:
+        raise ValueError("rs_conv2d_wgrad_bf16_tile: invalid arguments")
+    tile = "{}x{}".format(t >> 16, t & 255) + ("+{}x{}".format(t >> 16, (t >> 8) & 255) if (t >> 8) & 255 else "")
+    return "conv_wgrad_bf16<{}{}>".format("phase," if form == 2 else "", tile)
+
+
 def stem_conv_wgrad_bf16(dy, x4):
     """Packed fp32 gradient [64,7,8,4] of the stem filter from bf16 dy [N,H/2,W/2,64] and the NHWC4 bf16 input."""
 
@@ -615,7 +631,7 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         es = 2 if bf else 4
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
         form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d)) if bf else 0
-        name = ("conv_wgrad_bf16", "conv_wgrad_thin_bf16", "conv_wgrad_bf16<phase>")[form] if bf else "conv_wgrad_f32"
+        name = wgrad_kernel_name(d, form) if bf else "conv_wgrad_f32"
         _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes,
                 conv_flops(d) * (4.0 / 9.0 if form == 2 else 1.0))
     return dw

@@ -154,6 +154,14 @@ def test_wgrad_bf16(case):
     dw = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=pad)
     assert dw.dtype == torch.float32
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
+    # the instantiation the case is named after is the one that ran (what bench.py reports per symbol)
+    from robosat_amd import _lib
+    expected = {"128x128": "conv_wgrad_bf16<128x128>", "128x64": "conv_wgrad_bf16<128x64>", "64x128": "conv_wgrad_bf16<64x128>",
+                "64x64_s2": "conv_wgrad_bf16<64x64>", "32x128_generic": "conv_wgrad_bf16<32x128>",
+                "32x32_generic": "conv_wgrad_bf16<32x32>", "thin_c64": "conv_wgrad_thin_bf16", "32x32": "conv_wgrad_thin_bf16"}
+    if case[0] in expected:
+        d = _lib.ConvDesc(n, h, w, cin, 0, 0, k, k, stride, pad, y.shape[2], y.shape[3], cout, 0, 0)
+        assert ops.wgrad_kernel_name(d) == expected[case[0]]
 
 
 @pytest.mark.parametrize("cin,h,w", [(128, 16, 12), (32, 4, 8), (64, 12, 12)])
@@ -171,7 +179,8 @@ def test_wgrad_bf16_thin_upsample(cin, h, w):
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
 
 
-@pytest.mark.parametrize("n,c1,c2,cout,h,w", [(2, 128, 64, 64, 12, 10), (1, 256, 0, 128, 9, 7), (3, 64, 64, 256, 5, 16), (2, 256, 64, 128, 16, 16)])
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [(2, 128, 64, 64, 12, 10), (1, 256, 0, 128, 9, 7), (3, 64, 64, 256, 5, 16), (2, 256, 64, 128, 16, 16),
+                                              (1, 512, 256, 64, 6, 8)])
 def test_wgrad_bf16_upsample_concat(n, c1, c2, cout, h, w):
     """DecoderBlock filter gradient; takes the phase form (16 parity/offset reductions over SOURCE pixels + combine)."""
     from robosat_amd import ops
@@ -185,6 +194,12 @@ def test_wgrad_bf16_upsample_concat(n, c1, c2, cout, h, w):
     y.backward(gy)
     dw = ops.conv2d_wgrad(nhwc(gy), nhwc(a), 3, 3, src2=nhwc(b) if c2 else None, ups=1, pad=1)
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
+    from robosat_amd import _lib
+    d = _lib.ConvDesc(n, h, w, c1, c2, 1, 3, 3, 1, 1, 2 * h, 2 * w, cout, 0, 0)
+    expected = {(128, 64, 64): "conv_wgrad_bf16<phase,64x128+64x64>", (256, 0, 128): "conv_wgrad_bf16<phase,128x128>",
+                (64, 64, 256): "conv_wgrad_bf16<phase,128x64>", (256, 64, 128): "conv_wgrad_bf16<phase,128x128+128x64>",
+                (512, 256, 64): "conv_wgrad_bf16<phase,64x128>"}
+    assert ops.wgrad_kernel_name(d) == expected[(c1, c2, cout)]
 
 
 def test_bn_train_bf16():

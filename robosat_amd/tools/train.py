@@ -17,6 +17,7 @@ import argparse
 import collections
 import os
 import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -224,6 +225,7 @@ def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, 
     metrics = Metrics(range(num_classes))
 
     net.train() if training else net.eval()
+    started = time.perf_counter()
 
     for images, masks, tiles in tqdm(loader, desc=desc, unit="batch", ascii=True, disable=not master):
         images = images.to(device, non_blocking=True)
@@ -250,6 +252,8 @@ def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, 
     # one sync per epoch; same normalisation quirk as the reference: sum of batch-mean losses / number of samples
     # (with W ranks a global batch's loss is the mean of the ranks' shard losses and it holds W shards' samples)
     total_loss, total_samples = parallel.average_scalars([float(running_loss.item()), float(num_samples)], device)
+    if master and os.environ.get("ROBOSAT_TIMING", "0") == "1":  # (after the .item() above: the device has finished the pass)
+        print("rs train rank 0: {} pass of {} tiles in {:.2f} s".format(desc, num_samples, time.perf_counter() - started), file=sys.stderr)
     total_samples *= dist.get_world_size() if dist.is_initialized() else 1
     if metrics._counts is not None:
         parallel.sum_counts(metrics._counts)

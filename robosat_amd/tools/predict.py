@@ -143,7 +143,27 @@ def main(args):
         spent[key] += now - mark
         mark = now
 
-    for images, tiles in tqdm(loader, desc="Eval", unit="batch", ascii=True, disable=rank != 0):
+    def submit(tiles, quantized):
+        for tile, q in zip(tiles, quantized):
+            x, y, z = list(map(int, tile))
+            pending.append(writers.submit(write_png, np.array(q, copy=True), x, y, z))  # (a copy: the staging buffer is reused)
+        while len(pending) > 256:  # bounded backlog
+            pending.pop(0).result()
+
+    # The device-side pipeline runs one batch AHEAD of the host: batch i's bytes come back (asynchronously, into one of two
+    # pinned buffers) while batch i+1 is already uploading and computing, so the GPU does not wait for the loader hand-over,
+    # the PNG submissions or the copy itself.
+    staging, inflight = [None, None], None
+    ahead = os.environ.get("ROBOSAT_PREDICT_AHEAD", "1") == "1"  # (measurement knob: 0 = collect every batch at once)
+
+    def collect(entry):
+        host, event, tiles = entry
+        event.synchronize()
+        lap("device")
+        submit(tiles, host.numpy())
+        lap("writers")
+
+    for step, (images, tiles) in enumerate(tqdm(loader, desc="Eval", unit="batch", ascii=True, disable=rank != 0)):
         lap("loader")
         if host_pipeline:
             probs = net.predict_probs(images.to(device, non_blocking=True)).cpu().numpy()
@@ -153,16 +173,27 @@ def main(args):
                 assert np.allclose(np.sum(prob, axis=0), 1.0, atol=1e-6), "single channel requires probabilities to sum up to one"
                 q = quantize(prob[1:, :, :])
                 quantized.append(q.squeeze() if num_classes == 2 else np.ascontiguousarray(q.transpose(1, 2, 0)))
-        else:
-            quantized = net.predict_quantized(images.to(device, non_blocking=True), overlap=args.overlap, mean=mean, std=std).cpu().numpy()
+            lap("device")
+            submit(tiles, quantized)
+            lap("writers")
+            continue
+        q_dev = net.predict_quantized(images.to(device, non_blocking=True), overlap=args.overlap, mean=mean, std=std)
+        slot = step & 1
+        if staging[slot] is None or staging[slot].shape[1:] != q_dev.shape[1:] or staging[slot].shape[0] < q_dev.shape[0]:
+            staging[slot] = torch.empty(q_dev.shape, dtype=q_dev.dtype, pin_memory=True)
+        host = staging[slot][:q_dev.shape[0]]
+        host.copy_(q_dev, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        if inflight is not None:
+            collect(inflight)  # (the previous batch: its slot is free again before the next batch reuses it)
+        inflight = (host, event, tiles)
         lap("device")
-
-        for tile, q in zip(tiles, quantized):
-            x, y, z = list(map(int, tile))
-            pending.append(writers.submit(write_png, np.ascontiguousarray(q), x, y, z))
-        while len(pending) > 256:  # bounded backlog
-            pending.pop(0).result()
-        lap("writers")
+        if not ahead:
+            collect(inflight)
+            inflight = None
+    if inflight is not None:
+        collect(inflight)
 
     for job in pending:
         job.result()  # (re-raises a failed write)

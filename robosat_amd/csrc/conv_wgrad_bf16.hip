@@ -102,7 +102,7 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
 // G's that make up each filter tap: dW[ky][kx] = sum_{(py,r) : ky in S(py,r)} sum_{(px,s) : kx in S(px,s)} G, with
 // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2} (the taps that hit the same source pixel).
 template <int BMo, int BNo, int WGM, int WGN, int PK, bool PHASE>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const WgradArgsB p) {
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wgrad_bf16(const WgradArgsB p) {
   constexpr int NW = WGM * WGN;          // waves
   constexpr int NS = PK / 16;            // MFMA k-steps per chunk
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
@@ -194,8 +194,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   //      row within the instruction, 16-byte position, and the (swizzled) channel piece it fetches.
   const int ra_a = lane / (ROWA / 16), pp_a = lane % (ROWA / 16);
   const int ra_b = lane / (ROWB_ / 16), pp_b = lane % (ROWB_ / 16);
-  const int swa = WA > 1 ? ((ra_a / RPBA) & (WA - 1)) : 0;  // swz(R) for R = RIA*jj + ra_a (RIA is a multiple of 4)
-  const int swb = WB > 1 ? ((ra_b / RPBB) & (WB - 1)) : 0;
+  // swz(R) of the LDS row R = RIA * (wave + NW*j) + ra_a this lane fills: RIA*NW is a multiple of the swizzle period
+  // (WA*RPBA rows), so the row's swizzle does not depend on j
+  static_assert((RIA * NW) % (WA * RPBA) == 0 && (RIB * NW) % (WB * RPBB) == 0, "swizzle period");
+  const int swa = WA > 1 ? (((RIA * wave + ra_a) / RPBA) & (WA - 1)) : 0;
+  const int swb = WB > 1 ? (((RIB * wave + ra_b) / RPBB) & (WB - 1)) : 0;
   const int gpa = (((pp_a >> 2) ^ swa) << 2) | (pp_a & 3);  // global 16-byte piece (8 channels) of the row
   const int gpb = (((pp_b >> 2) ^ swb) << 2) | (pp_b & 3);
   const int cola = (co0 + gpa * 8) * 2;                     // byte offset of the piece inside a dy row
@@ -248,13 +251,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
   //      piece and LDS rows R = 16s + 8*(g>>1) + 4t + (q>>2); lane q addresses row (q>>2), channels 4*(q&3)..+3.
   const int g = lane >> 4, q = lane & 15, jr = q >> 2;
   const int chb = (16 * (g & 1) + 4 * (q & 3)) * 2;
-  const int rsw_a = WA > 1 ? ((jr / RPBA) & (WA - 1)) : 0;  // swz(R): R = 4*(...) + jr
-  const int rsw_b = WB > 1 ? ((jr / RPBB) & (WB - 1)) : 0;
-  int aoff[TM], boff[TN];
+  // the two halves of a fragment read rows 16s + 8*(g>>1) + 4t + jr (t = 0, 1): swz(R) per half (for tiles up to 128 wide
+  // the period divides 4 and both halves share it; the 256-wide tile's period is 8 rows)
+  int aoff[TM][2], boff[TN][2];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) aoff[tm] = (8 * (g >> 1) + jr) * ROWA + (((wm * TM + tm) ^ rsw_a) * 64) + chb;
+  for (int t = 0; t < 2; ++t) {
+    const int rr16 = 8 * (g >> 1) + 4 * t + jr;
+    const int rsw_a = WA > 1 ? ((rr16 / RPBA) & (WA - 1)) : 0;
+    const int rsw_b = WB > 1 ? ((rr16 / RPBB) & (WB - 1)) : 0;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) boff[tn] = ABYTES + (8 * (g >> 1) + jr) * ROWB_ + (((wn * TN + tn) ^ rsw_b) * 64) + chb;
+    for (int tm = 0; tm < TM; ++tm) aoff[tm][t] = rr16 * ROWA + (((wm * TM + tm) ^ rsw_a) * 64) + chb;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) boff[tn][t] = ABYTES + rr16 * ROWB_ + (((wn * TN + tn) ^ rsw_b) * 64) + chb;
+  }
 
   constexpr int NMMA = NS * TM * TN;
   constexpr int PSTEP = NMMA / (2 * NI) >= 1 ? NMMA / (2 * NI) : 1;  // front-loaded: the chunk's tail covers the latency
@@ -266,10 +275,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_bf16(const Wgrad
       bf16x8 fa[TM], fb[TN];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
-        fa[tm] = wb_tr_read8(L + aoff[tm] + (16 * s) * ROWA, L + aoff[tm] + (16 * s + 4) * ROWA);
+        fa[tm] = wb_tr_read8(L + aoff[tm][0] + (16 * s) * ROWA, L + aoff[tm][1] + (16 * s) * ROWA);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        fb[tn] = wb_tr_read8(L + boff[tn] + (16 * s) * ROWB_, L + boff[tn] + (16 * s + 4) * ROWB_);
+        fb[tn] = wb_tr_read8(L + boff[tn][0] + (16 * s) * ROWB_, L + boff[tn][1] + (16 * s) * ROWB_);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -352,7 +361,7 @@ __global__ void combine_phase_wgrad_kernel(const float* __restrict__ g, float* _
   dw[i] = acc;
 }
 
-enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32 };
+enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32, V256x128 };
 
 bool valid(const rs_conv_desc* d) {
   if (!d) return false;
@@ -387,6 +396,16 @@ Plan plan(const rs_conv_desc* d) {
   pl.variant = pl.bmo == 128 ? (pl.bno == 128 ? V128x128 : V128x64)
                : pl.bmo == 64 ? (pl.bno == 128 ? V64x128 : V64x64)
                               : (pl.bno == 128 ? V32x128 : V32x32);
+  // 256 couts x 128 cins by 8 waves (round 2): three quarters of the 128x128 tile's LDS-DMA bytes per multiply-add, two waves
+  // per SIMD inside ONE block (the tap-per-block launches run one block per CU).  RS_WGRAD_256=0: measurement knob.
+  static const bool use256 = [] {
+    const char* e = getenv("RS_WGRAD_256");
+    return !e || atoi(e) != 0;
+  }();
+  if (use256 && !pl.phase && !pl.bno2 && pl.variant == V128x128 && d->Cout % 256 == 0) {
+    pl.bmo = 256;
+    pl.variant = V256x128;
+  }
   pl.taps = pl.phase ? 16 : d->kh * d->kw;
   pl.tiles_ci = (pl.bno2 ? d->C1 : d->C1 + d->C2) / pl.bno;
   pl.tiles_ci2 = pl.bno2 ? d->C2 / pl.bno2 : 0;
@@ -546,6 +565,7 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
         case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
         case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;
         case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, false><<<grid, 64, 0, s>>>(a); break;
+        case V256x128: conv_wgrad_bf16<256, 128, 4, 2, 64, false><<<grid, 512, 0, s>>>(a); break;
         default: return RS_EINVAL;
       }
     }

@@ -132,6 +132,8 @@ WGRAD = [
     ("1x1_s2", 2, 256, 16, 16, 512, 1, 2, 0),
     ("split_big", 2, 32, 128, 128, 32, 3, 1, 1),
     ("tail", 1, 64, 13, 11, 128, 3, 1, 1),  # M = 143: not a multiple of the 64-pixel chunk
+    ("256x128", 2, 128, 20, 20, 256, 3, 1, 1),
+    ("256x128_1x1_tail", 1, 256, 15, 23, 512, 1, 1, 0),  # two cout tiles x two cin tiles, M = 345
     # Cout = 32 3x3 layers with Ho, Wo multiples of 8 take the all-taps-per-block kernel (conv_wgrad_thin_bf16.hip):
     # "32x128", "32x32", "split_big" above; these keep the generic 32-wide tiles covered and add Cin = 64
     ("32x128_generic", 1, 128, 36, 36, 32, 3, 1, 1),
@@ -157,7 +159,8 @@ def test_wgrad_bf16(case):
     # the instantiation the case is named after is the one that ran (what bench.py reports per symbol)
     from robosat_amd import _lib
     expected = {"128x128": "conv_wgrad_bf16<128x128>", "128x64": "conv_wgrad_bf16<128x64>", "64x128": "conv_wgrad_bf16<64x128>",
-                "64x64_s2": "conv_wgrad_bf16<64x64>", "32x128_generic": "conv_wgrad_bf16<32x128>",
+                "64x64_s2": "conv_wgrad_bf16<64x64>", "256x128": "conv_wgrad_bf16<256x128>",
+                "256x128_1x1_tail": "conv_wgrad_bf16<256x128>", "1x1_s2": "conv_wgrad_bf16<256x128>", "32x128_generic": "conv_wgrad_bf16<32x128>",
                 "32x32_generic": "conv_wgrad_bf16<32x32>", "thin_c64": "conv_wgrad_thin_bf16", "32x32": "conv_wgrad_thin_bf16"}
     if case[0] in expected:
         d = _lib.ConvDesc(n, h, w, cin, 0, 0, k, k, stride, pad, y.shape[2], y.shape[3], cout, 0, 0)

@@ -39,7 +39,7 @@ COVERED |= {"conv_thin_bf16<3x3>", "conv_thin_bf16<phase>", "conv_thin_bf16<dgra
 COVERED |= {"conv_igemm_f32<128x64,stem>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_thin_bf16", "conv_wgrad_f32"}
 # bf16 weight-gradient tiles: tests/test_gpu_bf16.py::test_wgrad_bf16 / test_wgrad_bf16_upsample_concat assert, case by case,
 # that these are the instantiations they ran (the last one is dec3's per-source split)
-COVERED |= {"conv_wgrad_bf16<{}>".format(t) for t in ("128x128", "128x64", "64x128", "64x64", "32x128", "32x32")}
+COVERED |= {"conv_wgrad_bf16<{}>".format(t) for t in ("256x128", "128x128", "128x64", "64x128", "64x64", "32x128", "32x32")}
 COVERED |= {"conv_wgrad_bf16<phase,{}>".format(t) for t in ("128x128", "128x64", "64x128", "64x128+64x64", "128x128+128x64")}
 
 

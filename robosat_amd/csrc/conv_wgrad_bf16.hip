@@ -479,7 +479,7 @@ extern "C" long rs_conv2d_wgrad_bf16_workspace_bytes(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
   int tb = 0, tslices = 0;
   if (rs_wgrad_thin_plan(d, &tb, &tslices)) {
-    const long n = 32L * 9 * d->C1;
+    const long n = (long)d->Cout * 9 * d->C1;
     return (tslices * n + rs_reduce_scratch_floats(n, tslices)) * (long)sizeof(float);
   }
   const Plan pl = plan(d);
@@ -496,7 +496,7 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
     if (rs_wgrad_thin_plan(d, &tb, &tslices)) {  // Cout = 32 3x3 layers: all nine taps in one block
       const int rc = rs_wgrad_thin_launch(d, dy, src1, reinterpret_cast<float*>(workspace), stream);
       if (rc) return rc;
-      const long n = 32L * 9 * d->C1;
+      const long n = (long)d->Cout * 9 * d->C1;
       float* ws = reinterpret_cast<float*>(workspace);
       return rs_reduce_splits(ws, dw, n, tslices, ws + (long)tslices * n, stream);
     }

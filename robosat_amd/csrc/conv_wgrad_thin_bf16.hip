@@ -22,10 +22,11 @@
 namespace {
 
 struct ThinArgs {
-  const bf16_t* dy;   // [N][Ho][Wo][32]
+  const bf16_t* dy;   // [N][Ho][Wo][Cout]
   const bf16_t* src;  // [N][Hs][Ws][Cin]
-  float* out;         // [slices][32][9*Cin]
+  float* out;         // [slices][Cout][9*Cin]
   int N, Hs, Ws, Ho, Wo;
+  int Cout, Cin;      // the layer's widths: block (x, y, z) owns couts [32y, 32y+32) and cins [32*CT*z, 32*CT*(z+1))
   int ppr, ppi;       // patches per row / per image
   int total_patches, patches_per_block;
 };
@@ -84,8 +85,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_thin_bf16(const ThinArgs p)
   int pat1 = pat0 + p.patches_per_block;
   if (pat1 > p.total_patches) pat1 = p.total_patches;
 
-  const __amdgpu_buffer_rsrc_t rsrc_dy = tb_make_rsrc(p.dy, (long)p.N * p.Ho * p.Wo * 64);
-  const __amdgpu_buffer_rsrc_t rsrc_x = tb_make_rsrc(p.src, (long)p.N * p.Hs * p.Ws * ROWX);
+  const int co_base = blockIdx.y * 32, ci_base = blockIdx.z * CIN;
+  const int dyrow = p.Cout * 2, xrow = p.Cin * 2;  // bytes per pixel in HBM
+  const __amdgpu_buffer_rsrc_t rsrc_dy = tb_make_rsrc(p.dy, (long)p.N * p.Ho * p.Wo * dyrow);
+  const __amdgpu_buffer_rsrc_t rsrc_x = tb_make_rsrc(p.src, (long)p.N * p.Hs * p.Ws * xrow);
 
   // ---- staging roles (fixed per thread): NH halo pieces + one dy piece -----------------------------------------
   int h_hy[NH], h_hx[NH], h_pc[NH], h_lds[NH];
@@ -115,12 +118,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_thin_bf16(const ThinArgs p)
     for (int j = 0; j < NH; ++j) {
       const int sy = sy0 + h_hy[j], sx = sx0 + h_hx[j];
       const bool ok = live && h_lds[j] >= 0 && h_hx[j] < HWU && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      const long off = ((long)(n * p.Hs + sy) * p.Ws + sx) * ROWX + h_pc[j] * 16;
+      const long off = ((long)(n * p.Hs + sy) * p.Ws + sx) * xrow + ci_base * 2 + h_pc[j] * 16;
       rh[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (int)off : -1, 0, 0);
     }
     {
       const long m = (long)(n * p.Ho + oy0 + (d_k >> 3)) * p.Wo + ox0 + (d_k & 7);
-      rd = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, live ? (int)(m * 64 + d_c * 16) : -1, 0, 0);
+      rd = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, live ? (int)(m * dyrow + co_base * 2 + d_c * 16) : -1, 0, 0);
     }
   };
   auto store_patch = [&](int buf) __attribute__((always_inline)) {
@@ -198,14 +201,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_thin_bf16(const ThinArgs p)
   }
 
   // D[i][j]: i = cout = (r&3) + 8*(r>>2) + 4*(lane>>5), j = cin (within this wave's tile) = lane&31
-  constexpr int K = 9 * CIN;
-  float* out = p.out + ((long)blockIdx.x * KG + kg) * 32 * K;
+  const long K = 9L * p.Cin;
+  float* out = p.out + ((long)blockIdx.x * KG + kg) * p.Cout * K + (long)co_base * K + ci_base + ct * 32 + (lane & 31);
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      out[(long)co * K + tap * CIN + ct * 32 + (lane & 31)] = acc[tap][r];
+      out[(long)co * K + tap * p.Cin] = acc[tap][r];
     }
 }
 
@@ -213,20 +216,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_thin_bf16(const ThinArgs p)
 
 // Shared with conv_wgrad_bf16.hip (declared in common.h): is `d` one of the thin 3x3 layers, and how is it split?
 int rs_wgrad_thin_plan(const rs_conv_desc* d, int* blocks, int* slices) {
-  if (!d || d->stem || d->C2 != 0 || d->Cout != 32 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return 0;
-  if (d->C1 != 32 && d->C1 != 64 && d->C1 != 128) return 0;
+  if (!d || d->stem || d->C2 != 0 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return 0;
+  if (d->Cout <= 0 || (d->Cout % 32) != 0) return 0;
+  if (d->C1 != 32 && d->C1 != 64 && (d->C1 % 128) != 0) return 0;  // slabs of 32 / 64 / 128 input channels per block
   if (d->ups != 0 && d->ups != 1) return 0;
   if ((d->Ho % 8) || (d->Wo % 8)) return 0;
   if (d->ups == 1 && (d->Ho != 2 * d->Hs || d->Wo != 2 * d->Ws)) return 0;
   if (d->ups == 0 && (d->Ho != d->Hs || d->Wo != d->Ws)) return 0;
   // 32-bit byte offsets
-  if ((long)d->N * d->Ho * d->Wo * 64 >= (1L << 31) || (long)d->N * d->Hs * d->Ws * d->C1 * 2 >= (1L << 31)) return 0;
+  if ((long)d->N * d->Ho * d->Wo * d->Cout * 2 >= (1L << 31) || (long)d->N * d->Hs * d->Ws * d->C1 * 2 >= (1L << 31)) return 0;
   const long patches = (long)d->N * (d->Ho / 8) * (d->Wo / 8);
-  long nb = patches < 512 ? patches : 512;  // one full wave of blocks (2 per CU); fewer partial slices to reduce
+  const int slab = d->C1 < 128 ? d->C1 : 128;
+  const long groups = (long)(d->Cout / 32) * (d->C1 / slab);  // (cout tile, cin slab) pairs: grid y x z
+  long nb;
+  if (groups == 1) {
+    nb = patches < 512 ? patches : 512;  // the Cout = 32 decoder tail: one full wave of blocks (2 per CU)
+  } else {
+    // wider layers (round 2: the encoder's stride-1 3x3 convolutions): ~256 blocks over all groups, and enough patches per block
+    // for its [32][9 * slab] fp32 partial tile (up to 147 KB) to be a small part of what it moves; otherwise the generic kernel
+    static const bool wide = [] {
+      const char* e = getenv("RS_WGRAD_THIN_WIDE");  // measurement knob
+      return !e || atoi(e) != 0;
+    }();
+    if (!wide || d->ups != 0) return 0;
+    nb = 256 / groups;
+    if (nb < 1) nb = 1;
+    if (patches / nb < 8) return 0;
+  }
   const long ppb = (patches + nb - 1) / nb;
   nb = (patches + ppb - 1) / ppb;
   if (blocks) *blocks = (int)nb;
-  if (slices) *slices = (int)nb * (4 / (d->C1 / 32));
+  if (slices) *slices = (int)nb * (4 / (slab / 32));
   return 1;
 }
 
@@ -242,20 +262,24 @@ int rs_wgrad_thin_launch(const rs_conv_desc* d, const void* dy, const void* src,
   a.Ws = d->Ws;
   a.Ho = d->Ho;
   a.Wo = d->Wo;
+  a.Cout = d->Cout;
+  a.Cin = d->C1;
   a.ppr = d->Wo / 8;
   a.ppi = (d->Ho / 8) * (d->Wo / 8);
   a.total_patches = d->N * a.ppi;
   a.patches_per_block = (a.total_patches + blocks - 1) / blocks;
   hipStream_t s = (hipStream_t)stream;
-  const int ct = d->C1 / 32;
+  const int slab = d->C1 < 128 ? d->C1 : 128;
+  const int ct = slab / 32;
+  const dim3 grid(blocks, d->Cout / 32, d->C1 / slab);
   if (d->ups == 0) {
-    if (ct == 1) conv_wgrad_thin_bf16<1, 0><<<blocks, 256, 0, s>>>(a);
-    else if (ct == 2) conv_wgrad_thin_bf16<2, 0><<<blocks, 256, 0, s>>>(a);
-    else conv_wgrad_thin_bf16<4, 0><<<blocks, 256, 0, s>>>(a);
+    if (ct == 1) conv_wgrad_thin_bf16<1, 0><<<grid, 256, 0, s>>>(a);
+    else if (ct == 2) conv_wgrad_thin_bf16<2, 0><<<grid, 256, 0, s>>>(a);
+    else conv_wgrad_thin_bf16<4, 0><<<grid, 256, 0, s>>>(a);
   } else {
-    if (ct == 1) conv_wgrad_thin_bf16<1, 1><<<blocks, 256, 0, s>>>(a);
-    else if (ct == 2) conv_wgrad_thin_bf16<2, 1><<<blocks, 256, 0, s>>>(a);
-    else conv_wgrad_thin_bf16<4, 1><<<blocks, 256, 0, s>>>(a);
+    if (ct == 1) conv_wgrad_thin_bf16<1, 1><<<grid, 256, 0, s>>>(a);
+    else if (ct == 2) conv_wgrad_thin_bf16<2, 1><<<grid, 256, 0, s>>>(a);
+    else conv_wgrad_thin_bf16<4, 1><<<grid, 256, 0, s>>>(a);
   }
   return RS_LAUNCH_RESULT();
 }

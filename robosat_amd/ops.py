@@ -449,8 +449,8 @@ def wgrad_kernel_name(d, form=None):
     lib = _lib.lib()
     if form is None:
         form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d))
-    if form == 1:
-        return "conv_wgrad_thin_bf16"
+    if form == 1:  # all-taps kernel: instantiated per input-channel slab (32 / 64 / 128) and for the fused x2 upsample
+        return "conv_wgrad_thin_bf16<{}{}>".format(min(d.C1, 128), ",ups" if d.ups else "")
     t = lib.rs_conv2d_wgrad_bf16_tile(ctypes.byref(d))
     if t <= 0:
         raise ValueError("rs_conv2d_wgrad_bf16_tile: invalid arguments")

@@ -140,6 +140,10 @@ WGRAD = [
     ("32x32_generic", 2, 32, 36, 44, 32, 3, 1, 1),
     ("thin_c64", 3, 64, 24, 40, 32, 3, 1, 1),
     ("thin_c128_edge", 2, 128, 8, 8, 32, 3, 1, 1),  # one patch per image: every halo side is padding
+    # the all-taps kernel on wider layers (round 2): grid = patch runs x 32-cout tiles x 128-cin slabs
+    ("thin_wide_c64", 4, 64, 128, 128, 64, 3, 1, 1),
+    ("thin_wide_c128_co64", 4, 128, 128, 128, 64, 3, 1, 1),
+    ("thin_wide_c256", 2, 256, 64, 64, 256, 3, 1, 1),
 ]
 
 
@@ -161,7 +165,9 @@ def test_wgrad_bf16(case):
     expected = {"128x128": "conv_wgrad_bf16<128x128>", "128x64": "conv_wgrad_bf16<128x64>", "64x128": "conv_wgrad_bf16<64x128>",
                 "64x64_s2": "conv_wgrad_bf16<64x64>", "256x128": "conv_wgrad_bf16<256x128>",
                 "256x128_1x1_tail": "conv_wgrad_bf16<256x128>", "1x1_s2": "conv_wgrad_bf16<256x128>", "32x128_generic": "conv_wgrad_bf16<32x128>",
-                "32x32_generic": "conv_wgrad_bf16<32x32>", "thin_c64": "conv_wgrad_thin_bf16", "32x32": "conv_wgrad_thin_bf16"}
+                "32x32_generic": "conv_wgrad_bf16<32x32>", "thin_c64": "conv_wgrad_thin_bf16<64>", "32x32": "conv_wgrad_thin_bf16<32>",
+                "thin_c128_edge": "conv_wgrad_thin_bf16<128>", "thin_wide_c64": "conv_wgrad_thin_bf16<64>",
+                "thin_wide_c128_co64": "conv_wgrad_thin_bf16<128>", "thin_wide_c256": "conv_wgrad_thin_bf16<128>"}
     if case[0] in expected:
         d = _lib.ConvDesc(n, h, w, cin, 0, 0, k, k, stride, pad, y.shape[2], y.shape[3], cout, 0, 0)
         assert ops.wgrad_kernel_name(d) == expected[case[0]]

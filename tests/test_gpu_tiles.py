@@ -36,7 +36,10 @@ for _dt in ("f32", "bf16"):
                 COVERED.add("conv_igemm_{}<{}{},r{}>".format(_dt, _form, _t, _r))
 # non-implicit-GEMM symbols of the step have their own parity tests (test_gpu_ops / test_gpu_train_ops / test_gpu_bf16)
 COVERED |= {"conv_thin_bf16<3x3>", "conv_thin_bf16<phase>", "conv_thin_bf16<dgrad4x4>"}  # test_thin_* below
-COVERED |= {"conv_igemm_f32<128x64,stem>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_thin_bf16", "conv_wgrad_f32"}
+COVERED |= {"conv_igemm_f32<128x64,stem>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_f32"}
+# all-taps weight gradient: per input-channel slab, with / without the fused upsample (test_wgrad_bf16 "thin_*" cases assert the
+# names; test_wgrad_bf16_thin_upsample runs the ",ups" forms)
+COVERED |= {"conv_wgrad_thin_bf16<{}>".format(t) for t in ("32", "64", "128", "32,ups", "64,ups", "128,ups")}
 # bf16 weight-gradient tiles: tests/test_gpu_bf16.py::test_wgrad_bf16 / test_wgrad_bf16_upsample_concat assert, case by case,
 # that these are the instantiations they ran (the last one is dec3's per-source split)
 COVERED |= {"conv_wgrad_bf16<{}>".format(t) for t in ("256x128", "128x128", "128x64", "64x128", "64x64", "32x128", "32x32")}

@@ -234,11 +234,7 @@ int rs_wgrad_thin_plan(const rs_conv_desc* d, int* blocks, int* slices) {
   } else {
     // wider layers (round 2: the encoder's stride-1 3x3 convolutions): ~256 blocks over all groups, and enough patches per block
     // for its [32][9 * slab] fp32 partial tile (up to 147 KB) to be a small part of what it moves; otherwise the generic kernel
-    static const bool wide = [] {
-      const char* e = getenv("RS_WGRAD_THIN_WIDE");  // measurement knob
-      return !e || atoi(e) != 0;
-    }();
-    if (!wide || d->ups != 0) return 0;
+    if (d->ups != 0) return 0;
     nb = 256 / groups;
     if (nb < 1) nb = 1;
     if (patches / nb < 8) return 0;

@@ -148,10 +148,36 @@ def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
     return y, z, st, bits
 
 
+def _prefetch_decoder_weights(net, dt, device):
+    """The decoder's derived weights for this step -- the phase-form filters of center / dec0..dec4 and the weights of their
+    4x4 / stride-2 data gradients, 12 small packing launches -- issued on the side stream, where they run beside the stem
+    and the encoder instead of in front of each decoder layer (forward) and each data gradient (backward).  Returns the
+    event the main stream waits for before the first decoder layer (None when the side stream is switched off)."""
+
+    main = torch.cuda.current_stream(device)
+    side = _side_stream(device)
+    if side == main:
+        return None
+    ready = torch.cuda.Event()
+    ready.record(main)  # (the optimizer step that wrote the master weights is on the main stream)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        packed = []
+        for blk in (net.center, net.dec0, net.dec1, net.dec2, net.dec3, net.dec4):
+            conv = blk.block.block
+            packed += [conv.phase(dt), conv.dgrad_phase(dt)]
+    done = torch.cuda.Event()
+    done.record(side)
+    for w in packed:
+        w.record_stream(main)  # allocated under the side stream, read by the main stream's kernels
+    return done
+
+
 def _forward(net, x, tape):
     from .unet import _bump_generation
 
     _bump_generation()  # a training forward re-derives every compute copy of the weights (see unet._GENERATION)
+    decoder_weights_ready = _prefetch_decoder_weights(net, net.compute_dtype, x.device)
     r = net.resnet
     t = tape.t
     dt = net.compute_dtype  # fp32 or bf16 activations (the image is cast on upload)
@@ -190,6 +216,8 @@ def _forward(net, x, tape):
         return ops.conv2d_phase(skip, block.block.block.phase(dt), src2=prev, relu=True)
 
     pooled, amc = ops.maxpool2d(enc4, 2, 2, 0, want_argmax=True)
+    if decoder_weights_ready is not None:
+        torch.cuda.current_stream(x.device).wait_event(decoder_weights_ready)
     center = up(net.center, pooled)
     dec0 = up(net.dec0, enc4, center)
     dec1 = up(net.dec1, enc3, dec0)
@@ -237,7 +265,7 @@ def _backward(net, tape, dlogits, arena):
         arena.wgrad(lambda: ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=wo), dz, skip, prev)
         # phase form: the gradient wrt the pre-upsample tensors is ONE 4x4 / stride-2 convolution over dz (the 2x2 sum of
         # interpolate's backward is folded into pre-summed taps): 4/9 of the MACs, output already at source resolution
-        wd = ops.pack_dgrad_phase_weight(conv.krsc(), dz.dtype)
+        wd = conv.dgrad_phase(dz.dtype)  # (packed beside the forward: _prefetch_decoder_weights)
         hw = (skip.shape[1], skip.shape[2])
         c1 = skip.shape[3]
         if prev is None and skip_grad_out is None:  # single source: the ReLU mask rides in the epilogue, nothing to split

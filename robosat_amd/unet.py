@@ -81,6 +81,17 @@ class _Conv(nn.Module):
             self._phase = c
         return c[1]
 
+    def dgrad_phase(self, dtype=torch.float32):
+        """Weights of the phase form's data gradient (one 4x4 / stride-2 convolution over dz, ``rs_pack_dgrad_phase_weight_dt``),
+        cached like ``phase``."""
+
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0], dtype)
+        c = getattr(self, "_dgrad_phase", None)
+        if c is None or c[0] != key:
+            c = (key, ops.pack_dgrad_phase_weight(self.krsc(), dtype))
+            self._dgrad_phase = c
+        return c[1]
+
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(self.cin, self.cout, self.k, self.stride, self.padding)
 

@@ -214,7 +214,7 @@ def _portable_optimizer_state(optimizer):
     state["state"] = {k: dict(st) for k, st in state["state"].items()}
     for st in state["state"].values():
         if torch.is_tensor(st.get("step")):
-            st["step"] = st["step"].detach().cpu()
+            st["step"] = st["step"].detach().to("cpu", copy=True)
     return state
 
 

@@ -180,3 +180,75 @@ def test_pretrained_encoder_loads_a_legacy_torchvision_state_dict(tmp_path, monk
         UNet(2, pretrained="require")
     with pytest.warns(UserWarning):
         UNet(2, pretrained=True)
+
+
+def test_checkpointed_optimizer_state_is_a_copy():
+    """`rs train` saves the optimizer every epoch and keeps training: the saved state must not alias the live one (the fused
+    Adam keeps its step counters where the parameters are; the checkpoint carries them as host tensors, as a stock Adam does)."""
+    from robosat_amd.tools.train import _portable_optimizer_state
+
+    p = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    opt = torch.optim.Adam(p, lr=1e-3, fused=True)
+    for q in p:
+        q.grad = torch.randn_like(q)
+    opt.step()
+    live = {id(st): st["step"] for st in opt.state.values()}
+    saved = _portable_optimizer_state(opt)
+    assert set(saved) == {"state", "param_groups"} and len(saved["state"]) == 2
+    for st in saved["state"].values():
+        assert st["step"].device.type == "cpu" and float(st["step"]) == 1.0
+        assert set(st) == {"step", "exp_avg", "exp_avg_sq"}
+    for st in opt.state.values():  # the live per-parameter dicts still hold the very same tensors
+        assert st["step"] is live[id(st)]
+    opt.step()  # and training goes on
+    assert all(float(st["step"]) == 2.0 for st in opt.state.values())
+    assert all(float(st["step"]) == 1.0 for st in saved["state"].values())
+    fresh = torch.optim.Adam(p, lr=1e-3)  # a stock Adam resumes from it
+    fresh.load_state_dict(saved)
+    assert all(float(st["step"]) == 1.0 for st in fresh.state.values())
+
+
+def test_mode_switches_and_invalidate_move_the_cache_generation():
+    """Derived weight copies are keyed on (data_ptr, _version, generation): `train()` / `eval()` / `invalidate_caches()`
+    move the generation, which is what catches optimizers that write parameters without bumping `_version` (fused Adam)."""
+    from robosat_amd import unet
+
+    net = unet.UNet(2, pretrained=False)
+    g0 = unet._GENERATION[0]
+    net.eval()
+    g1 = unet._GENERATION[0]
+    net.train()
+    g2 = unet._GENERATION[0]
+    net.invalidate_caches()
+    g3 = unet._GENERATION[0]
+    assert g0 < g1 < g2 < g3
+    w = net.dec5.block.weight
+    v = w._version
+    opt = torch.optim.Adam([w], lr=1e-3, fused=True)
+    w.grad = torch.randn_like(w)
+    before = w.detach().clone()
+    opt.step()
+    assert not torch.equal(before, w.detach())
+    if w._version == v:  # (the behaviour this guards against; a torch that bumps the counter makes the generation redundant, not wrong)
+        assert unet._GENERATION[0] == g3  # nothing moved by itself: the next training forward / mode switch must
+
+
+def test_decoded_tile_cache_holds_the_unaugmented_items(tmp_path):
+    """The tile cache (filled through a DataLoader, with workers too) holds exactly the items of UnaugmentedTiles, in tile order."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    from robosat_amd.datasets import DecodedTileCache, UnaugmentedTiles
+
+    root = synth.make_dataset(str(tmp_path / "ds"), n_train=9, n_val=2, size=96, seed=3)
+    img, lab = os.path.join(root, "training", "images"), os.path.join(root, "training", "labels")
+    items = UnaugmentedTiles([img], lab, 64, draw=False)
+    for workers in (0, 2):
+        cache = DecodedTileCache([img], lab, 64, torch.device("cpu"), workers=workers)
+        assert len(cache) == len(items) == 9 and tuple(cache.images.shape) == (9, 64, 64, 3) and cache.images.dtype == torch.uint8
+        assert tuple(cache.masks.shape) == (9, 64, 64) and cache.masks.dtype == torch.uint8
+        for i in range(len(items)):
+            image, mask, code, tiles = items[i]
+            assert code == 0 and torch.equal(cache.images[i], image) and torch.equal(cache.masks[i], mask)
+            assert tuple(cache.tiles[i]) == tuple(tiles[0])

@@ -16,7 +16,10 @@
 //            are all just per-lane address arithmetic: nothing is ever re-gathered from HBM per tap.
 //   waves  = Cin/32 cin tiles x (4 / (Cin/32)) k-step groups: 128 channels -> each wave owns one 32-channel tile and all
 //            4 k-steps; 32 channels -> each wave owns one k-step (its own partial slice, summed by the reduce kernel).
-//   output = partial slices [splits * KG][32][9 * Cin] fp32, reduced deterministically (no atomics) into KRSC dW.
+//   output = partial slices [splits * KG][Cout][9 * Cin] fp32, reduced deterministically (no atomics) into KRSC dW.
+//   wider layers (round 2): the grid's y / z dimensions walk 32-cout tiles and 128-cin slabs of a wider stride-1 3x3 layer
+//            (the encoder's conv2's: 64 -> 64 ... 512 -> 512), every block re-reading the patch's dy slice and halo slab; on
+//            layer1 (two cout tiles) that is 2.5x faster than nine tap-per-block passes, on the 128+ wide layers a wash.
 #include "common.h"
 
 namespace {

@@ -10,6 +10,10 @@ region starts.  Tiles shard across ranks with no data-path collective ("weak" sc
 One JSON line on stdout (rank 0): metric/value/unit... (the predict leg), plus
   "train"        -- the train leg of the metric (configs[2]: bf16, bs 32 per GPU, fwd + Lovasz + bwd + gradient
                     all-reduce + Adam): value (tiles/s over all ranks), ms_per_step, its own roofline object;
+  "legs"         -- the remaining BASELINE configurations, same timing discipline, short loops: configs[4] (4-band RGB+IR,
+                    4 classes, Lovasz, bf16 bs 32), fp32 training (the reference's arithmetic, bs 8), configs[3] (1024^2);
+  "step_ms"      -- min / median / max of the per-step device times (in every leg), next to the mean `ms_per_step`;
+  "miou"         -- "mIoU vs CPU ref": bf16 MI355X vs fp32 CPU oracle after the same short training run (N=1 only);
   "roofline"     -- dominant kernel, algorithmic FLOPs / HIP-event time over the launches of one pass, vs the fp32
                     MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
   "cpu_baseline" -- the CPU oracle (oracle/robosat_ref.py, kind "port") timed on this box's host cores on a bounded
@@ -45,6 +49,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--channels", type=int, default=3, help="input bands (4 = RGB + IR, BASELINE configs[4])")
     ap.add_argument("--phase", choices=["predict", "train"], default="predict",
                     help="predict = BASELINE configs[1] (default); train = fwd + loss + bwd + grad all-reduce + Adam")
     ap.add_argument("--loss", choices=["CrossEntropy", "Lovasz", "Focal"], default="Lovasz", help="train phase criterion")
@@ -54,16 +59,23 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-line comparison of one output tile with the CPU oracle")
     ap.add_argument("--no-train-leg", action="store_true", help="predict phase only: skip the bf16 train leg reported under \"train\"")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU per step of the train leg (configs[2]: 32)")
+    ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the train leg (>= 30: one stall must not move the mean)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="predict phase only: skip the legs reported under \"legs\" (configs[4] 4-band 4-class bf16 train, fp32 "
+                         "train bs 8, configs[3] 1024^2 predict)")
+    ap.add_argument("--no-miou", action="store_true", help="skip the bf16-vs-fp32-oracle convergence check reported under \"miou\"")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch / --train-batch tiles PER GPU (default); strong: they are the GLOBAL batch, split over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
     ap.add_argument("--layers-json", type=str, default="", help="also dump the per-layer roofline table here")
     return ap.parse_args()
 
 
-def build_model(classes, device, train=False, dtype="fp32"):
+def build_model(classes, device, train=False, dtype="fp32", channels=3):
     from robosat_amd.unet import UNet
 
     torch.manual_seed(0)
-    net = UNet(classes, pretrained=False, compute_dtype=dtype)  # random init of the reference architecture
+    net = UNet(classes, pretrained=False, compute_dtype=dtype, in_channels=channels)  # random init of the reference architecture
     g = torch.Generator().manual_seed(1)
     for name, buf in net.named_buffers():  # non-trivial BatchNorm statistics (fresh init would make BN an identity)
         if name.endswith("running_mean"):
@@ -175,7 +187,7 @@ def traffic_source():
     return {"file": "profiles/pmc_traffic.json", "measured": meta} if meta else {"file": "profiles/pmc_traffic.json", "measured": None}
 
 
-def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
+def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz", channels=3):
     """The CPU oracle on this box's host cores: bounded sample of the same workload (tiles of the same size).
 
     torch's intra-op pool does not scale to every core of a 2-socket host for these convolutions, so the thread count
@@ -184,7 +196,7 @@ def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
     from oracle import robosat_ref as R
 
     torch.manual_seed(0)
-    net = R.UNetRef(classes)
+    net = R.UNetRef(classes, in_channels=channels)
     net = net.train() if phase == "train" else net.eval()
     crit = R.LOSSES[loss_name]
     opt = torch.optim.Adam(net.parameters(), lr=1e-4) if phase == "train" else None
@@ -202,7 +214,7 @@ def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cands = sorted({c for c in (8, 16, 32, 64, 128) if c <= avail} | {min(avail, 8)})
     bs = 2 if phase == "train" else 1  # BatchNorm needs > 1 sample per channel at the 16x16 bottleneck
-    xs, ts = torch.randn(bs, 3, size // 2, size // 2), torch.randint(0, classes, (bs, size // 2, size // 2))
+    xs, ts = torch.randn(bs, channels, size // 2, size // 2), torch.randint(0, classes, (bs, size // 2, size // 2))
     best, best_t = cands[0], float("inf")
     for c in cands:
         torch.set_num_threads(c)
@@ -213,7 +225,7 @@ def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
         if dt < best_t:
             best, best_t = c, dt
     torch.set_num_threads(best)
-    x, t = torch.randn(bs, 3, size, size), torch.randint(0, classes, (bs, size, size))
+    x, t = torch.randn(bs, channels, size, size), torch.randint(0, classes, (bs, size, size))
     run(x, t)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -224,11 +236,11 @@ def cpu_baseline(classes, size, budget_s, phase="predict", loss_name="Lovasz"):
             break
     what = "UNetRef+softmax" if phase == "predict" else "UNetRef train step (fwd+{}+bwd+Adam)".format(loss_name)
     return {"value": round(n / el, 3), "unit": "tiles/s", "cores": best, "kind": "port",
-            "sample": "{} tiles of 3x{}x{} (batch {}), fp32, oracle/robosat_ref.py {} with {} of {} host cores (best of {})".format(
-                n, size, size, bs, what, best, avail, cands)}
+            "sample": "{} tiles of {}x{}x{} (batch {}), fp32, oracle/robosat_ref.py {} with {} of {} host cores (best of {})".format(
+                n, channels, size, size, bs, what, best, avail, cands)}
 
 
-def parity_vs_oracle(net, x, classes, got=None):
+def parity_vs_oracle(net, x, classes, got=None, channels=3):
     """The in-line output check: probabilities of ONE tile of the benchmark batch from the model the timed loop just ran
     (``got``: that loop's own last output row when given) against the CPU oracle (oracle/robosat_ref.py) holding the same
     state dict.  A kernel that wrote zeros -- or anything else -- at the benchmarked shapes shows up here, in the same JSON
@@ -236,7 +248,7 @@ def parity_vs_oracle(net, x, classes, got=None):
 
     from oracle import robosat_ref as R
 
-    ref = R.UNetRef(classes)
+    ref = R.UNetRef(classes, in_channels=channels)
     ref.load_state_dict({k: v.detach().float().cpu() for k, v in net.state_dict().items()})
     ref.eval()
     was_training = net.training
@@ -252,25 +264,34 @@ def parity_vs_oracle(net, x, classes, got=None):
             "what": "softmax probabilities of tile 0 of the benchmark batch vs oracle/robosat_ref.py (fp32, CPU) on the same weights"}
 
 
-def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
-    """Builds the model for `phase`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
-    returns (max-over-ranks seconds, step function, a callable producing rank 0's parity record)."""
+class Leg:
+    """One workload of the line: phase, dtype, tiles per GPU per step, tile size, classes, bands, loss."""
+
+    def __init__(self, phase, dtype, batch, size, classes, channels, loss, tag=""):
+        self.phase, self.dtype, self.batch, self.size, self.classes, self.channels, self.loss, self.tag = (
+            phase, dtype, batch, size, classes, channels, loss, tag)
+
+
+def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False):
+    """Builds the model for `leg`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
+    returns (max-over-ranks seconds, per-step milliseconds of this rank from HIP events between the steps, step function,
+    a callable producing rank 0's parity record)."""
 
     import torch.distributed as td
 
-    train = phase == "train"
-    net = build_model(args.classes, device, train, dtype)
+    train = leg.phase == "train"
+    net = build_model(leg.classes, device, train, leg.dtype, leg.channels)
     g = torch.Generator().manual_seed(100 + rank)
-    x = torch.randn(batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM
+    x = torch.randn(leg.batch, leg.channels, leg.size, leg.size, generator=g).to(device)  # resident in HBM
 
     if train:
         from robosat_amd import losses
         from robosat_amd.parallel import GradReducer
 
-        tgt = torch.randint(0, args.classes, (batch, args.size, args.size), generator=g).to(device)
-        crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=torch.ones(args.classes)),
-                "Focal": lambda: losses.FocalLoss2d(weight=torch.ones(args.classes)),
-                "Lovasz": lambda: losses.LovaszLoss2d()}[args.loss]().to(device)
+        tgt = torch.randint(0, leg.classes, (leg.batch, leg.size, leg.size), generator=g).to(device)
+        crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=torch.ones(leg.classes)),
+                "Focal": lambda: losses.FocalLoss2d(weight=torch.ones(leg.classes)),
+                "Lovasz": lambda: losses.LovaszLoss2d()}[leg.loss]().to(device)
         opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)  # (as `rs train` builds it on a GPU)
         if dist:
             from robosat_amd import parallel
@@ -296,35 +317,130 @@ def run_phase(args, phase, dtype, batch, steps, warmup, device, dist, rank):
 
     for _ in range(warmup):
         step()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # (recorded on the stream; no host sync)
     barrier()
     t0 = time.perf_counter()
     last = None
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         last = step()
+        marks[i + 1].record()
     barrier()
     el = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if dist:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         el = float(t.item())
+
     def parity():  # (outside the timed region, and after the roofline passes: the CPU oracle lets the GPU go idle)
-        if rank != 0 or args.no_parity:
+        if rank != 0 or no_parity:
             return None
-        rec = parity_vs_oracle(net, x, args.classes, got=None if train else last[0])
+        rec = parity_vs_oracle(net, x, leg.classes, got=None if train else last[0], channels=leg.channels)
         if train:
             rec["train_loss_last_step"] = float(last)
         return rec
 
-    return el, step, parity
+    return el, step_ms, step, parity
 
 
-def workload(args, phase, dtype, batch, world):
-    train = phase == "train"
-    return {"workload": ("rs predict ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes (BASELINE configs[1])" if not train else
-                         "rs train ResNet50-UNet, bs={} 3x{}x{} {} per GPU, {} classes, " + args.loss + " loss + Adam (BASELINE configs[2])").format(
-        batch, args.size, args.size, dtype, args.classes), "phase": phase, "tiles_per_gpu_per_step": batch,
-        "tile": args.size, "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
-                                           "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)}
+def step_stats(step_ms):
+    """min / median / max of the per-step device times (HIP events recorded between the steps of the timed loop): a stall
+    that hits one step -- another process polling the SMU, a host hiccup -- shows here instead of hiding in the mean."""
+
+    v = sorted(step_ms)
+    n = len(v)
+    return {"min": round(v[0], 3), "median": round((v[n // 2] + v[(n - 1) // 2]) / 2, 3), "max": round(v[-1], 3), "n": n}
+
+
+def workload(leg, world, cfg=""):
+    train = leg.phase == "train"
+    bands = "{}x{}x{}".format(leg.channels, leg.size, leg.size)
+    what = ("rs predict ResNet50-UNet, bs={} {} {} per GPU, {} classes" if not train else
+            "rs train ResNet50-UNet, bs={} {} {} per GPU, {} classes, " + leg.loss + " loss + Adam").format(
+        leg.batch, bands, leg.dtype, leg.classes) + (" (BASELINE {})".format(cfg) if cfg else "")
+    return {"workload": what, "phase": leg.phase, "tiles_per_gpu_per_step": leg.batch, "tile": leg.size, "bands": leg.channels,
+            "classes": leg.classes,
+            "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
+                            "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)}
+
+
+def baseline_config(leg):
+    """Which BASELINE.json configuration a leg is, if any."""
+
+    key = (leg.phase, leg.dtype, leg.batch, leg.size, leg.classes, leg.channels)
+    return {("predict", "fp32", 16, 512, 2, 3): "configs[1]", ("train", "bf16", 32, 512, 2, 3): "configs[2]",
+            ("predict", "fp32", 8, 1024, 2, 3): "configs[3]"}.get(key, "configs[4]" if key == ("train", "bf16", 32, 512, 4, 4) and
+                                                                  leg.loss == "Lovasz" else "")
+
+
+def miou_vs_cpu_ref(device, seed=31, n_train=24, n_val=8, size=128, batch=4, epochs=2, lr=3e-4):
+    """The metric's "mIoU vs CPU ref": the bf16 MI355X path and the fp32 CPU oracle train on the SAME learnable synthetic
+    tiles (rectangles brighter than their background, as tests/synth.py draws them) from the same initial weights, same
+    batches, same Adam, for `epochs` epochs, and are validated on the same held-out tiles with the reference's confusion
+    counts (metrics.py:27-84).  Small tiles, outside every timed region (~10 s, most of it the CPU side)."""
+
+    import numpy as np
+
+    from oracle import robosat_ref as R, seeded
+    from robosat_amd import losses
+    from robosat_amd.metrics import Metrics
+    from robosat_amd.unet import UNet
+
+    rng = np.random.default_rng(seed)
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+
+    def tiles(count):
+        xs, ts = [], []
+        for _ in range(count):
+            img = rng.integers(0, 120, size=(size, size, 3), dtype=np.uint8)
+            mask = np.zeros((size, size), dtype=np.int64)
+            for _ in range(int(rng.integers(1, 4))):
+                w, h = rng.integers(size // 8, size // 2, size=2)
+                x0, y0 = rng.integers(0, size - w), rng.integers(0, size - h)
+                mask[y0:y0 + h, x0:x0 + w] = 1
+                img[y0:y0 + h, x0:x0 + w] = rng.integers(130, 256, size=(h, w, 3), dtype=np.uint8)
+            xs.append(((img.astype(np.float32) / 255 - mean) / std).transpose(2, 0, 1))
+            ts.append(mask)
+        return torch.from_numpy(np.stack(xs)), torch.from_numpy(np.stack(ts))
+
+    xtr, ttr = tiles(n_train)
+    xva, tva = tiles(n_val)
+    sd = seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 8)
+    ref = R.UNetRef(2)
+    ref.load_state_dict(sd)
+    net = UNet(2, pretrained=False, compute_dtype="bf16")
+    net.load_state_dict(sd)
+    net = net.to(device)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=lr)
+    opt = torch.optim.Adam(net.parameters(), lr=lr, fused=True)
+    crit = losses.LovaszLoss2d().to(device)
+    torch.set_num_threads(min(32, max(1, len(os.sched_getaffinity(0)))))
+    ref.train()
+    net.train()
+    order = torch.Generator().manual_seed(seed)
+    for _ in range(epochs):
+        perm = torch.randperm(n_train, generator=order)
+        for i in range(0, n_train - batch + 1, batch):
+            idx = perm[i:i + batch]
+            opt_ref.zero_grad()
+            R.lovasz2d(ref(xtr[idx]), ttr[idx]).backward()
+            opt_ref.step()
+            opt.zero_grad()
+            crit(net(xtr[idx].to(device)), ttr[idx].to(device)).backward()
+            opt.step()
+    ref.eval()
+    net.eval()
+    counts = np.zeros(4, dtype=np.int64)
+    m = Metrics(range(2))
+    with torch.no_grad():
+        for a, s in zip(tva, ref(xva)):
+            counts += np.array(R.confusion_counts(a, s))
+        m.add_batch(tva.to(device), net(xva.to(device)))
+    cpu, gpu = float(R.metric_scores(*counts)[0]), float(m.get_miou())
+    return {"gpu": round(gpu, 4), "cpu_ref": round(cpu, 4), "abs_diff": round(abs(gpu - cpu), 4),
+            "what": "validation mIoU (metrics.py:43-84) after {} epochs of Lovasz/Adam(lr {}) on {} synthetic {}x{} tiles, {} held out: "
+                    "bf16 MI355X path vs fp32 CPU oracle, same initial weights and batches".format(epochs, lr, n_train, size, size, n_val)}
 
 
 def main():
@@ -358,7 +474,17 @@ def main():
             td.barrier()
         ctypes.CDLL(None).fflush(None)
 
-    el, step, parity = run_phase(args, args.phase, args.dtype, args.batch, args.steps, args.warmup, device, dist, rank)
+    strong = args.scaling == "strong"
+
+    def per_rank(batch):  # --scaling strong: the flag is the GLOBAL batch (rs train's `[common] batch_size`), split like DataParallel
+        if not strong:
+            return batch
+        if batch % world:
+            sys.exit("bench.py: --scaling strong needs a batch divisible by the {} ranks (got {})".format(world, batch))
+        return batch // world
+
+    main_leg = Leg(args.phase, args.dtype, per_rank(args.batch), args.size, args.classes, args.channels, args.loss)
+    el, step_ms, step, parity = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity)
     line = None
     # every rank runs the two untimed roofline passes: a train step contains the gradient all-reduce, so rank 0 alone
     # would wait for its peers forever
@@ -369,10 +495,15 @@ def main():
                 json.dump(layers, fp, indent=1)
         line = {
             "metric": "512x512 tiles/sec train+predict, 1/2/4/8 MI355X; mIoU vs CPU ref",
-            "value": round(world * args.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-            "config": workload(args, args.phase, args.dtype, args.batch, world),
+            "value": round(world * main_leg.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(step_ms),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "config": workload(main_leg, world, baseline_config(main_leg)),
+            # `roofline.frac` is on the FLOPs the kernels EXECUTE; SURVEY.md section 8d's algorithmic count rides along as
+            # `roofline.algorithmic` (its 100 %-of-peak ceiling of 941 tiles/s can be exceeded: see `flops_basis`)
+            "flops_basis": "executed (the DecoderBlock phase form runs 4/9 of the section-8d algorithmic multiply-adds: conv3x3 over a "
+                           "nearest-x2 upsample == four 2x2 convolutions on the source grid with pre-summed taps)",
             "roofline": roof, "parity": parity(),
         }
     del step
@@ -381,21 +512,43 @@ def main():
     # The metric is "train+predict": the headline `value` above is the predict leg (BASELINE configs[1]); the train leg
     # (configs[2]: bf16, bs 32 per GPU, fwd + Lovasz + bwd + RCCL gradient all-reduce + Adam) rides in the same line.
     if args.phase == "predict" and not args.no_train_leg:
-        tb, ts, tw = args.train_batch, max(1, min(args.steps, 10)), max(3, min(args.warmup, 5))
-        tel, tstep, tparity = run_phase(args, "train", "bf16", tb, ts, tw, device, dist, rank)
+        tleg = Leg("train", "bf16", per_rank(args.train_batch), args.size, args.classes, args.channels, args.loss)
+        ts, tw = max(1, args.train_steps), max(3, min(args.warmup, 5))
+        tel, tstep_ms, tstep, tparity = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity)
         troof, _ = roofline(tstep)
         if rank == 0:
-            line["train"] = {"value": round(world * tb * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
-                             "ms_per_step": round(tel / ts * 1e3, 3), "dtype": "bf16", "scaling": "weak",
-                             "config": workload(args, "train", "bf16", tb, world), "roofline": troof, "parity": tparity()}
+            line["train"] = {"value": round(world * tleg.batch * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
+                             "ms_per_step": round(tel / ts * 1e3, 3), "step_ms": step_stats(tstep_ms), "dtype": "bf16",
+                             "scaling": args.scaling, "config": workload(tleg, world, baseline_config(tleg)),
+                             "roofline": troof, "parity": tparity()}
         del tstep
         torch.cuda.empty_cache()
 
+    # The other BASELINE configurations, timed the same way (barrier + synchronize, max over ranks) with short loops and no
+    # roofline pass: configs[4] (4-band RGB+IR, 4 classes, Lovasz, bf16 bs 32), the reference's own arithmetic for training
+    # (fp32, bs 8) and configs[3] (1024^2 tiles, bs 8, fp32 predict).
+    if args.phase == "predict" and not args.no_extra_legs and args.size == 512:
+        extra = [("cfg5_train_bf16_4band_4class", Leg("train", "bf16", per_rank(32), 512, 4, 4, "Lovasz"), 10, 3),
+                 ("train_fp32_bs8", Leg("train", "fp32", per_rank(8), 512, 2, 3, "Lovasz"), 5, 2),
+                 ("cfg4_predict_fp32_1024_bs8", Leg("predict", "fp32", per_rank(8), 1024, 2, 3, "Lovasz"), 10, 2)]
+        for name, leg, ls, lw in extra:
+            lel, lstep_ms, lstep, lparity = run_phase(leg, ls, lw, device, dist, rank, no_parity=True)
+            if rank == 0:
+                line.setdefault("legs", {})[name] = {
+                    "value": round(world * leg.batch * ls / lel, 2), "unit": "tiles/s", "steps": ls, "warmup": lw,
+                    "ms_per_step": round(lel / ls * 1e3, 3), "step_ms": step_stats(lstep_ms), "dtype": leg.dtype,
+                    "config": workload(leg, world, baseline_config(leg))}
+            del lstep
+            torch.cuda.empty_cache()
+
     if rank == 0:
+        if world == 1 and not args.no_miou:
+            line["miou"] = miou_vs_cpu_ref(device)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds, args.phase, args.loss)
+            line["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds, args.phase, args.loss, args.channels)
             if "train" in line:  # the train leg's own CPU number (the oracle's fwd + Lovasz + bwd + Adam), shorter sample
-                line["train"]["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds * 0.7, "train", args.loss)
+                line["train"]["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds * 0.7, "train", args.loss,
+                                                             args.channels)
     if dist:
         import ctypes
 

@@ -8,6 +8,20 @@ the tools because this implementation has no CPU compute path.
 
 import tomli
 
+# Class counts the tools accept, stated once.  The reference's model takes any count but its tools are binary
+# (predict.py:98 asserts two classes; metrics.py:27-41 counts a 2x2 table): here the kernels behind the losses, the C x C
+# confusion matrix and the head take 2..8 classes, and a probability PNG holds one byte per non-background class in at most
+# 4 channels (mode P / LA / RGB / RGBA), i.e. up to 5 classes for `rs predict` -> `rs masks`.
+MIN_CLASSES, MAX_CLASSES_TRAIN, MAX_CLASSES_PREDICT = 2, 8, 5
+
+
+def check_num_classes(num_classes, tool):
+    """Raises ``ValueError`` when ``tool`` ("train" | "predict" | "serve") cannot handle ``num_classes`` classes."""
+
+    hi = MAX_CLASSES_PREDICT if tool == "predict" else MAX_CLASSES_TRAIN
+    if not MIN_CLASSES <= num_classes <= hi:
+        raise ValueError("rs {} handles {}..{} classes; the dataset config lists {}".format(tool, MIN_CLASSES, hi, num_classes))
+
 
 def load_config(path):
     """Parses the TOML file at ``path`` into a dictionary."""

@@ -98,7 +98,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 template <int C>
 __device__ __forceinline__ void final_epilogue(float (&acc)[C], long pix, long HW, int softmax, const double* __restrict__ anchors,
                                                uint8_t* __restrict__ qout, float* __restrict__ out, int Wimg, int ov) {
-  if (softmax) {
+  if (softmax == 1 || softmax == 2) {  // (mode 3 takes the argmax of the LOGITS: serve.py:160-164 -- no exp/div, exact ties)
     float mx = acc[0];
 #pragma unroll
     for (int c = 1; c < C; ++c) mx = fmaxf(mx, acc[c]);

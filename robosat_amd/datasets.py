@@ -71,18 +71,18 @@ class BufferedSlippyMapDirectory(_TileDirectory):
     sorted (x, y) order -- the reference walks ``os.listdir`` order; each tile's output is independent of the order -- and
     the last ``cache_tiles`` decoded neighbours are kept (per DataLoader worker), which turns ~9 decodes per tile into ~1-3."""
 
-    def __init__(self, root, transform=None, size=512, overlap=32, cache_tiles=192):
+    def __init__(self, root, transform=None, size=512, overlap=32, cache_tiles=192, mode="RGB"):
         assert overlap >= 0
         assert size >= 256
         super().__init__(root, ordered=True)
-        self.transform, self.size, self.overlap = transform, size, overlap
+        self.transform, self.size, self.overlap, self.mode = transform, size, overlap, mode
         self._store = dict(self.tiles)
         self._cache, self._cache_tiles = collections.OrderedDict(), cache_tiles
 
     def _open(self, path):
         image = self._cache.get(path)
         if image is None:
-            image = Image.open(path).convert("RGB")
+            image = Image.open(path).convert(self.mode)
             image.load()
             self._cache[path] = image
             if len(self._cache) > self._cache_tiles:
@@ -93,7 +93,7 @@ class BufferedSlippyMapDirectory(_TileDirectory):
 
     def __getitem__(self, i):
         tile = self.tiles[i][0]
-        image = buffer_tile_image(tile, self._store, overlap=self.overlap, tile_size=self.size, opener=self._open)
+        image = buffer_tile_image(tile, self._store, overlap=self.overlap, tile_size=self.size, opener=self._open, mode=self.mode)
         if self.transform is not None:
             image = self.transform(image)
         return image, torch.IntTensor([tile.x, tile.y, tile.z])
@@ -101,6 +101,34 @@ class BufferedSlippyMapDirectory(_TileDirectory):
     def unbuffer(self, probs):
         o = self.overlap
         return probs[:, o:probs.shape[1] - o, o:probs.shape[2] - o]
+
+
+class BufferedSlippyMapConcatenation(torch.utils.data.Dataset):
+    """Several ``BufferedSlippyMapDirectory`` sources over the same tiles, concatenated on the channel axis: what
+    ``SlippyMapTilesConcatenation`` (``datasets.py:44-78``) is to ``SlippyMapTiles``, for ``rs predict`` on multi-band models
+    (BASELINE configs[4]: RGB + IR).  Every source is composited with its own neighbours and converted to its own mode; the
+    per-source transforms must return tensors that concatenate on ``cat_dim`` (0 for ``[C,H,W]`` floats, 2 for ``[H,W,C]``
+    bytes)."""
+
+    def __init__(self, roots, transforms, modes, size=512, overlap=32, cat_dim=2):
+        super().__init__()
+        assert len(roots) == len(transforms) == len(modes) and roots
+        self.sources = [BufferedSlippyMapDirectory(r, transform=t, size=size, overlap=overlap, mode=m)
+                        for r, t, m in zip(roots, transforms, modes)]
+        first = [tile for tile, _ in self.sources[0].tiles]
+        for src in self.sources[1:]:
+            assert [tile for tile, _ in src.tiles] == first, "same tiles in all image directories"
+        self.cat_dim, self.overlap, self.size = cat_dim, overlap, size
+
+    def __len__(self):
+        return len(self.sources[0])
+
+    def __getitem__(self, i):
+        items = [src[i] for src in self.sources]
+        return torch.cat([image for image, _ in items], dim=self.cat_dim), items[0][1]
+
+    def unbuffer(self, probs):
+        return self.sources[0].unbuffer(probs)
 
 
 def draw_flip_rotations():
@@ -122,13 +150,15 @@ class UnaugmentedTiles(torch.utils.data.Dataset):
     and travel as an op code; the transposes, ``ToTensor`` and ``Normalize`` then run on the device (``rs_augment_tiles``).
     A tile crosses the DataLoader's queues and PCIe as 1 MiB of bytes instead of 5 MiB of floats + int64 labels."""
 
-    def __init__(self, image_dirs, label_dir, size, draw):
+    def __init__(self, image_dirs, label_dir, size, draw, modes=None):
         super().__init__()
         from .transforms import CenterCrop, ConvertImageMode, Resize
 
         self.source = SlippyMapTilesConcatenation(image_dirs, label_dir, joint_transform=None)
         target = (size, size)
-        self.to_image = [ConvertImageMode("RGB"), Resize(target, Image.BILINEAR), CenterCrop(target)]
+        modes = list(modes) if modes is not None else ["RGB"] * len(image_dirs)  # (the reference converts every source to RGB)
+        assert len(modes) == len(image_dirs), "one mode per image directory"
+        self.to_image = [[ConvertImageMode(m), Resize(target, Image.BILINEAR), CenterCrop(target)] for m in modes]
         self.to_mask = [ConvertImageMode("P"), Resize(target, Image.NEAREST), CenterCrop(target)]
         self.draw = draw
 
@@ -142,10 +172,11 @@ class UnaugmentedTiles(torch.utils.data.Dataset):
         mask, mask_tile = self.source.target[i]
         assert all(tile == mask_tile for _, tile in tiles_and_images), "image tile is the same as label tile"
         planes = []
-        for image, _ in tiles_and_images:
-            for fn in self.to_image:
+        for (image, _), chain in zip(tiles_and_images, self.to_image):
+            for fn in chain:
                 image = fn(image)
-            planes.append(np.asarray(image, dtype=np.uint8))
+            plane = np.asarray(image, dtype=np.uint8)
+            planes.append(plane if plane.ndim == 3 else plane[:, :, None])  # (a mode-L source is one band)
         for fn in self.to_mask:
             mask = fn(mask)
         image = torch.from_numpy(np.ascontiguousarray(np.concatenate(planes, axis=2)))
@@ -159,8 +190,8 @@ class DecodedTileCache:
     8f, N4): the items of ``UnaugmentedTiles`` (decoded by ``workers`` DataLoader processes).  A 512x512 RGB tile + its
     mask is 1 MiB: 100 000 tiles fit the MI355X's 288 GB with room to spare, and an epoch then costs no PNG/JPEG decode at all."""
 
-    def __init__(self, image_dirs, label_dir, size, device, workers=0):
-        source = UnaugmentedTiles(image_dirs, label_dir, size, draw=False)
+    def __init__(self, image_dirs, label_dir, size, device, workers=0, modes=None):
+        source = UnaugmentedTiles(image_dirs, label_dir, size, draw=False, modes=modes)
         images, masks = [], []
         for image, mask, _, _ in torch.utils.data.DataLoader(source, batch_size=64, num_workers=workers):
             images.append(image.to(device, non_blocking=True))
@@ -175,6 +206,14 @@ class DecodedTileCache:
         return len(self.tiles)
 
 
+def _per_band(values, channels):
+    """``values`` as one entry per band: as given when it has that many (``robosat_amd.bands``), else the reference's 3-entry
+    RGB statistics repeated per RGB source (tools/train.py:246 applies the same ``Normalize`` to every image)."""
+
+    values = list(values)
+    return values if len(values) == channels else (values * channels)[:channels]
+
+
 class HostDecodeLoader:
     """The reference's training / validation ``DataLoader`` (tools/train.py:262-274) with its transform chain split where
     it stops being deterministic: ``workers`` processes decode, convert, resize, crop and DRAW (``UnaugmentedTiles``); flip /
@@ -182,8 +221,8 @@ class HostDecodeLoader:
     ``(images [N,C,S,S] fp32 normalised, masks [N,S,S] int64, tiles)`` -- already on the device; same augmentation
     distribution, same seeded draws per worker as the host chain, bit-equal tensors (tests/test_gpu_tools.py)."""
 
-    def __init__(self, image_dirs, label_dir, size, batch_sampler, workers, device, mean, std):
-        self.dataset = UnaugmentedTiles(image_dirs, label_dir, size, draw=True)
+    def __init__(self, image_dirs, label_dir, size, batch_sampler, workers, device, mean, std, modes=None):
+        self.dataset = UnaugmentedTiles(image_dirs, label_dir, size, draw=True, modes=modes)
         self.loader = torch.utils.data.DataLoader(self.dataset, num_workers=workers, pin_memory=True, batch_sampler=batch_sampler)
         self.device, self.mean, self.std = device, list(mean), list(std)
         self.batch_sampler = batch_sampler  # (``set_epoch`` of the sharded sampler is reached through it, as on a DataLoader)
@@ -198,7 +237,7 @@ class HostDecodeLoader:
             images = images.to(self.device, non_blocking=True)
             masks = masks.to(self.device, non_blocking=True)
             n, channels = images.shape[0], images.shape[3]
-            mean, std = (self.mean * channels)[:channels], (self.std * channels)[:channels]
+            mean, std = _per_band(self.mean, channels), _per_band(self.std, channels)
             index = torch.arange(n, dtype=torch.int32, device=self.device)
             op = codes.to(torch.int32).to(self.device, non_blocking=True)
             out, om = ops.augment_tiles(images, masks, index, op, mean, std)
@@ -226,7 +265,7 @@ class DeviceAugmentLoader:
 
         c = self.cache
         channels = c.images.shape[3]
-        mean, std = (self.mean * channels)[:channels], (self.std * channels)[:channels]  # (several image dirs: per-band repeat)
+        mean, std = _per_band(self.mean, channels), _per_band(self.std, channels)
         for batch in self.batch_sampler:
             codes = [self.draw_op() for _ in batch]
             index = torch.tensor(batch, dtype=torch.int32).to(c.device, non_blocking=True)

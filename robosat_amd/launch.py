@@ -100,12 +100,22 @@ def spawn_ranks(argv, nprocs, env=None, timeout=None):
     return rc
 
 
-def relaunch_per_gpu(nprocs, module=None, script=None, args=None):
-    """Re-execute the current tool once per rank and exit with their status.  ``module`` (``python -m module``) or
-    ``script`` (``python script``) names what to run; ``args`` defaults to this process's own arguments."""
+def run_per_gpu(nprocs, args, module=None, script=None):
+    """Run a tool once per rank -- ``python -m module <args>`` or ``python script <args>`` -- and return the job's exit
+    status.  ``args`` is the tool's command line REBUILT from the arguments its ``main()`` received (not this process's
+    ``sys.argv``: a library caller of ``train.main(namespace)`` has a different command line), and the caller decides what
+    to do with the status (the tools return normally on 0 -- an in-process caller keeps running -- and raise ``SystemExit``
+    with it otherwise)."""
 
-    args = list(sys.argv[1:] if args is None else args)
-    argv = [sys.executable] + (["-m", module] if module else [script]) + args
+    argv = [sys.executable] + (["-m", module] if module else [script]) + [str(a) for a in args]
     sys.stdout.flush()
     sys.stderr.flush()
-    sys.exit(spawn_ranks(argv, nprocs))
+    return spawn_ranks(argv, nprocs)
+
+
+def check_ranks_fit_devices(world, device_count, backend):
+    """RCCL refuses two ranks on one device; say so before the communicator does (with a stack of C++ frames)."""
+
+    if backend == "nccl" and world > max(1, device_count):
+        raise RuntimeError("{} ranks but {} visible GPU(s): RCCL needs one device per rank (lower ROBOSAT_GPUS / "
+                           "--nproc-per-node, or ROBOSAT_DIST_BACKEND=gloo for a shared-device test)".format(world, device_count))

@@ -16,11 +16,34 @@ def _check(inputs, targets):
     return inputs.contiguous(), targets.contiguous()
 
 
+def _global_batch_normaliser(loss, stats):
+    """Data-parallel ranks: make the weighted-NLL normaliser the GLOBAL batch's.
+
+    The reference's ``DataParallel`` gathers the logits of all replicas and evaluates ONE loss over the global batch
+    (tools/train.py:180-186): ``sum_i w_i l_i / sum_i w_i`` with both sums over every pixel of every shard.  Each rank here
+    sees only its shard, and the mean of per-shard ratios is a different number (and gradient) whenever the shards' class
+    mixes -- hence their weight sums -- differ.  The fix costs one scalar all-reduce: with ``D = mean_r sum_i w_i`` (the
+    global denominator / world) replacing the local denominator, the rank's loss becomes ``num_r / D`` and the average of
+    the ranks' losses / gradients that ``rs train`` forms anyway is exactly the global-batch loss / gradient.
+    ``stats[1]`` (what ``rs_nll_loss_bwd`` divides by) is rewritten in place; returns the rescaled loss."""
+
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return loss
+    local = stats[1].clone()
+    den = stats[1:2]
+    dist.all_reduce(den)  # (a 4-byte SUM on the device; no host sync)
+    den.div_(dist.get_world_size())
+    return loss * (local / den[0])
+
+
 class _NLLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, targets, weight, mode, gamma):
         x = inputs.detach().float()
         loss, stats = ops.nll_loss_fwd(x, targets, weight, mode, gamma)
+        loss = _global_batch_normaliser(loss, stats)
         ctx.save_for_backward(x, targets, stats)
         ctx.weight, ctx.mode, ctx.gamma = weight, mode, gamma
         return loss

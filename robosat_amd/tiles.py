@@ -47,17 +47,18 @@ def tiles_from_csv(path):
                 yield Tile(*(int(v) for v in row))
 
 
-def buffer_tile_image(tile, tiles, overlap, tile_size, nodata=0, opener=None):
+def buffer_tile_image(tile, tiles, overlap, tile_size, nodata=0, opener=None, mode="RGB"):
     """The tile's RGB image with an ``overlap``-pixel border taken from its 8 neighbours (``nodata`` where a
     neighbour is missing): size ``tile_size + 2*overlap`` squared (reference tiles.py:162-227).
 
-    ``tiles`` is a mapping ``Tile -> path`` (or an iterable of pairs).  ``opener(path)`` returns the decoded RGB image
+    ``mode`` (extension; default the reference's "RGB") is the PIL mode of the composite: "L" for a single-band source.
+    ``tiles`` is a mapping ``Tile -> path`` (or an iterable of pairs).  ``opener(path)`` returns the decoded image in that mode
     (default: ``Image.open(path).convert("RGB")``); ``BufferedSlippyMapDirectory`` passes a small LRU cache here, because
     the composite of every tile decodes nine files and neighbouring tiles share six of them."""
 
     store = tiles if isinstance(tiles, dict) else dict(tiles)
     size = tile_size + 2 * overlap
-    composite = Image.new(mode="RGB", size=(size, size), color=nodata)
+    composite = Image.new(mode=mode, size=(size, size), color=nodata)
 
     # per axis and neighbour offset: (destination start, source start, length)
     span = {-1: (0, tile_size - overlap, overlap), 0: (overlap, 0, tile_size), 1: (overlap + tile_size, 0, overlap)}
@@ -72,7 +73,7 @@ def buffer_tile_image(tile, tiles, overlap, tile_size, nodata=0, opener=None):
             (tx, sx, w), (ty, sy, h) = span[dx], span[dy]
             if w == 0 or h == 0:
                 continue
-            piece = Image.open(path).convert("RGB") if opener is None else opener(path)
+            piece = Image.open(path).convert(mode) if opener is None else opener(path)
             if dx == 0 and dy == 0:
                 composite.paste(piece, box=(tx, ty))
             else:

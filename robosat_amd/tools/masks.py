@@ -69,7 +69,9 @@ def main(args):
     for start in tqdm(range(0, len(tilesets), batch), desc="Masks", unit="batch", ascii=True):
         group = tilesets[start:start + batch]
         for tileset in group:
-            assert len(set(tile for tile, _ in tileset)), "tilesets in sync"
+            # (the reference's `assert len(set(...))` can never fail -- masks.py:60; a second probability directory listing
+            # other tiles must not be voted against this one silently)
+            assert len(set(tile for tile, _ in tileset)) == 1, "tilesets in sync"
         # [K models][tiles of the batch][H][W][C-1]
         stacks = [[load_quantized(path) for _, path in tileset] for tileset in group]
         shape = stacks[0][0].shape
@@ -80,6 +82,8 @@ def main(args):
         masks = ops.softvote_masks(dq, args.weights).view(len(group), h, w).cpu().numpy()
 
         names = colors or (["denim", "orange"] if cq == 1 else DEFAULT_COLORS[:cq + 1])
+        if len(names) < cq + 1:
+            sys.exit("Error: the probabilities encode {} classes but the dataset config lists {} colors".format(cq + 1, len(names)))
         palette = make_palette(*names)
         for tileset, mask in zip(group, masks):
             x, y, z = tileset[0][0]

@@ -19,9 +19,10 @@ from torch.utils.data import DataLoader
 from tqdm import tqdm
 
 from robosat_amd import launch, png
+from robosat_amd.bands import bands_from_config, split_per_source
 from robosat_amd.colors import continuous_palette_for_color
-from robosat_amd.config import load_config
-from robosat_amd.datasets import BufferedSlippyMapDirectory
+from robosat_amd.config import check_num_classes, load_config
+from robosat_amd.datasets import BufferedSlippyMapConcatenation, BufferedSlippyMapDirectory
 from robosat_amd.transforms import Compose, ConvertImageMode, ImageToTensor, ImageToUint8, Normalize
 from robosat_amd.unet import UNet
 
@@ -41,7 +42,20 @@ def add_parser(subparser):
     parser.add_argument("probs", type=str, help="directory to save slippy map probability masks to")
     parser.add_argument("--model", type=str, required=True, help="path to model configuration file")
     parser.add_argument("--dataset", type=str, required=True, help="path to dataset configuration file")
+    # extension (multi-band models, BASELINE configs[4]): one more slippy-map directory per further entry of the dataset's
+    # `[common] image_dirs` (e.g. the infrared tiles), same z/x/y as `tiles`
+    parser.add_argument("--extra_tiles", type=str, nargs="*", default=[], help="directories with the further image bands")
     parser.set_defaults(func=main)
+
+
+def argv_from_args(args):
+    """The ``rs predict`` command line equivalent to the namespace ``main()`` received (see tools/train.py)."""
+
+    argv = ["predict", "--batch_size", str(args.batch_size), "--checkpoint", args.checkpoint, "--overlap", str(args.overlap),
+            "--tile_size", str(args.tile_size), "--workers", str(args.workers), "--model", args.model, "--dataset", args.dataset]
+    extra = list(getattr(args, "extra_tiles", None) or [])
+    # (positionals first: `--extra_tiles` takes any number of values and would swallow them)
+    return argv + [args.tiles, args.probs] + (["--extra_tiles"] + extra if extra else [])
 
 
 def strip_module_prefix(state_dict):
@@ -85,32 +99,50 @@ def main(args):
 
     if not launch.under_launcher():
         gpus = int(os.environ.get("ROBOSAT_GPUS", torch.cuda.device_count()))
-        if gpus > 1:
-            launch.relaunch_per_gpu(gpus, module="robosat_amd.tools")
+        if gpus > 1 and getattr(args, "spawn", True):  # (`spawn=False`: the library caller's opt-out)
+            status = launch.run_per_gpu(gpus, argv_from_args(args), module="robosat_amd.tools")
+            if status != 0:
+                sys.exit(status)
+            return
     world, rank, local = launch.dist_env()
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
     num_classes = len(dataset["common"]["classes"])
+    try:
+        check_num_classes(num_classes, "predict")
+        bands = bands_from_config(dataset, model)  # (default: the reference's one RGB directory, ImageNet statistics)
+    except ValueError as err:
+        sys.exit("Error: {}".format(err))
+    roots = [args.tiles] + list(getattr(args, "extra_tiles", None) or [])
+    if len(roots) != len(bands.dirs):
+        sys.exit("Error: the dataset config names {} image source(s) {}; give the further ones with --extra_tiles".format(
+            len(bands.dirs), bands.dirs))
 
     chkpt = torch.load(args.checkpoint, map_location=device)
-    net = UNet(num_classes, pretrained=False, compute_dtype=model.get("model", {}).get("compute_dtype", "fp32")).to(device)
+    net = UNet(num_classes, pretrained=False, compute_dtype=model.get("model", {}).get("compute_dtype", "fp32"),
+               in_channels=bands.channels).to(device)
     net.load_state_dict(strip_module_prefix(chkpt["state_dict"]))
     net.eval()
 
-    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    mean, std = bands.mean, bands.std
     # Default: the device-side pipeline -- tiles go up as uint8, ToTensor + Normalize, the
     # network, softmax, the un-buffer crop and the 8-bit quantisation all run on the GPU and one byte per pixel comes
     # back.  ROBOSAT_PREDICT_HOST_PIPELINE=1 keeps the reference's host-side steps (same bytes; the parity tests compare).
     host_pipeline = os.environ.get("ROBOSAT_PREDICT_HOST_PIPELINE", "0") == "1"
     if host_pipeline:
-        transform = Compose([ConvertImageMode(mode="RGB"), ImageToTensor(), Normalize(mean=mean, std=std)])
+        transforms = [Compose([ConvertImageMode(mode=md), ImageToTensor(), Normalize(mean=m, std=s)])
+                      for md, m, s in zip(bands.modes, split_per_source(bands, mean), split_per_source(bands, std))]
     else:
-        transform = Compose([ConvertImageMode(mode="RGB"), ImageToUint8()])
-    assert 2 <= num_classes <= 5, "the probability PNGs hold 1..4 channels: binary models (reference) up to 5 classes"
+        transforms = [Compose([ConvertImageMode(mode=md), ImageToUint8()]) for md in bands.modes]
 
-    directory = BufferedSlippyMapDirectory(args.tiles, transform=transform, size=args.tile_size, overlap=args.overlap)
+    if len(roots) == 1:
+        directory = BufferedSlippyMapDirectory(args.tiles, transform=transforms[0], size=args.tile_size, overlap=args.overlap,
+                                               mode=bands.modes[0])
+    else:
+        directory = BufferedSlippyMapConcatenation(roots, transforms, bands.modes, size=args.tile_size, overlap=args.overlap,
+                                                   cat_dim=0 if host_pipeline else 2)
     assert len(directory) > 0, "at least one tile in dataset"
 
     loader = DataLoader(directory, num_workers=args.workers, pin_memory=True,

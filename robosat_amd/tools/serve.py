@@ -16,6 +16,7 @@ import numpy as np
 import torch
 from PIL import Image
 
+from robosat_amd.bands import bands_from_config
 from robosat_amd.colors import make_palette
 from robosat_amd.config import load_config
 from robosat_amd.unet import UNet
@@ -54,14 +55,20 @@ class Predictor:
         self.checkpoint = checkpoint
         self.model = model
         self.dataset = dataset
+        # the band layout of the dataset config (default: one RGB image, ImageNet statistics -- serve.py:152-153); a served
+        # tile is ONE image, so a multi-band model needs a single 4-band source (`image_modes = ["RGBA"]`)
+        self.bands = bands_from_config(dataset, model)
+        if len(self.bands.dirs) != 1:
+            raise ValueError("rs serve fetches one image per tile: the dataset config must name a single image source")
         self.net = self.net_from_chkpt_()
         self.palette = make_palette(*self.dataset["common"]["colors"])
 
     def segment(self, image):
         """PIL image -> mode-P mask image: ``argmax`` of the logits, palette from the dataset's colours."""
 
-        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
-        u8 = torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8)).unsqueeze(0)
+        mean, std = self.bands.mean, self.bands.std
+        pixels = np.array(image.convert(self.bands.modes[0]), dtype=np.uint8)
+        u8 = torch.from_numpy(pixels if pixels.ndim == 3 else pixels[:, :, None]).unsqueeze(0)
         mask = self.net.predict_classes(u8.to(self.device, non_blocking=True), mean=mean, std=std)[0].cpu().numpy()
         mask = Image.fromarray(mask, mode="P")
         mask.putpalette(self.palette)
@@ -70,7 +77,8 @@ class Predictor:
     def net_from_chkpt_(self):
         chkpt = torch.load(self.checkpoint, map_location=self.device)
         num_classes = len(self.dataset["common"]["classes"])
-        net = UNet(num_classes, pretrained=False, compute_dtype=self.model.get("model", {}).get("compute_dtype", "fp32")).to(self.device)
+        net = UNet(num_classes, pretrained=False, compute_dtype=self.model.get("model", {}).get("compute_dtype", "fp32"),
+                   in_channels=self.bands.channels).to(self.device)
         state = chkpt["state_dict"]
         net.load_state_dict({(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()})
         net.eval()

@@ -27,14 +27,15 @@ from torch.utils.data import DataLoader
 from tqdm import tqdm
 
 from robosat_amd import launch, parallel
-from robosat_amd.config import load_config
+from robosat_amd.bands import bands_from_config, split_per_source
+from robosat_amd.config import check_num_classes, load_config
 from robosat_amd.datasets import SlippyMapTilesConcatenation
 from robosat_amd.log import Log
 from robosat_amd.losses import CrossEntropyLoss2d, FocalLoss2d, LovaszLoss2d, mIoULoss2d
 from robosat_amd.metrics import Metrics
 from robosat_amd.transforms import (
     CenterCrop, ConvertImageMode, ImageToTensor, JointCompose, JointRandomHorizontalFlip, JointRandomRotation,
-    JointTransform, MaskToTensor, Normalize, Resize,
+    JointPerSource, JointTransform, MaskToTensor, Normalize, Resize,
 )
 from robosat_amd.unet import UNet
 
@@ -66,8 +67,24 @@ def add_parser(subparser):
 def _dist_env():
     world, rank, local = launch.dist_env()
     if world > 1:
+        try:
+            launch.check_ranks_fit_devices(world, torch.cuda.device_count(), os.environ.get("ROBOSAT_DIST_BACKEND", "nccl"))
+        except RuntimeError as err:
+            sys.exit("Error: {}".format(err))
         parallel.init_process_group(world, rank)
     return world, rank, local
+
+
+def argv_from_args(args):
+    """The ``rs train`` command line equivalent to the namespace ``main()`` received (what the per-GPU ranks are started
+    with: an in-process caller's own ``sys.argv`` is somebody else's command line)."""
+
+    argv = ["train", "--model", args.model, "--dataset", args.dataset, "--workers", str(args.workers)]
+    if args.checkpoint:
+        argv += ["--checkpoint", args.checkpoint]
+    if args.resume:
+        argv += ["--resume", "True"]
+    return argv
 
 
 def main(args):
@@ -84,8 +101,12 @@ def main(args):
         # the reference uses every visible GPU (DataParallel, tools/train.py:69): one process per GPU here
         gpus = int(os.environ.get("ROBOSAT_GPUS", torch.cuda.device_count()))
         nranks = launch.ranks_for_batch(batch_size, gpus)
-        if nranks > 1:
-            launch.relaunch_per_gpu(nranks, module="robosat_amd.tools")
+        # (`spawn=False` on the namespace is the library caller's opt-out: train in THIS process on one GPU)
+        if nranks > 1 and getattr(args, "spawn", True):
+            status = launch.run_per_gpu(nranks, argv_from_args(args), module="robosat_amd.tools")
+            if status != 0:
+                sys.exit(status)
+            return
 
     world, rank, local = _dist_env()
     if batch_size % world != 0:
@@ -100,7 +121,14 @@ def main(args):
     num_classes = len(dataset["common"]["classes"])
     # [model] compute_dtype = "bf16" (extension key; default "fp32" = the parity path) selects the bf16 MFMA kernels
     compute_dtype = model.get("model", {}).get("compute_dtype", "fp32")
-    in_channels = int(model.get("model", {}).get("in_channels", 3))  # extension key: 4 = RGB + IR (BASELINE configs[4])
+    # extension keys: the dataset's `[common] image_dirs / image_modes` name the bands (robosat_amd.bands; default = the
+    # reference's one RGB directory), `[model] in_channels` must agree with them when given (4 = RGB + IR, BASELINE configs[4])
+    try:
+        check_num_classes(num_classes, "train")
+        bands = bands_from_config(dataset, model)
+    except ValueError as err:
+        sys.exit("Error: {}".format(err))
+    in_channels = bands.channels
     # The reference always starts from torchvision's ImageNet encoder (unet.py:94).  Without a checkpoint to fine-tune
     # from, a missing weights file is an error unless `[model] pretrained = false` (extension key) asks for a random one.
     pretrained = model.get("model", {}).get("pretrained", True)
@@ -306,15 +334,15 @@ def get_split_loaders(model, dataset, workers, device, rank=0, world=1):
     size = model["common"]["image_size"]
     batch_size = model["common"]["batch_size"] // world
     path = dataset["common"]["dataset"]
-    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    bands = bands_from_config(dataset, model)
     seed = int(os.environ.get("ROBOSAT_SEED", "0"))
     loaders = []
     for split, shuffle in (("training", True), ("validation", False)):
-        images, labels = [os.path.join(path, split, "images")], os.path.join(path, split, "labels")
+        images, labels = [os.path.join(path, split, d) for d in bands.dirs], os.path.join(path, split, "labels")
         count = len(SlippyMapTilesConcatenation(images, labels))
         assert count > 0, "at least one tile in {} dataset".format(split)
         sampler = ShardedBatchSampler(count, batch_size, rank, world, shuffle, seed if shuffle else 0)
-        loaders.append(HostDecodeLoader(images, labels, size, sampler, workers, device, mean, std))
+        loaders.append(HostDecodeLoader(images, labels, size, sampler, workers, device, bands.mean, bands.std, modes=bands.modes))
     return loaders
 
 
@@ -325,14 +353,15 @@ def get_device_loaders(model, dataset, device, rank=0, world=1, workers=0):
     size = model["common"]["image_size"]
     batch_size = model["common"]["batch_size"] // world
     path = dataset["common"]["dataset"]
-    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    bands = bands_from_config(dataset, model)
     seed = int(os.environ.get("ROBOSAT_SEED", "0"))
     loaders = []
     for split, shuffle in (("training", True), ("validation", False)):
-        cache = DecodedTileCache([os.path.join(path, split, "images")], os.path.join(path, split, "labels"), size, device, workers)
+        cache = DecodedTileCache([os.path.join(path, split, d) for d in bands.dirs], os.path.join(path, split, "labels"), size,
+                                 device, workers, modes=bands.modes)
         assert len(cache) > 0, "at least one tile in {} dataset".format(split)
         sampler = ShardedBatchSampler(len(cache), batch_size, rank, world, shuffle, seed if shuffle else 0)
-        loaders.append(DeviceAugmentLoader(cache, sampler, mean, std))
+        loaders.append(DeviceAugmentLoader(cache, sampler, bands.mean, bands.std))
     return loaders
 
 
@@ -341,11 +370,13 @@ def get_dataset_loaders(model, dataset, workers, rank=0, world=1):
     batch_size = model["common"]["batch_size"] // world  # the TOML batch is the global one (DataParallel scatters it)
     path = dataset["common"]["dataset"]
 
-    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    # one RGB directory with the ImageNet statistics unless the dataset config names other bands (robosat_amd.bands)
+    bands = bands_from_config(dataset, model)
+    means, stds = split_per_source(bands, bands.mean), split_per_source(bands, bands.std)
 
     transform = JointCompose(
         [
-            JointTransform(ConvertImageMode("RGB"), ConvertImageMode("P")),
+            JointPerSource([ConvertImageMode(m) for m in bands.modes], ConvertImageMode("P")),
             JointTransform(Resize(target_size, Image.BILINEAR), Resize(target_size, Image.NEAREST)),
             JointTransform(CenterCrop(target_size), CenterCrop(target_size)),
             JointRandomHorizontalFlip(0.5),
@@ -353,15 +384,15 @@ def get_dataset_loaders(model, dataset, workers, rank=0, world=1):
             JointRandomRotation(0.5, 90),
             JointRandomRotation(0.5, 90),
             JointTransform(ImageToTensor(), MaskToTensor()),
-            JointTransform(Normalize(mean=mean, std=std), None),
+            JointPerSource([Normalize(mean=m, std=s) for m, s in zip(means, stds)], None),
         ]
     )
 
     train_dataset = SlippyMapTilesConcatenation(
-        [os.path.join(path, "training", "images")], os.path.join(path, "training", "labels"), transform
+        [os.path.join(path, "training", d) for d in bands.dirs], os.path.join(path, "training", "labels"), transform
     )
     val_dataset = SlippyMapTilesConcatenation(
-        [os.path.join(path, "validation", "images")], os.path.join(path, "validation", "labels"), transform
+        [os.path.join(path, "validation", d) for d in bands.dirs], os.path.join(path, "validation", "labels"), transform
     )
 
     assert len(train_dataset) > 0, "at least one tile in training dataset"

@@ -111,6 +111,22 @@ class JointTransform:
         return images, mask
 
 
+class JointPerSource:
+    """One (stateless) transformation PER image source -- e.g. ``ConvertImageMode("RGB")`` for the first directory and
+    ``ConvertImageMode("L")`` for an infrared one, or each source's own ``Normalize`` -- where ``JointTransform`` applies the
+    same one to all of them (the band layout of ``robosat_amd.bands``); ``None`` entries leave a source / the mask untouched."""
+
+    def __init__(self, image_transforms, mask_transform=None):
+        self.image_transforms, self.mask_transform = list(image_transforms), mask_transform
+
+    def __call__(self, images, mask):
+        assert len(images) == len(self.image_transforms), "one transformation per image source"
+        images = [v if fn is None else fn(v) for fn, v in zip(self.image_transforms, images)]
+        if self.mask_transform is not None:
+            mask = self.mask_transform(mask)
+        return images, mask
+
+
 class _JointRandomTranspose:
     """With probability ``p`` applies one PIL transpose ``method`` to all images and the mask alike."""
 

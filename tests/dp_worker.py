@@ -96,6 +96,43 @@ def gpu_unet(rank, world, dtype):
             "replica_drift": drift, "fc_has_no_grad": bool(fc_grad), "loss_local": loss_local, "loss_dp": loss_dp}
 
 
+def gpu_weighted_ce(rank, world):
+    """Weighted cross-entropy / focal loss on shards with different class mixes: the average of the ranks' losses and
+    gradients must equal the loss / gradient of ONE evaluation over the global batch, which is what the reference's
+    DataParallel computes (tools/train.py:180-186) -- not the mean of per-shard normalised losses."""
+    import torch.nn.functional as F
+
+    from robosat_amd import losses
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    c, n, h, w = 3, 2, 32, 48
+    weight = torch.tensor([0.5, 2.0, 5.0])
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(world * n, c, h, w, generator=g)
+    # rank 0's shard is almost all class 0, rank 1's mostly class 2: very different weight sums
+    probs = [torch.tensor([0.9, 0.08, 0.02]), torch.tensor([0.1, 0.2, 0.7])]
+    targets = torch.cat([torch.multinomial(probs[r % 2], n * h * w, True, generator=g).view(n, h, w) for r in range(world)])
+    out = {}
+    for name, crit, ref in (("ce", losses.CrossEntropyLoss2d(weight=weight), lambda x: F.nll_loss(F.log_softmax(x, 1), targets, weight=weight)),
+                            ("focal", losses.FocalLoss2d(weight=weight),
+                             lambda x: F.nll_loss((1 - F.softmax(x, 1)) ** 2 * F.log_softmax(x, 1), targets, weight=weight))):
+        x_ref = logits.clone().requires_grad_(True)
+        want = ref(x_ref)
+        want.backward()
+        mine = logits[rank * n:(rank + 1) * n].to(dev).requires_grad_(True)
+        loss = crit.to(dev)(mine, targets[rank * n:(rank + 1) * n].to(dev))
+        loss.backward()
+        mean_loss = loss.detach().clone()
+        dist.all_reduce(mean_loss)
+        mean_loss /= world
+        got = mine.grad.cpu() / world  # (what the gradient all-reduce's average contributes for this shard)
+        want_g = x_ref.grad[rank * n:(rank + 1) * n]
+        out[name] = {"loss_err": abs(float(mean_loss) - float(want)) / abs(float(want)),
+                     "grad_err": float((got - want_g).abs().max() / want_g.abs().max())}
+    return out
+
+
 def main():
     mode, outdir = sys.argv[1], sys.argv[2]
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
@@ -104,6 +141,8 @@ def main():
     parallel.init_process_group(world, rank, backend="gloo")
     if mode == "cpu":
         res = cpu_logic(rank, world)
+    elif mode == "gpu_wce":
+        res = gpu_weighted_ce(rank, world)
     elif mode == "fail":
         if rank == 1:
             sys.exit(3)  # a lost rank: the launcher must stop the survivor (who would wait forever below)

@@ -135,3 +135,100 @@ def test_split_chain_items_match_reference(tmp_path):
         assert np.array_equal(a_img, b_img.numpy()) and np.array_equal(a_mask, b_mask.numpy()), (i, code)
         seen.add(code)
     assert len(seen) >= 4  # (the seeds exercise several elements of the flip / rotation group)
+
+
+def test_four_band_items_are_the_reference_chain_per_source(tmp_path):
+    """BASELINE configs[4] feeds RGB + IR: two image directories concatenated on the channel axis by the dataset layer
+    (datasets.py:44-78), each converted to ITS mode (RGB / L) and normalised with ITS statistics (robosat_amd.bands).  The
+    reference's own classes, run once per directory with that directory's mode and statistics under the same seed (the joint
+    random transforms draw once per item, whatever the number of images), must give the same bands; and the split chain the
+    default ``rs train`` loader uses (worker: decode / convert / resize / crop / draw; device: transposes + normalise, here
+    its CPU statement) must give the same item again."""
+    rd, rt = _reference_modules()
+    from oracle import tools_ref as T
+    from robosat_amd import datasets as md, transforms as mt
+    from robosat_amd.bands import bands_from_config, split_per_source
+
+    size = 96
+    root = synth.make_dataset(str(tmp_path / "ds"), n_train=6, n_val=2, size=128, seed=13, classes=4, ir=True)
+    bands = bands_from_config({"common": {"image_dirs": ["images", "ir"], "image_modes": ["RGB", "L"]}}, {"model": {"in_channels": 4}})
+    assert bands.channels == 4 and bands.mean[:3] == MEAN and len(bands.mean) == 4
+    dirs = [os.path.join(root, "training", d) for d in bands.dirs]
+    lab = os.path.join(root, "training", "labels")
+    means, stds = split_per_source(bands, bands.mean), split_per_source(bands, bands.std)
+
+    def ref_chain(mode, mean, std):
+        return rt.JointCompose([
+            rt.JointTransform(rt.ConvertImageMode(mode), rt.ConvertImageMode("P")),
+            rt.JointTransform(rt.Resize((size, size), 2), rt.Resize((size, size), 0)),
+            rt.JointTransform(rt.CenterCrop((size, size)), rt.CenterCrop((size, size))),
+            rt.JointRandomHorizontalFlip(0.5),
+            rt.JointRandomRotation(0.5, 90),
+            rt.JointRandomRotation(0.5, 90),
+            rt.JointRandomRotation(0.5, 90),
+            rt.JointTransform(rt.ImageToTensor(), rt.MaskToTensor()),
+            rt.JointTransform(rt.Normalize(mean=mean, std=std), None),
+        ])
+
+    refs = [rd.SlippyMapTilesConcatenation([d], lab, ref_chain(m, mu, sd)) for d, m, mu, sd in zip(dirs, bands.modes, means, stds)]
+    ours = md.SlippyMapTilesConcatenation(dirs, lab, mt.JointCompose([
+        mt.JointPerSource([mt.ConvertImageMode(m) for m in bands.modes], mt.ConvertImageMode("P")),
+        mt.JointTransform(mt.Resize((size, size), 2), mt.Resize((size, size), 0)),
+        mt.JointTransform(mt.CenterCrop((size, size)), mt.CenterCrop((size, size))),
+        mt.JointRandomHorizontalFlip(0.5),
+        mt.JointRandomRotation(0.5, 90),
+        mt.JointRandomRotation(0.5, 90),
+        mt.JointRandomRotation(0.5, 90),
+        mt.JointTransform(mt.ImageToTensor(), mt.MaskToTensor()),
+        mt.JointPerSource([mt.Normalize(mean=mu, std=sd) for mu, sd in zip(means, stds)], None),
+    ]))
+    split = md.UnaugmentedTiles(dirs, lab, size, draw=True, modes=bands.modes)
+    assert len(ours) == len(split) == 6
+    for i in range(len(ours)):
+        parts = []
+        for ref in refs:
+            random.seed(500 + i)
+            b_img, b_mask, _ = ref[i]
+            parts.append(b_img)
+        want = torch.cat(parts, dim=0)
+        random.seed(500 + i)
+        a_img, a_mask, a_tiles = ours[i]
+        assert tuple(a_img.shape) == (4, size, size) and len(a_tiles) == 2 and a_tiles[0] == a_tiles[1]
+        assert torch.equal(a_img, want) and torch.equal(a_mask, b_mask), i
+        assert int(a_mask.max()) <= 3
+        random.seed(500 + i)
+        u8, m8, code, _ = split[i]
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (size, size, 4)
+        draws = [0.0 if code & 1 else 1.0] + [0.0] * (code >> 1) + [1.0] * (3 - (code >> 1))
+        s_img, s_mask = T.augment(u8.numpy(), m8.numpy(), draws, bands.mean, bands.std)
+        assert np.array_equal(s_img, want.numpy()) and np.array_equal(s_mask, b_mask.numpy()), (i, code)
+
+
+def test_four_band_buffered_predict_tiles(tmp_path):
+    """``rs predict --extra_tiles``: every source composited with its own neighbours in its own mode, then concatenated --
+    band for band what the reference's BufferedSlippyMapDirectory gives for each directory on its own."""
+    rd, rt = _reference_modules()
+    from robosat_amd import datasets as md, transforms as mt
+
+    root = synth.make_dataset(str(tmp_path / "ds"), n_train=8, n_val=0, size=256, seed=14, classes=4, ir=True)
+    rgb, ir = os.path.join(root, "training", "images"), os.path.join(root, "training", "ir")
+    both = md.BufferedSlippyMapConcatenation([rgb, ir], [mt.Compose([mt.ConvertImageMode("RGB"), mt.ImageToUint8()]),
+                                                         mt.Compose([mt.ConvertImageMode("L"), mt.ImageToUint8()])],
+                                             ["RGB", "L"], size=256, overlap=32, cat_dim=2)
+    ref_rgb = rd.BufferedSlippyMapDirectory(rgb, transform=rt.Compose([rt.ConvertImageMode("RGB"), rt.ImageToTensor()]), size=256, overlap=32)
+    # (the reference composites in RGB only, tiles.py:186: an L-mode file comes back as three equal planes)
+    ref_ir = rd.BufferedSlippyMapDirectory(ir, transform=rt.Compose([rt.ConvertImageMode("RGB"), rt.ImageToTensor()]), size=256, overlap=32)
+    want = {}
+    for i in range(len(ref_rgb)):
+        a, tile = ref_rgb[i]
+        want.setdefault(tuple(tile.tolist()), {})["rgb"] = a
+    for i in range(len(ref_ir)):
+        a, tile = ref_ir[i]
+        want[tuple(tile.tolist())]["ir"] = a
+    assert len(both) == 8
+    for i in range(len(both)):
+        u8, tile = both[i]
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (320, 320, 4)
+        w = want[tuple(tile.tolist())]
+        got = u8.permute(2, 0, 1).float().div(255)
+        assert torch.equal(got[:3], w["rgb"]) and torch.equal(got[3], w["ir"][0]), tile

@@ -36,6 +36,17 @@ def test_two_rank_train_step_averages_gradients_and_keeps_replicas_identical(tmp
     assert res[0]["loss_local"] != res[1]["loss_local"]
 
 
+def test_two_rank_weighted_losses_are_the_global_batch_loss(tmp_path):
+    """with class weights the per-shard normalisers differ; the ranks exchange the denominator (one scalar
+    all-reduce) so that averaged losses / gradients equal the reference's single global-batch evaluation."""
+    rc, res = run_world2("gpu_wce", tmp_path, timeout=600)
+    assert rc == 0, res
+    for r in res:
+        for name in ("ce", "focal"):
+            assert r[name]["loss_err"] <= 2e-5, (name, r)
+            assert r[name]["grad_err"] <= 1e-3, (name, r)
+
+
 def _rs(args, env_extra, cwd):
     env = dict(os.environ)
     env.update(env_extra)

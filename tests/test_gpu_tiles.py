@@ -287,7 +287,8 @@ def test_bench_symbols_are_covered(tmp_path):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "2",
+                        "--no-miou"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -297,3 +298,7 @@ def test_bench_symbols_are_covered(tmp_path):
     assert not missing, missing
     assert line["parity"]["max_abs_vs_oracle"] <= 1e-3
     assert line["train"]["parity"]["max_abs_vs_oracle"] <= 5e-2
+    # the other BASELINE configurations ride in the same line (configs[4]: 4 bands, 4 classes; fp32 training; configs[3])
+    assert set(line["legs"]) == {"cfg5_train_bf16_4band_4class", "train_fp32_bs8", "cfg4_predict_fp32_1024_bs8"}
+    assert all(leg["value"] > 0 for leg in line["legs"].values())
+    assert line["legs"]["cfg5_train_bf16_4band_4class"]["config"]["bands"] == 4

@@ -257,9 +257,14 @@ def test_miou_both_branches_vs_oracle(noise, margin, branch):
     close(got_in.grad.cpu(), ref_in.grad, 1e-3, "miou grad")
 
 
-@pytest.mark.parametrize("n,c,h,w", [(3, 2, 128, 128), (2, 4, 64, 96), (1, 3, 48, 80)])
+@pytest.mark.parametrize("n,c,h,w", [(3, 2, 128, 128), (2, 4, 64, 96), (1, 3, 48, 80),
+                                     (2, 2, 512, 512),    # 524 288 keys per image: what BASELINE configs[2] sorts (x 32 images)
+                                     (1, 4, 512, 512),    # 1 048 576 keys per image: configs[4]
+                                     (3, 3, 256, 320)])   # 245 760 keys: not a multiple of the 8 192-key digit tile x blocks
 def test_lovasz_vs_oracle(n, c, h, w):
-    """Multi-block radix sort / scan sizes (P up to 65k per image) against the CPU oracle."""
+    """Multi-block radix sort / segmented scan against the CPU oracle (reference losses.py:96-119), from one-block images up
+    to the key counts the benchmark runs -- the 8 192-element LDS digit tiles, the multi-block scan carry and the segment
+    offsets across > 64 blocks per image are only reached at the full sizes -- with the same bars at every size."""
     from robosat_amd import losses
     from oracle import seeded
 

@@ -252,3 +252,72 @@ def test_decoded_tile_cache_holds_the_unaugmented_items(tmp_path):
             image, mask, code, tiles = items[i]
             assert code == 0 and torch.equal(cache.images[i], image) and torch.equal(cache.masks[i], mask)
             assert tuple(cache.tiles[i]) == tuple(tiles[0])
+
+
+def test_band_layout_defaults_and_validation():
+    """robosat_amd.bands: no keys = the reference's single RGB directory with the ImageNet statistics (train.py:246,262);
+    extension keys name further sources; inconsistent layouts are errors, not silent 3-band batches."""
+    from robosat_amd.bands import bands_from_config, split_per_source
+
+    b = bands_from_config({"common": {"dataset": "/x"}})
+    assert b.dirs == ["images"] and b.modes == ["RGB"] and b.channels == 3
+    assert b.mean == [0.485, 0.456, 0.406] and b.std == [0.229, 0.224, 0.225]
+    b = bands_from_config({"common": {"image_dirs": ["images", "ir"]}}, {"model": {"in_channels": 4}})
+    assert b.modes == ["RGB", "L"] and b.channels == 4 and split_per_source(b, b.mean) == [[0.485, 0.456, 0.406], [0.449]]
+    b = bands_from_config({"common": {"image_dirs": ["rgbi"], "image_modes": ["RGBA"], "mean": [0.1, 0.2, 0.3, 0.4], "std": [1, 1, 1, 2]}})
+    assert b.channels == 4 and b.mean == [0.1, 0.2, 0.3, 0.4] and b.std == [1.0, 1.0, 1.0, 2.0]
+    for bad, model in (({"common": {"image_dirs": ["a", "b"], "image_modes": ["RGB"]}}, None),            # modes vs dirs
+                       ({"common": {"image_dirs": ["a", "b"], "image_modes": ["RGB", "RGB"]}}, None),      # 6 bands
+                       ({"common": {"image_modes": ["CMYK"]}}, None),                                        # unknown mode
+                       ({"common": {"mean": [0.5]}}, None),                                                  # 1 mean for 3 bands
+                       ({"common": {}}, {"model": {"in_channels": 4}}),                                      # model wants 4, dataset has 3
+                       ({"common": {"image_dirs": []}}, None)):
+        with pytest.raises(ValueError):
+            bands_from_config(bad, model)
+
+
+def test_class_count_limits_are_stated_once():
+    from robosat_amd.config import check_num_classes
+
+    for tool, ok, bad in (("train", (2, 8), (1, 9)), ("predict", (2, 5), (1, 6))):
+        for n in ok:
+            check_num_classes(n, tool)
+        for n in bad:
+            with pytest.raises(ValueError):
+                check_num_classes(n, tool)
+
+
+def test_tools_rebuild_their_command_line_from_the_namespace():
+    """The per-GPU relaunch must not replay the HOST program's sys.argv: the command line is rebuilt from the
+    namespace main() received, and parses back to it."""
+    import argparse
+
+    from robosat_amd.tools import predict, train
+
+    sub = argparse.ArgumentParser().add_subparsers()
+    train.add_parser(sub)
+    predict.add_parser(sub)
+    parser = sub._name_parser_map
+    ns = argparse.Namespace(model="m.toml", dataset="d.toml", checkpoint="c.pth", resume=True, workers=3)
+    argv = train.argv_from_args(ns)
+    back = parser["train"].parse_args(argv[1:])
+    assert argv[0] == "train" and (back.model, back.dataset, back.checkpoint, back.resume, back.workers) == ("m.toml", "d.toml", "c.pth", True, 3)
+    ns = argparse.Namespace(model="m.toml", dataset="d.toml", checkpoint=None, resume=False, workers=0)
+    back = parser["train"].parse_args(train.argv_from_args(ns)[1:])
+    assert back.checkpoint is None and back.resume is False
+    ns = argparse.Namespace(batch_size=4, checkpoint="c.pth", overlap=16, tile_size=256, workers=2, tiles="t", probs="p", model="m", dataset="d",
+                            extra_tiles=["ir"])
+    back = parser["predict"].parse_args(predict.argv_from_args(ns)[1:])
+    assert (back.tiles, back.probs, back.extra_tiles, back.batch_size, back.overlap) == ("t", "p", ["ir"], 4, 16)
+    ns.extra_tiles = []
+    back = parser["predict"].parse_args(predict.argv_from_args(ns)[1:])
+    assert back.extra_tiles == [] and back.tiles == "t"
+
+
+def test_nccl_needs_a_device_per_rank():
+    from robosat_amd.launch import check_ranks_fit_devices
+
+    check_ranks_fit_devices(2, 2, "nccl")
+    check_ranks_fit_devices(2, 1, "gloo")
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        check_ranks_fit_devices(2, 1, "nccl")

@@ -64,6 +64,7 @@ def parse():
                     help="predict phase only: skip the legs reported under \"legs\" (configs[4] 4-band 4-class bf16 train, fp32 "
                          "train bs 8, configs[3] 1024^2 predict)")
     ap.add_argument("--no-miou", action="store_true", help="skip the bf16-vs-fp32-oracle convergence check reported under \"miou\"")
+    ap.add_argument("--grad-dtype", choices=["fp32", "bf16"], default="fp32", help="what the gradient all-reduce puts on the wire (N > 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch / --train-batch tiles PER GPU (default); strong: they are the GLOBAL batch, split over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
@@ -272,7 +273,7 @@ class Leg:
             phase, dtype, batch, size, classes, channels, loss, tag)
 
 
-def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False):
+def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtype="fp32"):
     """Builds the model for `leg`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
     returns (max-over-ranks seconds, per-step milliseconds of this rank from HIP events between the steps, step function,
     a callable producing rank 0's parity record)."""
@@ -297,7 +298,8 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False):
             from robosat_amd import parallel
 
             parallel.broadcast_module(net)  # (the replicas are seeded identically; this is what `rs train` does)
-            net.grad_reducer = GradReducer()  # bucketed RCCL all-reduce overlapped with the backward kernels
+            # bucketed RCCL all-reduce overlapped with the backward kernels
+            net.grad_reducer = GradReducer(wire_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32)
 
         def step():
             opt.zero_grad()
@@ -363,6 +365,7 @@ def workload(leg, world, cfg=""):
             "classes": leg.classes,
             "parallelism": ("tiles sharded over {} rank(s), no collective" if not train else
                             "dp{}: replica per GPU, flat-arena RCCL all-reduce of 37.3M gradients per step").format(world)}
+
 
 
 def baseline_config(leg):
@@ -484,7 +487,7 @@ def main():
         return batch // world
 
     main_leg = Leg(args.phase, args.dtype, per_rank(args.batch), args.size, args.classes, args.channels, args.loss)
-    el, step_ms, step, parity = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity)
+    el, step_ms, step, parity = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity, args.grad_dtype)
     line = None
     # every rank runs the two untimed roofline passes: a train step contains the gradient all-reduce, so rank 0 alone
     # would wait for its peers forever
@@ -514,7 +517,7 @@ def main():
     if args.phase == "predict" and not args.no_train_leg:
         tleg = Leg("train", "bf16", per_rank(args.train_batch), args.size, args.classes, args.channels, args.loss)
         ts, tw = max(1, args.train_steps), max(3, min(args.warmup, 5))
-        tel, tstep_ms, tstep, tparity = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity)
+        tel, tstep_ms, tstep, tparity = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity, args.grad_dtype)
         troof, _ = roofline(tstep)
         if rank == 0:
             line["train"] = {"value": round(world * tleg.batch * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
@@ -532,7 +535,7 @@ def main():
                  ("train_fp32_bs8", Leg("train", "fp32", per_rank(8), 512, 2, 3, "Lovasz"), 5, 2),
                  ("cfg4_predict_fp32_1024_bs8", Leg("predict", "fp32", per_rank(8), 1024, 2, 3, "Lovasz"), 10, 2)]
         for name, leg, ls, lw in extra:
-            lel, lstep_ms, lstep, lparity = run_phase(leg, ls, lw, device, dist, rank, no_parity=True)
+            lel, lstep_ms, lstep, lparity = run_phase(leg, ls, lw, device, dist, rank, no_parity=True, grad_dtype=args.grad_dtype)
             if rank == 0:
                 line.setdefault("legs", {})[name] = {
                     "value": round(world * leg.batch * ls / lel, 2), "unit": "tiles/s", "steps": ls, "warmup": lw,

@@ -225,6 +225,11 @@ int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, const rs_bf16
 /* fp32 master weights -> bf16 compute copies: plain cast (KRSC stays KRSC), and the data-gradient packing of
  * rs_pack_dgrad_weight with a bf16 result. */
 int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stream);
+/* dst = (float)src * scale.  The gradient exchange of robosat/tools/train.py:69 (DataParallel's reduce-add of 149.4 MB
+ * fp32 onto device 0) done in bf16 on the wire (`[model] grad_dtype = "bf16"`, 74.7 MB): the bucket is cast with
+ * rs_cast_f32_to_bf16, summed by RCCL, and comes back through this call with scale = 1 / world into the fp32 arena the
+ * optimizer reads.  src / dst 16-byte aligned. */
+int rs_cast_bf16_to_f32_scaled(const rs_bf16* src, float* dst, long n, float scale, rs_stream_t stream);
 int rs_pack_dgrad_weight_bf16(const float* w_krsc, rs_bf16* out, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
 
 /* The 7x7/2 stem (resnet.conv1, unet.py:122) in bf16: x NHWC4 bf16 [N][H][W][4] (rs_nchw_to_nhwc4_bf16), weights packed

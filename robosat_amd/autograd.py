@@ -44,6 +44,10 @@ class GradArena:
     data-parallel reducer (``robosat_amd.parallel.GradReducer``), which sums it over RCCL while the rest of the
     backward keeps computing -- no flatten/unflatten copies, no per-tensor collectives."""
 
+    # measurement hook (tests/dp_worker.py): a list -> every arena appends (start, main_done) timing events, recorded on the
+    # main stream when the backward starts and right before the one join with the side stream at its end
+    TRACE = None
+
     def __init__(self, params, device, reducer=None):
         # sized for the parameters that receive a gradient: `params` excludes resnet.fc (never used by UNet.forward).
         # Slices are 16-byte aligned; with a reducer the <= 3 floats of padding between them travel over the wire, so the
@@ -57,6 +61,10 @@ class GradArena:
         self.sent = 0
         self.reducer = reducer
         self.grads = {}
+        self._t0 = None
+        if GradArena.TRACE is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(torch.cuda.current_stream(device))
 
     def take(self, param, shape):
         """Next 16-byte aligned slice, shaped ``shape`` (the kernel's layout, e.g. KRSC), registered for ``param``."""
@@ -95,16 +103,35 @@ class GradArena:
         torch.cuda.current_stream().wait_stream(self.side)
 
     def flush(self):
+        """Hand the range completed since the last flush to the reducer -- ordered after the SIDE stream.
+
+        A bucket is complete when (a) the side stream has finished its weight gradients and (b) the main stream has written
+        its BatchNorm / bias gradients: the side stream is made to wait for an event recorded on the main stream now (b), it
+        is itself the stream the weight gradients run on (a), and the collective is issued with the side stream current, so
+        RCCL's communicator stream waits for exactly that.  The main stream -- the backward's critical path -- neither
+        waits for the side stream (which trails it by milliseconds) nor for the wire: it goes on with the next layer's data
+        gradient.  (Round 2 joined the side stream into the main stream at each of the five flushes.)"""
+
         if self.reducer is not None and self.off > self.sent:
-            self.join()  # the bucket's weight gradients are complete
-            self.reducer.reduce_async(self.flat[self.sent:self.off])
+            main = torch.cuda.current_stream()
+            if self.side != main:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self.reducer.reduce_async(self.flat[self.sent:self.off])
             self.sent = self.off
 
     def finish(self):
-        self.join()
         self.flush()
         if self.reducer is not None:
-            self.reducer.wait()
+            with torch.cuda.stream(self.side):
+                self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)
+        if self._t0 is not None:
+            done = torch.cuda.Event(enable_timing=True)
+            done.record(torch.cuda.current_stream())
+            GradArena.TRACE.append((self._t0, done))
+        self.join()  # once per step: the optimizer (main stream) needs every gradient
 
 
 class _Tape:

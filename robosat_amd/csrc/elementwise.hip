@@ -289,7 +289,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 
 }  // namespace
 
-extern "C" int rs_abi_version(void) { return 15; }
+extern "C" int rs_abi_version(void) { return 16; }
 
 extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
@@ -314,6 +314,32 @@ extern "C" int rs_maxpool2d_fwd_dt(const void* x, int x_dtype, void* y, int y_dt
 extern "C" int rs_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride,
                                 int pad, int Ho, int Wo, rs_stream_t stream) {
   return rs_maxpool2d_fwd_dt(x, RS_F32, y, RS_F32, argmax, N, H, W, C, k, stride, pad, Ho, Wo, stream);
+}
+
+// dst = (float)src * scale: the way back from a bf16 gradient exchange (the all-reduced SUM of the ranks' bf16 gradient
+// copies -> their fp32 mean in the optimizer's arena), 8 elements per thread.
+__global__ void cast_bf16_f32_scaled_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n, float scale) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i);
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (float)v[e] * scale;
+      b[e] = (float)v[4 + e] * scale;
+    }
+    *reinterpret_cast<f32x4*>(dst + i) = a;
+    *reinterpret_cast<f32x4*>(dst + i + 4) = b;
+  } else {
+    for (long j = i; j < n; ++j) dst[j] = (float)src[j] * scale;
+  }
+}
+
+extern "C" int rs_cast_bf16_to_f32_scaled(const rs_bf16* src, float* dst, long n, float scale, rs_stream_t stream) {
+  if (!src || !dst || n <= 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return RS_EINVAL;
+  cast_bf16_f32_scaled_kernel<<<rs_cdiv(rs_cdiv(n, 8), 256), 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const bf16_t*>(src), dst, n, scale);
+  return RS_LAUNCH_RESULT();
 }
 
 extern "C" int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stream) {

@@ -372,6 +372,15 @@ def cast_bf16(t):
     return out
 
 
+def cast_f32_scaled(src_bf16, dst_f32, scale):
+    """dst (fp32, in place) = float(src bf16) * scale: the way back from a bf16 gradient exchange (``GradReducer``)."""
+
+    assert src_bf16.numel() == dst_f32.numel()
+    check(_lib.lib().rs_cast_bf16_to_f32_scaled(_dev(src_bf16, "src", BF16), _dev(dst_f32, "dst"), src_bf16.numel(),
+                                                 ctypes.c_float(scale), _stream()), "rs_cast_bf16_to_f32_scaled")
+    return dst_f32
+
+
 class _WPrepItem(ctypes.Structure):  # rs_wprep_item (include/robosat_hip.h)
     _fields_ = [("w", ctypes.c_void_p), ("cast", ctypes.c_void_p), ("dgrad", ctypes.c_void_p), ("Cout", ctypes.c_int),
                 ("taps", ctypes.c_int), ("Cin", ctypes.c_int), ("tile_begin", ctypes.c_int)]

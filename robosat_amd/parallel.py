@@ -67,31 +67,56 @@ def _broadcast_flat(tensors, src):
 
 
 class GradReducer:
-    """Averages ranges of the flat gradient arena across ranks, asynchronously."""
+    """Averages ranges of the flat gradient arena across ranks, asynchronously.
 
-    def __init__(self, group=None):
+    ``reduce_async`` is called with the stream the collective should be ordered after as torch's CURRENT stream
+    (``ProcessGroupNCCL`` makes its communicator stream wait for the current stream, runs the collective there and returns):
+    ``GradArena.flush`` calls it under the weight-gradient side stream, so a bucket's exchange starts when that stream has
+    finished the bucket's last weight gradient -- the backward's main stream (data gradients, BatchNorm) is never made to
+    wait for the side stream or for the wire.  ``wait`` -- called once, at the end of the backward --
+    makes the current stream wait for every pending collective.
+
+    ``wire_dtype=torch.bfloat16`` (``[model] grad_dtype = "bf16"``): the bucket travels as bf16 (74.7 MB per step instead of
+    149.4 MB): cast on the device (``rs_cast_f32_to_bf16``), summed by RCCL, and converted back into the fp32 arena with the
+    1/world scale (``rs_cast_bf16_to_f32_scaled``) -- the optimizer still reads fp32 gradients, local accumulation (the
+    weight-gradient kernels) stays fp32; what is rounded is each rank's contribution to the sum and the partial sums on the
+    ring.  Default: fp32 on the wire, bit-identical replicas, the reference's arithmetic."""
+
+    def __init__(self, group=None, wire_dtype=torch.float32):
         self.group = group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        if wire_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("GradReducer: gradients travel as fp32 or bf16")
+        self.wire_dtype = wire_dtype
         self._pending = []
 
     def reduce_async(self, flat):
-        """Enqueue an in-place average of ``flat`` (a contiguous 1-D view).  With the RCCL backend the collective runs
-        on the communicator's own stream after the kernels enqueued so far and overlaps with later compute."""
+        """Enqueue an in-place average of ``flat`` (a contiguous 1-D fp32 view), ordered after torch's current stream."""
 
         if self.world == 1:
             return
-        if self.backend == "nccl":
+        if self.wire_dtype == torch.bfloat16 and flat.is_cuda:
+            from . import ops
+
+            wire = ops.cast_bf16(flat)
+            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((work, flat, wire))
+        elif self.backend == "nccl":
             work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            self._pending.append((work, None))
-        else:  # gloo (CPU tests): no AVG
+            self._pending.append((work, None, None))
+        else:  # gloo (CPU tests, two ranks on one GPU): no AVG
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((work, flat))
+            self._pending.append((work, flat, None))
 
     def wait(self):
-        for work, flat in self._pending:
-            work.wait()
-            if flat is not None:
+        for work, flat, wire in self._pending:
+            work.wait()  # (device tensors: the CURRENT stream waits for the collective; the host does not block on RCCL)
+            if wire is not None:
+                from . import ops
+
+                ops.cast_f32_scaled(wire, flat, 1.0 / self.world)
+            elif flat is not None:
                 flat.div_(self.world)
         self._pending = []
 

@@ -135,7 +135,12 @@ def main(args):
     pretrained = False if (args.checkpoint or not pretrained) else "require"
     net = Replica(UNet(num_classes, pretrained=pretrained, compute_dtype=compute_dtype, in_channels=in_channels)).to(device)
     if world > 1:
-        net.module.grad_reducer = parallel.GradReducer()
+        # [model] grad_dtype = "bf16" (extension key): the gradient exchange travels as bf16 (74.7 MB per step instead of
+        # 149.4 MB); default fp32 = the reference's arithmetic, bit-identical replicas
+        grad_dtype = model.get("model", {}).get("grad_dtype", "fp32")
+        if grad_dtype not in ("fp32", "bf16"):
+            sys.exit("Error: [model] grad_dtype must be \"fp32\" or \"bf16\"")
+        net.module.grad_reducer = parallel.GradReducer(wire_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32)
 
     try:
         weight = torch.Tensor(dataset["weights"]["values"])

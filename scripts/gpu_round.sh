@@ -11,19 +11,28 @@
 TAG=$1; shift
 export TMPDIR=/tmp
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
-B="python $REPO/bench.py --no-cpu-baseline"
+B="python $REPO/bench.py --no-cpu-baseline --no-extra-legs --no-miou"
 for STAGE in "$@"; do
   echo "=== stage $STAGE ($(date +%T))"
   case $STAGE in
   tests)
-    timeout 2400 python -m pytest tests -m gpu -q --maxfail 20 --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/pytest_gpu.log ;;
+    # -rP: the captured stdout of PASSING tests too (worst / mean gradient cosines, full-size Lovasz errors, mIoU pairs)
+    timeout 2400 python -m pytest tests -m gpu -q -rP --maxfail 20 --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/pytest_gpu.log
+    grep -E "cosine|Lovasz kernel|mIoU after|main-stream|cfg[0-9] " $OUT/pytest_gpu.log | head -40 ;;
   smoke)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   bench)
-    timeout 900 python bench.py --layers-json $OUT/layers_predict.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
-    tail -1 $OUT/bench_default.log > $OUT/bench_default.json; cut -c1-700 $OUT/bench_default.json
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers-json $OUT/layers_predict.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
+    tail -1 $OUT/bench_default.log > $OUT/bench_default.json; python scripts/bench_brief.py $OUT/bench_default.json
     timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --layers-json $OUT/layers_train.json > $OUT/bench_train.log 2>&1; echo "train bench exit $?"
     tail -1 $OUT/bench_train.log > $OUT/bench_train_bf16_bs32.json; cut -c1-500 $OUT/bench_train_bf16_bs32.json ;;
+  smi)
+    # does a concurrent SMU poller (what the driver runs beside its bench: one sample every 5 s) move the train leg?  Same
+    # command with a much denser poller (every 0.5 s) beside it; compare train.step_ms min / median / max with `bench`.
+    ( while true; do rocm-smi --showuse --showmemuse --json > /dev/null 2>&1; sleep 0.5; done ) & SMI=$!
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra-legs --no-miou --no-cpu-baseline > $OUT/bench_with_smi.log 2>&1; echo "bench exit $?"
+    kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
+    tail -1 $OUT/bench_with_smi.log > $OUT/bench_with_smi.json; python scripts/bench_brief.py $OUT/bench_with_smi.json ;;
   trace)
     cd /tmp
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_predict -o p -- $B --no-train-leg --steps 5 --warmup 2 > $OUT/trace_predict.log 2>&1; echo "exit $?"

@@ -73,6 +73,8 @@ def gpu_unet(rank, world, dtype):
     dist.all_reduce(want, op=dist.ReduceOp.SUM)
     want /= world
     got, loss_dp = grads(parallel.GradReducer())
+    wire, _ = grads(parallel.GradReducer(wire_dtype=torch.bfloat16))  # `[model] grad_dtype = "bf16"`: half the bytes on the wire
+    wire_err = float((wire - want).norm() / want.norm())
     peers = [torch.zeros_like(got) for _ in range(world)]
     dist.all_gather(peers, got)
     err = float((got - want).abs().max() / want.abs().max())
@@ -92,7 +94,32 @@ def gpu_unet(rank, world, dtype):
         dist.broadcast(ref, src=0)
         drift = max(drift, float((v.float() - ref.float()).abs().max()))
     fc_grad = net.resnet.fc.weight.grad is None
-    return {"grad_rel_err": err, "local_vs_mean": differs, "peer_equal": bool(all(torch.equal(p, got) for p in peers)),
+
+    # the exchange must not put the wire (or the weight-gradient stream) on the backward's critical path: time from the start
+    # of the backward to the main stream's last kernel before its ONE join with the side stream, with and without a reducer
+    from robosat_amd.autograd import GradArena
+
+    xb = torch.randn(4, 3, 256, 256, generator=g).to(dev)
+    tb = torch.randint(0, 2, (4, 256, 256), generator=g).to(dev)
+
+    def main_stream_ms(reducer):
+        net.grad_reducer = reducer
+        best = float("inf")
+        for i in range(4):
+            for p in net.parameters():
+                p.grad = None
+            GradArena.TRACE = []
+            crit(net(xb), tb).backward()
+            torch.cuda.synchronize()
+            (t0, t1), = GradArena.TRACE
+            if i:
+                best = min(best, t0.elapsed_time(t1))
+        GradArena.TRACE = None
+        dist.barrier()
+        return best
+
+    ms_plain, ms_dp = main_stream_ms(None), main_stream_ms(parallel.GradReducer())
+    return {"wire_bf16_rel_err": wire_err, "main_stream_ms": [ms_plain, ms_dp], "grad_rel_err": err, "local_vs_mean": differs, "peer_equal": bool(all(torch.equal(p, got) for p in peers)),
             "replica_drift": drift, "fc_has_no_grad": bool(fc_grad), "loss_local": loss_local, "loss_dp": loss_dp}
 
 

@@ -33,6 +33,13 @@ def test_two_rank_train_step_averages_gradients_and_keeps_replicas_identical(tmp
         assert r["peer_equal"]
         assert r["replica_drift"] == 0.0, r
         assert r["fc_has_no_grad"]
+        # bf16 on the wire: each rank's contribution is rounded to 8 mantissa bits before the sum
+        assert r["wire_bf16_rel_err"] <= 8e-3, r
+        # the collectives are ordered after the weight-gradient stream, not joined into the main stream: the backward's main
+        # stream takes as long with a reducer as without (5 % + 0.3 ms of slack for the extra event records)
+        plain, dp = r["main_stream_ms"]
+        print(mode, "main-stream backward ms without / with the reducer:", plain, dp)
+        assert dp <= 1.05 * plain + 0.3, r
     assert res[0]["loss_local"] != res[1]["loss_local"]
 
 

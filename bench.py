@@ -275,8 +275,8 @@ class Leg:
 
 def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtype="fp32"):
     """Builds the model for `leg`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
-    returns (max-over-ranks seconds, per-step milliseconds of this rank from HIP events between the steps, step function,
-    a callable producing rank 0's parity record)."""
+    returns (max-over-ranks seconds, per-step milliseconds of this rank from HIP events between the steps, the EAGER step
+    function, a callable producing rank 0's parity record, whether the timed steps were hipGraph replays)."""
 
     import torch.distributed as td
 
@@ -293,7 +293,10 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
         crit = {"CrossEntropy": lambda: losses.CrossEntropyLoss2d(weight=torch.ones(leg.classes)),
                 "Focal": lambda: losses.FocalLoss2d(weight=torch.ones(leg.classes)),
                 "Lovasz": lambda: losses.LovaszLoss2d()}[leg.loss]().to(device)
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)  # (as `rs train` builds it on a GPU)
+        # as `rs train` builds it on a GPU: fused, and capturable when the step is replayed as a hipGraph (one rank; see below)
+        # (needs 3 untimed calls: two eager steps, then the call that captures -- a capture inside the timed region is not a step)
+        graphed = not dist and warmup >= 3 and os.environ.get("ROBOSAT_TRAIN_GRAPH", "1") != "0"
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True, capturable=graphed)
         if dist:
             from robosat_amd import parallel
 
@@ -301,15 +304,29 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
             # bucketed RCCL all-reduce overlapped with the backward kernels
             net.grad_reducer = GradReducer(wire_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32)
 
-        def step():
+        def step():  # the eager step (what the roofline pass brackets launch by launch)
             opt.zero_grad()
             loss = crit(net(x), tgt)
             loss.backward()
             opt.step()
             return loss
+
+        timed = step
+        if graphed:
+            # what `rs train` runs (robosat_amd.graph.TrainStepGraph): two eager steps, then the whole step -- zero_grad,
+            # forward, loss, backward, Adam -- is ONE hipGraph replay per batch (the batch is copied into the graph's static
+            # input first, as the tool does with every new batch; that copy is inside the timed step)
+            from robosat_amd.graph import TrainStepGraph
+
+            stepper = TrainStepGraph(net, crit, opt)
+
+            def timed():
+                return stepper(x, tgt)[0]
     else:
         def step():
             return net.predict_probs(x)
+
+        timed = step
 
     def barrier():
         torch.cuda.synchronize()
@@ -318,14 +335,14 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        step()
+        timed()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # (recorded on the stream; no host sync)
     barrier()
     t0 = time.perf_counter()
     last = None
     marks[0].record()
     for i in range(steps):
-        last = step()
+        last = timed()
         marks[i + 1].record()
     barrier()
     el = time.perf_counter() - t0
@@ -343,7 +360,7 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
             rec["train_loss_last_step"] = float(last)
         return rec
 
-    return el, step_ms, step, parity
+    return el, step_ms, step, parity, bool(train and graphed and stepper.captured)
 
 
 def step_stats(step_ms):
@@ -487,7 +504,7 @@ def main():
         return batch // world
 
     main_leg = Leg(args.phase, args.dtype, per_rank(args.batch), args.size, args.classes, args.channels, args.loss)
-    el, step_ms, step, parity = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity, args.grad_dtype)
+    el, step_ms, step, parity, hipgraph = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity, args.grad_dtype)
     line = None
     # every rank runs the two untimed roofline passes: a train step contains the gradient all-reduce, so rank 0 alone
     # would wait for its peers forever
@@ -500,6 +517,7 @@ def main():
             "metric": "512x512 tiles/sec train+predict, 1/2/4/8 MI355X; mIoU vs CPU ref",
             "value": round(world * main_leg.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(step_ms),
+            "hipgraph": hipgraph,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": workload(main_leg, world, baseline_config(main_leg)),
@@ -517,11 +535,12 @@ def main():
     if args.phase == "predict" and not args.no_train_leg:
         tleg = Leg("train", "bf16", per_rank(args.train_batch), args.size, args.classes, args.channels, args.loss)
         ts, tw = max(1, args.train_steps), max(3, min(args.warmup, 5))
-        tel, tstep_ms, tstep, tparity = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity, args.grad_dtype)
+        tel, tstep_ms, tstep, tparity, tgraph = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity, args.grad_dtype)
         troof, _ = roofline(tstep)
         if rank == 0:
             line["train"] = {"value": round(world * tleg.batch * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
                              "ms_per_step": round(tel / ts * 1e3, 3), "step_ms": step_stats(tstep_ms), "dtype": "bf16",
+                             "hipgraph": tgraph,
                              "scaling": args.scaling, "config": workload(tleg, world, baseline_config(tleg)),
                              "roofline": troof, "parity": tparity()}
         del tstep
@@ -532,14 +551,15 @@ def main():
     # (fp32, bs 8) and configs[3] (1024^2 tiles, bs 8, fp32 predict).
     if args.phase == "predict" and not args.no_extra_legs and args.size == 512:
         extra = [("cfg5_train_bf16_4band_4class", Leg("train", "bf16", per_rank(32), 512, 4, 4, "Lovasz"), 10, 3),
-                 ("train_fp32_bs8", Leg("train", "fp32", per_rank(8), 512, 2, 3, "Lovasz"), 5, 2),
+                 ("train_fp32_bs8", Leg("train", "fp32", per_rank(8), 512, 2, 3, "Lovasz"), 5, 3),
                  ("cfg4_predict_fp32_1024_bs8", Leg("predict", "fp32", per_rank(8), 1024, 2, 3, "Lovasz"), 10, 2)]
         for name, leg, ls, lw in extra:
-            lel, lstep_ms, lstep, lparity = run_phase(leg, ls, lw, device, dist, rank, no_parity=True, grad_dtype=args.grad_dtype)
+            lel, lstep_ms, lstep, lparity, lgraph = run_phase(leg, ls, lw, device, dist, rank, no_parity=True, grad_dtype=args.grad_dtype)
             if rank == 0:
                 line.setdefault("legs", {})[name] = {
                     "value": round(world * leg.batch * ls / lel, 2), "unit": "tiles/s", "steps": ls, "warmup": lw,
                     "ms_per_step": round(lel / ls * 1e3, 3), "step_ms": step_stats(lstep_ms), "dtype": leg.dtype,
+                    "hipgraph": lgraph,
                     "config": workload(leg, world, baseline_config(leg))}
             del lstep
             torch.cuda.empty_cache()

@@ -124,13 +124,13 @@ class GradArena:
 
     def finish(self):
         self.flush()
-        if self.reducer is not None:
-            with torch.cuda.stream(self.side):
-                self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)
-        if self._t0 is not None:
+        if self._t0 is not None:  # (before the waits below: gloo's wait blocks the HOST, which would delay this record)
             done = torch.cuda.Event(enable_timing=True)
             done.record(torch.cuda.current_stream())
             GradArena.TRACE.append((self._t0, done))
+        if self.reducer is not None:
+            with torch.cuda.stream(self.side):
+                self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)
         self.join()  # once per step: the optimizer (main stream) needs every gradient
 
 

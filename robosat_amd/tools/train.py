@@ -151,7 +151,10 @@ def main(args):
 
     # same optimiser, same defaults as the reference (train.py:81); on the GPU as torch's single-pass fused kernels (the
     # default multi-tensor form is 19 launches that re-read p, g, m, v several times: 0.4 ms of a 25 ms step)
-    optimizer = Adam(net.parameters(), lr=model["opt"]["lr"], fused=device.type == "cuda")
+    # `[model] graph` (extension key, default true): the training step is captured into one hipGraph after two eager batches
+    # (robosat_amd.graph) -- which needs the optimizer's step counters on the device (`capturable`)
+    use_graph = bool(model.get("model", {}).get("graph", True)) and world == 1
+    optimizer = Adam(net.parameters(), lr=model["opt"]["lr"], fused=device.type == "cuda", capturable=use_graph)
 
     resume = 0
     if args.checkpoint:
@@ -191,6 +194,9 @@ def main(args):
     if resume >= num_epochs:
         sys.exit("Error: Epoch {} set in {} already reached by the checkpoint provided".format(num_epochs, args.model))
 
+    from robosat_amd.graph import TrainStepGraph
+
+    stepper = TrainStepGraph(net, criterion, optimizer, enabled=use_graph)
     history = collections.defaultdict(list)
     log = Log(os.path.join(model["common"]["checkpoint"], "log"), out=sys.stdout if master else None) if master else None
 
@@ -214,7 +220,7 @@ def main(args):
         say("Epoch: {}/{}".format(epoch + 1, num_epochs))
         train_loader.batch_sampler.set_epoch(epoch)
 
-        train_hist = train(train_loader, num_classes, device, net, optimizer, criterion, master)
+        train_hist = train(train_loader, num_classes, device, net, optimizer, criterion, master, stepper=stepper)
         say(fmt.format("Train   ", train_hist["loss"], train_hist["miou"], fg, train_hist["fg_iou"], train_hist["mcc"]))
         for k, v in train_hist.items():
             history["train " + k].append(v)
@@ -251,7 +257,7 @@ def _portable_optimizer_state(optimizer):
     return state
 
 
-def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, desc="Train"):
+def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, desc="Train", stepper=None):
     training = optimizer is not None
     num_samples = 0
     running_loss = torch.zeros((), device=device, dtype=torch.float64)
@@ -267,17 +273,21 @@ def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, 
         assert images.size()[2:] == masks.size()[1:], "resolutions for images and masks are in sync"
         num_samples += int(images.size(0))
 
-        if training:
-            optimizer.zero_grad()
-        outputs = net(images)
+        if training and stepper is not None:
+            # zero_grad / forward / loss / backward / optimizer.step (tools/train.py:180-188) as one hipGraph replay once the
+            # first batches have run eagerly; loss and outputs are then the graph's static tensors, consumed right below
+            loss, outputs = stepper(images, masks)
+        else:
+            if training:
+                optimizer.zero_grad()
+            outputs = net(images)
+            loss = criterion(outputs, masks)
+            if training:
+                loss.backward()
+                optimizer.step()
 
         assert outputs.size()[2:] == masks.size()[1:], "resolutions for predictions and masks are in sync"
         assert outputs.size()[1] == num_classes, "classes for predictions and dataset are in sync"
-
-        loss = criterion(outputs, masks)
-        if training:
-            loss.backward()
-            optimizer.step()
 
         running_loss += loss.detach()  # stays on the device: no per-step host sync
         metrics.add_batch(masks, outputs.detach())
@@ -298,8 +308,8 @@ def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, 
     }
 
 
-def train(loader, num_classes, device, net, optimizer, criterion, master=True):
-    return _epoch(loader, num_classes, device, net, criterion, master, optimizer=optimizer, desc="Train")
+def train(loader, num_classes, device, net, optimizer, criterion, master=True, stepper=None):
+    return _epoch(loader, num_classes, device, net, criterion, master, optimizer=optimizer, desc="Train", stepper=stepper)
 
 
 @torch.no_grad()

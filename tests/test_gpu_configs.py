@@ -209,10 +209,12 @@ def test_cfg5_train_bs32_512_bf16_four_band_four_class_step_vs_oracle():
     got_in = logits.detach()[:2].clone().requires_grad_(True)
     got = crit(got_in, t[:2].to(DEV))
     got.backward()
-    print("cfg5 Lovasz kernel on 2 x 1M keys: loss", got.item(), "oracle", want.item(),
-          "max |dgrad|", float((got_in.grad.cpu() - sub.grad).abs().max()), "of", float(sub.grad.abs().max()))
     assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item()))
-    assert float((got_in.grad.cpu() - sub.grad).abs().max()) <= 2e-3 * float(sub.grad.abs().max())
+    from lovasz_check import assert_lovasz_grad_close  # (per group of equal errors: the reference's sort is not stable)
+
+    rel = assert_lovasz_grad_close(sub.detach(), t[:2], got_in.grad.cpu(), sub.grad, 2e-3)
+    print("cfg5 Lovasz kernel on 2 x 1M keys: loss", got.item(), "oracle", want.item(), "gradient max err over tie groups",
+          "{:.2e} of the largest entry".format(rel))
 
     cos = {}
     for name, p in net.named_parameters():

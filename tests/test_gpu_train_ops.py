@@ -277,8 +277,14 @@ def test_lovasz_vs_oracle(n, c, h, w):
     got = losses.LovaszLoss2d()(got_in, targets.to(DEV))
     got.backward()
     assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (got.item(), want.item())
-    # the Jaccard deltas are differences of nearly equal fp32 numbers: 1 ulp of jac (3e-8) is ~4e-4 of a delta
-    close(got_in.grad.cpu(), ref_in.grad, 2e-3, "lovasz grad")
+    # Equal errors may be sorted in any order (torch's CPU sort is not stable at the large sizes): gradients are compared per
+    # group of equal errors -- elementwise wherever an error is unique -- see tests/lovasz_check.py.  The Jaccard deltas are
+    # differences of nearly equal fp32 numbers: 1 ulp of jac (3e-8) is ~4e-4 of a delta at 32k keys.
+    from lovasz_check import assert_lovasz_grad_close
+
+    rel = assert_lovasz_grad_close(logits, targets, got_in.grad.cpu(), ref_in.grad, 2e-3)
+    print("lovasz {}: loss {} oracle {}, gradient max err over tie groups {:.2e} of the largest entry".format(
+        (n, c, h, w), got.item(), want.item(), rel))
 
 
 def test_metrics_match_reference_golden(golden_dir):

@@ -107,3 +107,52 @@ def test_optimizer_updates_that_bypass_version_counters_are_seen(dtype):
     assert runs[True][0] == pytest.approx(runs[False][0], rel=1e-5)
     for a, b in zip(runs[True], runs[False]):  # later losses see the updates: a stale weight copy shows here
         assert a == pytest.approx(b, rel=2e-2 if dtype == "bf16" else 2e-3)
+
+
+@pytest.mark.parametrize("dtype,loss_name", [("bf16", "Lovasz"), ("fp32", "CrossEntropy")])
+def test_graphed_train_step_is_the_eager_step(dtype, loss_name):
+    """The hipGraph replay of the training step (robosat_amd.graph.TrainStepGraph: what `rs train` and the bench's train legs
+    run) launches the very kernels of the eager step in the same order on the same two streams: six steps over changing
+    batches give bit-identical losses, logits, parameters, BatchNorm buffers and Adam state either way -- and a batch of
+    another shape in the middle falls back to the eager step without disturbing the graph."""
+    from robosat_amd import losses
+    from robosat_amd.graph import TrainStepGraph
+    from robosat_amd.unet import UNet
+
+    init = seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 9)
+    batches = [(seeded.synthetic_images(2, 3, 96, 128, 40 + i).to(DEV), seeded.synthetic_targets(2, 2, 96, 128, 40 + i).to(DEV))
+               for i in range(6)]
+    odd = (seeded.synthetic_images(1, 3, 64, 64, 77).to(DEV), seeded.synthetic_targets(1, 2, 64, 64, 77).to(DEV))
+    order = batches[:4] + [odd] + batches[4:]
+    runs = {}
+    for graphed in (False, True):
+        net = UNet(2, pretrained=False, compute_dtype=dtype)
+        net.load_state_dict(init)
+        net = net.to(DEV).train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)
+        crit = (losses.LovaszLoss2d() if loss_name == "Lovasz" else losses.CrossEntropyLoss2d(weight=torch.tensor([1.0, 3.0]))).to(DEV)
+        stepper = TrainStepGraph(net, crit, opt, warmup=2, enabled=graphed)
+        ls, outs = [], []
+        for i, (x, t) in enumerate(order):
+            loss, logits = stepper(x, t)
+            ls.append(loss.clone())  # (the graph's static outputs are overwritten by the next replay)
+            outs.append(logits.clone())
+            assert stepper.captured == (graphed and i >= 2), (graphed, i)
+        torch.cuda.synchronize()
+        net.eval()
+        runs[graphed] = {"loss": torch.stack(ls).cpu(), "outs": [o.cpu() for o in outs], "probs": net.predict_probs(batches[0][0]).cpu(),
+                         "state": {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
+                         "adam": [st["exp_avg_sq"].detach().cpu().clone() for st in opt.state.values()],
+                         "steps": {float(st["step"]) for st in opt.state.values()}}
+    a, b = runs[False], runs[True]
+    print(dtype, "losses eager", a["loss"].tolist(), "graphed", b["loss"].tolist())
+    assert torch.equal(a["loss"], b["loss"])
+    for x, y in zip(a["outs"], b["outs"]):
+        assert torch.equal(x, y)
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), k
+    for x, y in zip(a["adam"], b["adam"]):
+        assert torch.equal(x, y)
+    assert a["steps"] == b["steps"] == {7.0}
+    assert torch.equal(a["probs"], b["probs"])  # eval after graph replays reads the CURRENT weights (derived caches dropped)
+    assert int(b["state"]["resnet.bn1.num_batches_tracked"]) == 7

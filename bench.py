@@ -295,7 +295,9 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
                 "Lovasz": lambda: losses.LovaszLoss2d()}[leg.loss]().to(device)
         # as `rs train` builds it on a GPU: fused, and capturable when the step is replayed as a hipGraph (one rank; see below)
         # (needs 3 untimed calls: two eager steps, then the call that captures -- a capture inside the timed region is not a step)
-        graphed = not dist and warmup >= 3 and os.environ.get("ROBOSAT_TRAIN_GRAPH", "1") != "0"
+        # Opt-in (ROBOSAT_TRAIN_GRAPH=1 here, `[model] graph = true` in rs train): replayed, the step measures 24.7 ms against
+        # 23.5 ms eager (profiles/r03/host_sensitivity.txt) -- the graph executor serialises the weight-gradient branch.
+        graphed = not dist and warmup >= 3 and os.environ.get("ROBOSAT_TRAIN_GRAPH", "0") == "1"
         opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True, capturable=graphed)
         if dist:
             from robosat_amd import parallel

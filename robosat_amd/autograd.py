@@ -44,8 +44,10 @@ class GradArena:
     data-parallel reducer (``robosat_amd.parallel.GradReducer``), which sums it over RCCL while the rest of the
     backward keeps computing -- no flatten/unflatten copies, no per-tensor collectives."""
 
-    # measurement hook (tests/dp_worker.py): a list -> every arena appends (start, main_done) timing events, recorded on the
-    # main stream when the backward starts and right before the one join with the side stream at its end
+    # measurement hook (tests/dp_worker.py): a list -> every arena appends a dict: `events` = (start, main_done) timing events
+    # recorded on the main stream when the backward starts and right before its one join with the side stream at the end;
+    # `joins` = how often the main stream was made to wait for the side stream; `flushes` = per bucket, whether the collective
+    # was issued with the side stream current (i.e. ordered after it, not after the main stream)
     TRACE = None
 
     def __init__(self, params, device, reducer=None):
@@ -61,7 +63,7 @@ class GradArena:
         self.sent = 0
         self.reducer = reducer
         self.grads = {}
-        self._t0 = None
+        self._t0, self.joins, self.flushes = None, 0, []
         if GradArena.TRACE is not None:
             self._t0 = torch.cuda.Event(enable_timing=True)
             self._t0.record(torch.cuda.current_stream(device))
@@ -100,6 +102,7 @@ class GradArena:
                 t.record_stream(self.side)  # the caching allocator must not recycle them under the side stream
 
     def join(self):
+        self.joins += 1
         torch.cuda.current_stream().wait_stream(self.side)
 
     def flush(self):
@@ -119,6 +122,7 @@ class GradArena:
                 ev.record(main)
                 self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
+                self.flushes.append(torch.cuda.current_stream() == self.side)
                 self.reducer.reduce_async(self.flat[self.sent:self.off])
             self.sent = self.off
 
@@ -127,7 +131,7 @@ class GradArena:
         if self._t0 is not None:  # (before the waits below: gloo's wait blocks the HOST, which would delay this record)
             done = torch.cuda.Event(enable_timing=True)
             done.record(torch.cuda.current_stream())
-            GradArena.TRACE.append((self._t0, done))
+            GradArena.TRACE.append({"events": (self._t0, done), "joins": self.joins, "flushes": list(self.flushes)})
         if self.reducer is not None:
             with torch.cuda.stream(self.side):
                 self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)

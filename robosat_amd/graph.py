@@ -12,6 +12,12 @@ single launch per batch.  The first ``warmup`` batches run eagerly (they are rea
 optimizer state, the workspaces and the weight-prep tables); the capture itself executes nothing, the first replay is the
 next real step.  Same kernels, same order, same numbers as the eager step (tests/test_gpu_train_step.py).
 
+Measured (one MI355X, bs 32 / 512^2 bf16, profiles/r03/host_sensitivity.txt): 24.7 ms per replayed step against 23.5 ms
+eager -- ROCm's graph executor runs the forked weight-gradient branch BEHIND the main branch (the replay takes what the
+eager step takes with the side stream switched off, 24.8 ms, minus the launch gaps), while the eager step overlaps the two.
+The eager step stays GPU-bound with the host thread on half a core (23.7 ms), so the graph is the option for hosts slower
+than that (`[model] graph = true`, ROBOSAT_TRAIN_GRAPH=1 for the bench), not the default.
+
 Not captured: steps with a gradient reducer (the RCCL exchange of ``robosat_amd.parallel`` has never run on hardware; it
 stays eager until it has), batches of another shape (they run eagerly), optimizers that are not capturable.
 """

@@ -151,9 +151,12 @@ def main(args):
 
     # same optimiser, same defaults as the reference (train.py:81); on the GPU as torch's single-pass fused kernels (the
     # default multi-tensor form is 19 launches that re-read p, g, m, v several times: 0.4 ms of a 25 ms step)
-    # `[model] graph` (extension key, default true): the training step is captured into one hipGraph after two eager batches
-    # (robosat_amd.graph) -- which needs the optimizer's step counters on the device (`capturable`)
-    use_graph = bool(model.get("model", {}).get("graph", True)) and world == 1
+    # `[model] graph = true` (extension key, default false): the training step is captured into one hipGraph after two eager
+    # batches (robosat_amd.graph) -- which needs the optimizer's step counters on the device (`capturable`).  Measured on one
+    # MI355X at bs 32 / 512^2 bf16: 24.7 ms per step replayed vs 23.5 ms eager (the graph executor runs the weight-gradient
+    # branch behind the main branch instead of beside it), so it is the option for hosts too slow to issue ~600 launches in
+    # 23 ms, not the default.
+    use_graph = bool(model.get("model", {}).get("graph", False)) and world == 1
     optimizer = Adam(net.parameters(), lr=model["opt"]["lr"], fused=device.type == "cuda", capturable=use_graph)
 
     resume = 0

@@ -102,24 +102,25 @@ def gpu_unet(rank, world, dtype):
     xb = torch.randn(4, 3, 256, 256, generator=g).to(dev)
     tb = torch.randint(0, 2, (4, 256, 256), generator=g).to(dev)
 
-    def main_stream_ms(reducer):
+    def main_stream(reducer):
         net.grad_reducer = reducer
-        best = float("inf")
+        best, rec = float("inf"), None
         for i in range(4):
             for p in net.parameters():
                 p.grad = None
             GradArena.TRACE = []
             crit(net(xb), tb).backward()
             torch.cuda.synchronize()
-            (t0, t1), = GradArena.TRACE
+            rec, = GradArena.TRACE
             if i:
-                best = min(best, t0.elapsed_time(t1))
+                best = min(best, rec["events"][0].elapsed_time(rec["events"][1]))
         GradArena.TRACE = None
         dist.barrier()
-        return best
+        return best, rec["joins"], rec["flushes"]
 
-    ms_plain, ms_dp = main_stream_ms(None), main_stream_ms(parallel.GradReducer())
-    return {"wire_bf16_rel_err": wire_err, "main_stream_ms": [ms_plain, ms_dp], "grad_rel_err": err, "local_vs_mean": differs, "peer_equal": bool(all(torch.equal(p, got) for p in peers)),
+    (ms_plain, joins_plain, _), (ms_dp, joins_dp, flushes) = main_stream(None), main_stream(parallel.GradReducer())
+    return {"wire_bf16_rel_err": wire_err, "main_stream_ms": [ms_plain, ms_dp], "joins": [joins_plain, joins_dp],
+            "flushes_on_side_stream": flushes, "grad_rel_err": err, "local_vs_mean": differs, "peer_equal": bool(all(torch.equal(p, got) for p in peers)),
             "replica_drift": drift, "fc_has_no_grad": bool(fc_grad), "loss_local": loss_local, "loss_dp": loss_dp}
 
 

@@ -120,7 +120,7 @@ def test_graphed_train_step_is_the_eager_step(dtype, loss_name):
     from robosat_amd.unet import UNet
 
     init = seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 9)
-    batches = [(seeded.synthetic_images(2, 3, 96, 128, 40 + i).to(DEV), seeded.synthetic_targets(2, 2, 96, 128, 40 + i).to(DEV))
+    batches = [(seeded.synthetic_images(2, 3, 128, 192, 40 + i).to(DEV), seeded.synthetic_targets(2, 2, 128, 192, 40 + i).to(DEV))
                for i in range(6)]
     odd = (seeded.synthetic_images(1, 3, 64, 64, 77).to(DEV), seeded.synthetic_targets(1, 2, 64, 64, 77).to(DEV))
     order = batches[:4] + [odd] + batches[4:]

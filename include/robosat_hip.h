@@ -286,6 +286,21 @@ int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, c
                            const float* scale, const float* shift, const void* residual, const void* relu_mask, void* out,
                            rs_stream_t stream);
 
+/* DecoderBlock (unet.py:63-73) in fp32 as a Winograd F(2x2, 2x2) convolution on the phase form: each parity's 2x2
+ * convolution on the source grid produces 2x2 blocks of outputs from 3x3 blocks of inputs with 9 multiplies instead of 16
+ * (transforms with 0 / +-1 coefficients only): 9/16 of the phase form's MFMA work, 1/4 of the reference-shape count -- for
+ * the fp32 path, whose matrix cores (157 TFLOP/s) are the bottleneck of these layers (conv_wino_f32.hip).  `d` describes the
+ * layer like rs_conv2d_fwd_phase_dt (ups = 1, 3x3, pad 1, Ho = 2 Hs); the epilogue is the model's: optional ReLU (d->relu).
+ * `u` = [4][9][Cout][C1+C2] from rs_pack_wino_phase_weight(phase pack [4][Cout][2][2][Cin] of rs_pack_phase_weight_dt).
+ * rs_conv2d_phase_wino_ok: 0 if this form cannot run `d` (needs >= 4 tiles per image side, channel counts % 16, Cout % 32,
+ * 32-bit offsets): use rs_conv2d_fwd_phase_dt; 1 if it can and should; 2 if it can but the launch has too few work items to
+ * fill the chip with one persistent block per CU (the generic kernel is the faster choice).  rs_conv2d_phase_wino_name: the launched instantiation, for reports. */
+int rs_conv2d_phase_wino_ok(const rs_conv_desc* d);
+const char* rs_conv2d_phase_wino_name(const rs_conv_desc* d);
+int rs_pack_wino_phase_weight(const float* w_phase, float* u, int Cout, int Cin, rs_stream_t stream);
+int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1, const float* src2, const float* u, float* out,
+                             rs_stream_t stream);
+
 /* ... and its data gradient: d loss / d (pre-upsample input) is ONE 4x4 / stride-2 / pad-1 convolution over dz with
  * pre-summed taps (rs_conv2d_fwd[_bf16] with kh = kw = 4 and these weights, [Cin][4][4][Cout]): the gradient lands at
  * the source resolution with 4/9 of the multiply-adds and the 2x2 sum of interpolate's backward already inside;

@@ -128,14 +128,16 @@ class GradArena:
 
     def finish(self):
         self.flush()
+        done = None
         if self._t0 is not None:  # (before the waits below: gloo's wait blocks the HOST, which would delay this record)
             done = torch.cuda.Event(enable_timing=True)
             done.record(torch.cuda.current_stream())
-            GradArena.TRACE.append({"events": (self._t0, done), "joins": self.joins, "flushes": list(self.flushes)})
         if self.reducer is not None:
             with torch.cuda.stream(self.side):
                 self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)
         self.join()  # once per step: the optimizer (main stream) needs every gradient
+        if done is not None:
+            GradArena.TRACE.append({"events": (self._t0, done), "joins": self.joins, "flushes": list(self.flushes)})
 
 
 class _Tape:
@@ -243,8 +245,10 @@ def _forward(net, x, tape):
         enc.append(h)
     enc1, enc2, enc3, enc4 = enc
 
-    def up(block, skip, prev=None):  # DecoderBlock in phase form: four 2x2 convolutions on the source grid
-        return ops.conv2d_phase(skip, block.block.block.phase(dt), src2=prev, relu=True)
+    def up(block, skip, prev=None):  # DecoderBlock on the source grid: Winograd form in fp32, phase form in bf16
+        from .unet import decoder_block
+
+        return decoder_block(block.block.block, skip, prev, dt)
 
     pooled, amc = ops.maxpool2d(enc4, 2, 2, 0, want_argmax=True)
     if decoder_weights_ready is not None:

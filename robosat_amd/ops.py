@@ -328,6 +328,64 @@ def conv2d_phase(src1, weight_phase, src2=None, scale=None, shift=None, residual
     return out
 
 
+def _phase_desc(src1, src2, cout, relu):
+    n, hs, ws, c1 = src1.shape
+    c2 = 0 if src2 is None else src2.shape[3]
+    return ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, int(relu), 0)
+
+
+def wino_ok(src1, src2, cout, force=False):
+    """Whether the fp32 Winograd form of DecoderBlock (``conv2d_phase_wino``) should run this layer
+    (``rs_conv2d_phase_wino_ok``: it can, and the launch is large enough to fill the chip); ``force``: whether it CAN (the
+    parity tests reach the kernel with small problems).  ROBOSAT_WINOGRAD=0 switches it off (A/B measurements: the generic
+    phase kernel then runs every layer)."""
+
+    import os
+
+    if src1.dtype != torch.float32 or (not force and os.environ.get("ROBOSAT_WINOGRAD", "1") == "0"):
+        return False
+    rc = _lib.lib().rs_conv2d_phase_wino_ok(ctypes.byref(_phase_desc(src1, src2, cout, False)))
+    return rc != 0 if force else rc == 1
+
+
+def pack_wino_phase_weight(weight_phase):
+    """Phase pack [4,Cout,2,2,Cin] fp32 -> U = G g G^T, [4,9,Cout,Cin]: the transformed filters of the Winograd form."""
+
+    _, cout, _, _, cin = weight_phase.shape
+    u = torch.empty((4, 9, cout, cin), device=weight_phase.device, dtype=torch.float32)
+    check(_lib.lib().rs_pack_wino_phase_weight(_dev(weight_phase, "w_phase"), _dev(u, "u"), cout, cin, _stream()),
+          "rs_pack_wino_phase_weight")
+    return u
+
+
+def conv2d_phase_wino(src1, u, src2=None, relu=False):
+    """DecoderBlock in fp32 as a Winograd F(2x2, 2x2) convolution on the phase form (``rs_conv2d_fwd_phase_wino``): same
+    result as ``conv2d_phase`` up to fp32 summation order, 9/16 of its multiply-adds."""
+
+    n, hs, ws, c1 = src1.shape
+    c2 = 0 if src2 is None else src2.shape[3]
+    cout = u.shape[2]
+    assert tuple(u.shape) == (4, 9, cout, c1 + c2)
+    if src2 is not None and tuple(src2.shape[:3]) != (n, hs, ws):
+        raise RuntimeError("Sizes of tensors must match except in dimension 1: skip {} vs decoder {}".format(
+            tuple(src1.shape[:3]), tuple(src2.shape[:3])))
+    d = _phase_desc(src1, src2, cout, relu)
+    out = torch.empty((n, 2 * hs, 2 * ws, cout), device=src1.device, dtype=torch.float32)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv2d_fwd_phase_wino(ctypes.byref(d), _dev(src1, "src1"), _dev(src2, "src2"), _dev(u, "u"), _dev(out, "out"),
+                                             _stream())
+    check(rc, "rs_conv2d_fwd_phase_wino")
+    if PROFILE is not None:
+        ev1.record()
+        name = _lib.lib().rs_conv2d_phase_wino_name(ctypes.byref(d)).decode()
+        # executed: 9 multiply-adds per 2x2 outputs of a parity = 1/4 of the reference-shape count (the phase form: 4/9)
+        _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 4),
+                conv_flops(d) * 0.25)
+    return out
+
+
 def conv_tile_name(d, bf16=False, phase=False):
     """Report name of the kernel a convolution launch runs, 1:1 with the launched symbol:
     ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel)."""

@@ -81,6 +81,17 @@ class _Conv(nn.Module):
             self._phase = c
         return c[1]
 
+    def phase_wino(self):
+        """The transformed filters U = G g G^T of the fp32 Winograd form of DecoderBlock (``rs_pack_wino_phase_weight`` on
+        the phase pack), cached like ``phase``."""
+
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0])
+        c = getattr(self, "_phase_wino", None)
+        if c is None or c[0] != key:
+            c = (key, ops.pack_wino_phase_weight(self.phase(torch.float32)))
+            self._phase_wino = c
+        return c[1]
+
     def dgrad_phase(self, dtype=torch.float32):
         """Weights of the phase form's data gradient (one 4x4 / stride-2 convolution over dz, ``rs_pack_dgrad_phase_weight_dt``),
         cached like ``phase``."""
@@ -194,6 +205,16 @@ class DecoderBlock(nn.Module):
     def __init__(self, num_in, num_out):
         super().__init__()
         self.block = ConvRelu(num_in, num_out)
+
+
+def decoder_block(conv, skip, prev, dt):
+    """relu(conv3x3(interpolate(cat[skip, prev], x2 nearest), pad 1)) -- reference unet.py:63-73 -- on the source grid: in
+    fp32 as the Winograd F(2x2, 2x2) form of the four parity convolutions where the layer qualifies (9/16 of the phase form's
+    multiply-adds; the fp32 matrix cores are what bounds these layers), else the phase form itself (bf16; tiny layers)."""
+
+    if dt == torch.float32 and ops.wino_ok(skip, prev, conv.cout):
+        return ops.conv2d_phase_wino(skip, conv.phase_wino(), src2=prev, relu=True)
+    return ops.conv2d_phase(skip, conv.phase(dt), src2=prev, relu=True)
 
 
 def _find_pretrained():
@@ -499,7 +520,7 @@ class UNet(nn.Module):
         enc1, enc2, enc3, enc4 = enc
 
         def up(block, skip, prev=None):  # DecoderBlock in phase form: four 2x2 convolutions on the source grid
-            return ops.conv2d_phase(skip, block.block.block.phase(dt), src2=prev, relu=True)
+            return decoder_block(block.block.block, skip, prev, dt)
 
         center = up(self.center, ops.maxpool2d(enc4, 2, 2, 0))
         dec0 = up(self.dec0, enc4, center)

@@ -37,11 +37,11 @@ def test_two_rank_train_step_averages_gradients_and_keeps_replicas_identical(tmp
         assert r["wire_bf16_rel_err"] <= 8e-3, r
         # the exchange is ordered after the weight-gradient stream and never joined into the main stream: with a reducer the
         # main stream waits for the side stream exactly as often as without (ONCE, at the end of the backward; round 2: once
-        # more per bucket), and each of the 5 buckets' collectives was issued with the side stream current.  (The timings are
+        # more per bucket), and every bucket's collective was issued with the side stream current.  (The timings are
         # printed, not asserted: two ranks share this box's one GPU and gloo moves the buckets through host memory, so the
         # main stream's wall time here says nothing about RCCL on eight devices.)
         assert r["joins"] == [1, 1], r
-        assert r["flushes_on_side_stream"] == [True] * 5, r
+        assert len(r["flushes_on_side_stream"]) >= 5 and all(r["flushes_on_side_stream"]), r  # (5 buckets + the stem's rest)
         print(mode, "main-stream backward ms without / with the reducer (informational):", r["main_stream_ms"])
     assert res[0]["loss_local"] != res[1]["loss_local"]
 

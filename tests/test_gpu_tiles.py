@@ -302,3 +302,59 @@ def test_bench_symbols_are_covered(tmp_path):
     assert set(line["legs"]) == {"cfg5_train_bf16_4band_4class", "train_fp32_bs8", "cfg4_predict_fp32_1024_bs8"}
     assert all(leg["value"] > 0 for leg in line["legs"].values())
     assert line["legs"]["cfg5_train_bf16_4band_4class"]["config"]["bands"] == 4
+
+
+# ---- fp32 Winograd form of DecoderBlock (conv_wino_f32.hip) --------------------------------------------------------------------
+WINO = {"conv_wino_f32<phase,p8,64x64>", "conv_wino_f32<phase,p8,128x32>", "conv_wino_f32<phase,p4,64x64>", "conv_wino_f32<phase,p4,128x32>"}
+COVERED |= WINO
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,h,w,want", [
+    (2, 64, 32, 64, 16, 16, "p8,64x64"),     # one 8x8 tile patch per image, two sources
+    (3, 48, 0, 128, 20, 36, "p8,64x64"),     # ragged patches (10 x 18 tiles), single source, 16-channel chunks that are not 32-multiples
+    (2, 128, 0, 32, 32, 32, "p8,128x32"),    # dec4's shape class: 32 couts, two patches per block
+    (5, 32, 32, 96, 8, 8, "p4,128x32"),      # 4x4-tile patches, 8 per block, blocks that straddle images, Cout % 64 != 0
+    (3, 64, 0, 64, 9, 13, "p4,64x64"),       # odd sizes: ragged last tile row / column (positions past the image), center's class
+    (1, 32, 16, 64, 64, 48, "p8,64x64"),     # many patches per image
+])
+def test_winograd_phase_form_vs_fp32_reference(n, c1, c2, cout, h, w, want):
+    """relu(conv3x3(interpolate(cat[a, b], x2), pad 1)) through the Winograd F(2x2, 2x2) kernel against plain PyTorch fp32 --
+    and against the generic phase kernel on the same launch; the transforms have 0 / +-1 coefficients, so the two agree to
+    fp32 summation-order noise."""
+    from robosat_amd import ops
+
+    a = rnd(n, c1, h, w, seed=51)
+    b = rnd(n, c2, h, w, seed=52) if c2 else None
+    wt = rnd(cout, c1 + c2, 3, 3, seed=53) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    x = a if b is None else torch.cat([a, b], 1)
+    ref = F.relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, padding=1))
+    s1, s2 = nhwc(a, torch.float32), (nhwc(b, torch.float32) if b is not None else None)
+    wp = ops.pack_phase_weight(krsc(wt, torch.float32), torch.float32)
+    assert ops.wino_ok(s1, s2, cout, force=True)
+    ops.PROFILE = []
+    try:
+        got = ops.conv2d_phase_wino(s1, ops.pack_wino_phase_weight(wp), src2=s2, relu=True)
+        torch.cuda.synchronize()
+        name = ops.PROFILE[0][0]
+    finally:
+        ops.PROFILE = None
+    assert name == "conv_wino_f32<phase,{}>".format(want) and name in COVERED, name
+    close(nchw(got), ref, torch.float32, "winograd vs fp32 reference")
+    if c1 % 32 == 0 and c2 % 32 == 0:  # (the generic kernel's channel granularity)
+        generic = ops.conv2d_phase(s1, wp, src2=s2, relu=True)
+        assert float((got - generic).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # without the ReLU (negative outputs survive) and on a second call (no state left in the kernel)
+    got2 = ops.conv2d_phase_wino(s1, ops.pack_wino_phase_weight(wp), src2=s2, relu=False)
+    ref2 = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, padding=1)
+    close(nchw(got2), ref2, torch.float32, "winograd, no relu")
+
+
+def test_winograd_declines_what_it_cannot_run():
+    from robosat_amd import ops
+
+    tiny = torch.zeros(1, 4, 4, 64, device=DEV)  # 2 x 2 tiles per image: the generic phase kernel's job
+    assert not ops.wino_ok(tiny, None, 64, force=True)
+    assert not ops.wino_ok(torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF), None, 64, force=True)  # bf16 keeps the phase form
+    small = torch.zeros(1, 16, 16, 64, device=DEV)  # runnable, but 4 work items: left to the generic kernel's many small blocks
+    assert ops.wino_ok(small, None, 64, force=True) and not ops.wino_ok(small, None, 64)
+    assert ops.wino_ok(torch.zeros(16, 64, 64, 64, device=DEV), None, 64)

@@ -293,8 +293,9 @@ int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, c
  * layer like rs_conv2d_fwd_phase_dt (ups = 1, 3x3, pad 1, Ho = 2 Hs); the epilogue is the model's: optional ReLU (d->relu).
  * `u` = [4][9][Cout][C1+C2] from rs_pack_wino_phase_weight(phase pack [4][Cout][2][2][Cin] of rs_pack_phase_weight_dt).
  * rs_conv2d_phase_wino_ok: 0 if this form cannot run `d` (needs >= 4 tiles per image side, channel counts % 16, Cout % 32,
- * 32-bit offsets): use rs_conv2d_fwd_phase_dt; 1 if it can and should; 2 if it can but the launch has too few work items to
- * fill the chip with one persistent block per CU (the generic kernel is the faster choice).  rs_conv2d_phase_wino_name: the launched instantiation, for reports. */
+ * 32-bit offsets): use rs_conv2d_fwd_phase_dt; 1 if it can and should; 2 if it can but should not (fewer than 8 tiles per image
+ * side: the generic kernel is faster).  The answer depends on the layer's geometry only, never on N: the two forms differ in
+ * summation order, and a tile's output must not depend on the size of the batch it travels in.  rs_conv2d_phase_wino_name: the launched instantiation, for reports. */
 int rs_conv2d_phase_wino_ok(const rs_conv_desc* d);
 const char* rs_conv2d_phase_wino_name(const rs_conv_desc* d);
 int rs_pack_wino_phase_weight(const float* w_phase, float* u, int Cout, int Cin, rs_stream_t stream);

@@ -365,8 +365,11 @@ bool wino_plan(const rs_conv_desc* d, WinoPlan* pl) {
   if ((long)d->N * d->Ho * d->Wo >= (1L << 31)) return false;
   // one block per CU and no other block to hide behind: a launch with fewer work items than ~half the CUs (the `center`
   // block at small batches) is faster on the generic phase kernel's 4-blocks-per-CU grid
-  const long items = (long)rs_cdiv((long)d->N * rs_cdiv(ty, pl->pb) * rs_cdiv(tx, pl->pb), pl->sb) * (d->Cout / (32 * pl->wgn)) * 4;
-  pl->worth = items >= 128;
+  // Worth it -- a decision on the layer's GEOMETRY alone, never on the batch size: a tile's probabilities must not depend on
+  // its batch neighbours (the two forms differ in fp32 summation order), so the same kernel runs a layer at every N.  One
+  // full 8x8 patch of tiles per image side at least (Hs, Ws >= 15): with fewer, a block's tiles straddle images and the
+  // persistent one-block-per-CU grid is short of work items at any batch size (`center` at 512^2: 0.32 vs 0.21 ms).
+  pl->worth = pl->pb == 8;
   return true;
 }
 

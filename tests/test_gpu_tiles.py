@@ -355,6 +355,7 @@ def test_winograd_declines_what_it_cannot_run():
     tiny = torch.zeros(1, 4, 4, 64, device=DEV)  # 2 x 2 tiles per image: the generic phase kernel's job
     assert not ops.wino_ok(tiny, None, 64, force=True)
     assert not ops.wino_ok(torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF), None, 64, force=True)  # bf16 keeps the phase form
-    small = torch.zeros(1, 16, 16, 64, device=DEV)  # runnable, but 4 work items: left to the generic kernel's many small blocks
+    small = torch.zeros(16, 8, 8, 64, device=DEV)  # runnable (4x4-tile patches), but left to the generic kernel: < 8 tiles per side
     assert ops.wino_ok(small, None, 64, force=True) and not ops.wino_ok(small, None, 64)
-    assert ops.wino_ok(torch.zeros(16, 64, 64, 64, device=DEV), None, 64)
+    # the choice is the layer's geometry, never the batch size: a tile's output must not depend on its batch neighbours
+    assert ops.wino_ok(torch.zeros(1, 16, 16, 64, device=DEV), None, 64) and ops.wino_ok(torch.zeros(16, 16, 16, 64, device=DEV), None, 64)

@@ -166,7 +166,10 @@ def pmc_traffic(kernel):
     passes, corrected as MI355X_MICROARCH.md prescribes) -- profiles/pmc_traffic.json, written by scripts/pmc_summary.py
     from a run of this same command.  None when no counter run has been committed for this kernel."""
 
-    return _pmc_table().get(kernel)
+    table = _pmc_table()
+    if kernel in table:
+        return table[kernel]
+    return table.get(kernel.split("+")[0] + ">") if "+" in kernel else None  # ("conv_wgrad_bf16<phase,128x128+128x64>": by its first tile)
 
 
 def _pmc_table():
@@ -281,6 +284,7 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
     import torch.distributed as td
 
     train = leg.phase == "train"
+    torch.cuda.reset_peak_memory_stats(device)
     net = build_model(leg.classes, device, train, leg.dtype, leg.channels)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(leg.batch, leg.channels, leg.size, leg.size, generator=g).to(device)  # resident in HBM
@@ -339,15 +343,27 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
     for _ in range(warmup):
         timed()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # (recorded on the stream; no host sync)
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    marks[0].record()
-    for i in range(steps):
-        last = timed()
-        marks[i + 1].record()
-    barrier()
-    el = time.perf_counter() - t0
+    # Python's cyclic collector runs when it pleases; a full collection in the middle of the timed steps stalls the host thread
+    # that issues the launches (one step of a 10-step leg was seen to take 845 ms instead of 25).  Collect now, keep it off
+    # for the timed region -- `rs train` does the same around its epoch loops (tools/train.py:_epoch).
+    import gc
+
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        last = None
+        marks[0].record()
+        for i in range(steps):
+            last = timed()
+            marks[i + 1].record()
+        barrier()
+        el = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if dist:
         t = torch.tensor([el], device=device, dtype=torch.float64)
@@ -362,6 +378,7 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
             rec["train_loss_last_step"] = float(last)
         return rec
 
+    run_phase.peak_gb = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)  # (read by the caller right after)
     return el, step_ms, step, parity, bool(train and graphed and stepper.captured)
 
 
@@ -371,7 +388,9 @@ def step_stats(step_ms):
 
     v = sorted(step_ms)
     n = len(v)
-    return {"min": round(v[0], 3), "median": round((v[n // 2] + v[(n - 1) // 2]) / 2, 3), "max": round(v[-1], 3), "n": n}
+    med = (v[n // 2] + v[(n - 1) // 2]) / 2
+    return {"min": round(v[0], 3), "median": round(med, 3), "max": round(v[-1], 3), "n": n,
+            "stalled_steps": sum(1 for x in v if x > 1.5 * med)}
 
 
 def workload(leg, world, cfg=""):
@@ -542,7 +561,7 @@ def main():
         if rank == 0:
             line["train"] = {"value": round(world * tleg.batch * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
                              "ms_per_step": round(tel / ts * 1e3, 3), "step_ms": step_stats(tstep_ms), "dtype": "bf16",
-                             "hipgraph": tgraph,
+                             "hipgraph": tgraph, "peak_hbm_gb": run_phase.peak_gb,
                              "scaling": args.scaling, "config": workload(tleg, world, baseline_config(tleg)),
                              "roofline": troof, "parity": tparity()}
         del tstep
@@ -552,16 +571,16 @@ def main():
     # roofline pass: configs[4] (4-band RGB+IR, 4 classes, Lovasz, bf16 bs 32), the reference's own arithmetic for training
     # (fp32, bs 8) and configs[3] (1024^2 tiles, bs 8, fp32 predict).
     if args.phase == "predict" and not args.no_extra_legs and args.size == 512:
-        extra = [("cfg5_train_bf16_4band_4class", Leg("train", "bf16", per_rank(32), 512, 4, 4, "Lovasz"), 10, 3),
-                 ("train_fp32_bs8", Leg("train", "fp32", per_rank(8), 512, 2, 3, "Lovasz"), 5, 3),
-                 ("cfg4_predict_fp32_1024_bs8", Leg("predict", "fp32", per_rank(8), 1024, 2, 3, "Lovasz"), 10, 2)]
+        extra = [("cfg5_train_bf16_4band_4class", Leg("train", "bf16", per_rank(32), 512, 4, 4, "Lovasz"), 10, 4),
+                 ("train_fp32_bs8", Leg("train", "fp32", per_rank(8), 512, 2, 3, "Lovasz"), 5, 4),
+                 ("cfg4_predict_fp32_1024_bs8", Leg("predict", "fp32", per_rank(8), 1024, 2, 3, "Lovasz"), 10, 3)]
         for name, leg, ls, lw in extra:
             lel, lstep_ms, lstep, lparity, lgraph = run_phase(leg, ls, lw, device, dist, rank, no_parity=True, grad_dtype=args.grad_dtype)
             if rank == 0:
                 line.setdefault("legs", {})[name] = {
                     "value": round(world * leg.batch * ls / lel, 2), "unit": "tiles/s", "steps": ls, "warmup": lw,
                     "ms_per_step": round(lel / ls * 1e3, 3), "step_ms": step_stats(lstep_ms), "dtype": leg.dtype,
-                    "hipgraph": lgraph,
+                    "hipgraph": lgraph, "peak_hbm_gb": run_phase.peak_gb,
                     "config": workload(leg, world, baseline_config(leg))}
             del lstep
             torch.cuda.empty_cache()

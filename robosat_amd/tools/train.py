@@ -260,15 +260,10 @@ def _portable_optimizer_state(optimizer):
     return state
 
 
-def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, desc="Train", stepper=None):
-    training = optimizer is not None
+def _epoch_loop(loader, num_classes, device, net, criterion, master, optimizer, desc, stepper, training, metrics, running_loss):
+    """The batches of one pass; returns the number of samples seen (``running_loss`` and ``metrics`` accumulate in place)."""
+
     num_samples = 0
-    running_loss = torch.zeros((), device=device, dtype=torch.float64)
-    metrics = Metrics(range(num_classes))
-
-    net.train() if training else net.eval()
-    started = time.perf_counter()
-
     for images, masks, tiles in tqdm(loader, desc=desc, unit="batch", ascii=True, disable=not master):
         images = images.to(device, non_blocking=True)
         masks = masks.to(device, non_blocking=True)
@@ -294,6 +289,34 @@ def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, 
 
         running_loss += loss.detach()  # stays on the device: no per-step host sync
         metrics.add_batch(masks, outputs.detach())
+
+    return num_samples
+
+
+def _epoch(loader, num_classes, device, net, criterion, master, optimizer=None, desc="Train", stepper=None):
+    training = optimizer is not None
+    num_samples = 0
+    running_loss = torch.zeros((), device=device, dtype=torch.float64)
+    metrics = Metrics(range(num_classes))
+
+    net.train() if training else net.eval()
+    started = time.perf_counter()
+
+    # A step is ~600 kernel launches issued by this thread; a full cyclic-GC pass in the middle of an epoch stalls it for
+    # tens to hundreds of milliseconds while the GPU runs dry.  Nothing in the loop creates reference cycles that must be
+    # reclaimed promptly (tensors are freed by reference count): collect between passes, not inside them.
+    import gc
+
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        result = _epoch_loop(loader, num_classes, device, net, criterion, master, optimizer, desc, stepper, training, metrics,
+                             running_loss)
+    finally:
+        if gc_was_on:
+            gc.enable()
+            gc.collect()
+    num_samples = result
 
     # one sync per epoch; same normalisation quirk as the reference: sum of batch-mean losses / number of samples
     # (with W ranks a global batch's loss is the mean of the ranks' shard losses and it holds W shards' samples)

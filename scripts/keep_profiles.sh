@@ -1,0 +1,30 @@
+#!/bin/bash
+# Copies what is kept of one GPU-box visit (gpurun_out/TAG, written by scripts/gpu_round.sh) into profiles/ROUND and re-stamps
+# profiles/pmc_traffic.json with the commit of the tree that was profiled.   scripts/keep_profiles.sh TAG ROUND [COMMIT]
+TAG=$1; ROUND=$2; COMMIT=${3:-$(git rev-parse --short HEAD)}
+SRC=gpurun_out/$TAG; DST=profiles/$ROUND; mkdir -p $DST
+cp $SRC/bench_default.json $DST/bench_default.json
+cp $SRC/bench_default.json $DST/bench_driver_command.json   # (the `bench` stage runs the driver's command: --gpus 1 --steps 20 --warmup 5)
+cp $SRC/bench_train_bf16_bs32.json $DST/ 2>/dev/null
+cp $SRC/layers_predict.json $SRC/layers_train.json $DST/ 2>/dev/null
+cp $SRC/predict_kernel_stats.csv $DST/predict_fp32_bs16_512_kernel_stats.csv 2>/dev/null
+cp $SRC/train_kernel_stats.csv $DST/train_bf16_bs32_512_kernel_stats.csv 2>/dev/null
+cp $SRC/train_serial_kernel_stats.csv $DST/train_bf16_bs32_512_serial_kernel_stats.csv 2>/dev/null
+cp $SRC/pmc_mfma_per_kernel.txt $DST/ 2>/dev/null
+cp $SRC/bench_others.txt $SRC/latency.txt $DST/ 2>/dev/null
+python scripts/bench_brief.py $SRC/bench_default.json > $DST/bench_brief.txt
+if [ -d $SRC/pmc ]; then
+  python scripts/pmc_traffic.py $SRC/pmc profiles/pmc_traffic.json $TAG > $DST/pmc_hbm_traffic.txt
+  python - "$COMMIT" <<PY
+import json, sys
+p = "profiles/pmc_traffic.json"
+d = json.load(open(p))
+d["_meta"]["commit"] = sys.argv[1]
+json.dump(d, open(p, "w"), indent=1, sort_keys=True)
+PY
+fi
+# the test log without the tool chatter: summary line + every captured line that carries a number a reader may ask for
+{ grep -E "passed|failed" $SRC/pytest_gpu.log | tail -1
+  grep -E "cosine|Lovasz kernel|lovasz \(|mIoU after|main-stream|cfg[0-9] |max\|dprob\||losses eager|worst " $SRC/pytest_gpu.log | grep -v "print(" | sort -u
+} > $DST/pytest_gpu.log
+ls -la $DST

@@ -28,16 +28,26 @@ def bench_name(k):
     if m:
         return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "f" else "bf16",
                                                   "phase," if m.group(5) == "1" else "", m.group(2), m.group(3), m.group(4))
+    # per-instantiation names, spelled as bench.py reports them (ops.wgrad_kernel_name / conv_tile_name / rs_conv2d_phase_wino_name)
+    m = re.search(r"conv_wino_f32_kernel<(\d+), (\d+), (\d+)>", k)
+    if m:
+        return "conv_wino_f32<phase,p{},{}x{}>".format(m.group(1), 16 * int(m.group(2)), 32 * int(m.group(3)))
+    m = re.search(r"conv_thin_bf16<(\d)>", k)
+    if m:
+        return "conv_thin_bf16<{}>".format(("3x3", "phase", "dgrad4x4")[int(m.group(1))])
+    m = re.search(r"conv_wgrad_thin_bf16<(\d+), (\d)>", k)
+    if m:
+        return "conv_wgrad_thin_bf16<{}{}>".format(32 * int(m.group(1)), ",ups" if m.group(2) == "1" else "")
+    m = re.search(r"conv_wgrad_bf16<(\d+), (\d+), \d+, \d+, \d+, (true|false)>", k)
+    if m:  # (a two-launch layer -- "128x128+128x64" in the bench's name -- is looked up by its first tile)
+        return "conv_wgrad_bf16<{}{}x{}>".format("phase," if m.group(3) == "true" else "", m.group(1), m.group(2))
     m = re.search(r"_ZN\d+_GLOBAL__N_1\d+([a-z_0-9]+?)I", k)
     if m:
         return m.group(1)
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), \d+, \d+, 1>", k)
     if m:
         return "conv_igemm_f32<{}x{},stem>".format(m.group(1), m.group(2))
-    m = re.search(r"conv_wgrad_bf16<[^>]*, true>", k)
-    if m:
-        return "conv_wgrad_bf16<phase>"
-    m = re.search(r"(conv_wgrad_thin_bf16|conv_wgrad_bf16|conv_wgrad_f32)", k)
+    m = re.search(r"(conv_wgrad_f32)", k)
     if m:
         return m.group(1)
     m = re.match(r"(?:void )?(\w+)", k)

@@ -13,26 +13,37 @@
 // LDS-DMA stream, not by MFMA, and the transform would only add bytes: bf16 keeps the phase form.
 //
 // Mapping.  GEMM rows = TILES (2x2 blocks of source positions -> 4x4 output pixels over the four parities; each parity is
-// its own set of blocks), columns = couts, K = input channels of cat[skip, prev] in 16-channel chunks (64-byte rows).
-//   block  = 4 compute waves + 1 PRODUCER wave, persistent (one block per CU walks work items = (32*WGM tiles, 32*WGN couts,
-//            parity)).  A compute wave owns a 32 x 32 (tiles x couts) sub-problem and keeps NINE 32x32 accumulators (one per
-//            transformed position xi): 144 registers; its 64-cycle MFMAs are issued back to back on nine independent
-//            accumulators while its own LDS reads and transform adds run underneath.  The producer wave issues EVERY LDS-DMA
-//            instruction of the block (an LDS-DMA instruction holds the issuing wave for 60-180 cycles: with the 14-18
-//            pieces per chunk this kernel needs, spread over the compute waves they cost a fifth of the MFMA time -- measured:
-//            104 -> see profiles/r03) and runs one chunk ahead across item boundaries, so the next item's first chunk streams
-//            in while the compute waves store the previous item's outputs.
+// its own set of work items), columns = couts, K = input channels of cat[skip, prev] in 16-channel chunks (64-byte rows).
+//   block  = 8 waves, persistent: one block per CU walks work items (16*TG tiles x 32*CG couts x parity; TG x CG = 4 x 2, or
+//            8 x 1 for the 32-cout layer).  A wave owns 16 tiles x 32 couts and keeps 9 x 2 accumulators of
+//            v_mfma_f32_16x16x4_f32 (one pair per transformed position xi): 72 registers, two waves per SIMD -- while one
+//            wave reads its patch and runs the transform's vector ops, the other's MFMAs keep the matrix core busy.
 //   LDS    = per K-chunk the block's source HALO -- every source pixel any of its tiles touches, once: (2 PB + 1)^2 pixels
 //            per PB x PB patch of tiles, 64 bytes each -- plus the transformed filters U[xi][cout][16 ch], both by LDS-DMA
 //            (buffer_load ... lds; out-of-image pixels arrive as zeros), double buffered, one barrier per chunk.  A source
-//            pixel is fetched ONCE per block and chunk (the generic phase kernel fetches it once per tap: 4x).
-//   reads  = each lane reads the 3x3 patch of its tile (9 ds_read_b128), forms B^T d B with 12 vector subtractions, reads
-//            the 9 filter pieces and issues 36 MFMAs per 8 channels.  Halo rows are stored even-x-first with a padded pitch
-//            and an XOR swizzle (found by exhaustive search against ds_read_b128's four 16-lane groups) so that all 18 reads
-//            are bank-conflict free; the lane -> tile assignment is part of that solution.
-//   store  = A^T M A on the accumulators (12 adds per output element), ReLU, 16-byte stores straight from registers: a lane
-//            holds 4 consecutive couts of its tile's pixels.
+//            pixel is fetched ONCE per block and chunk (the generic phase kernel fetches it once per tap: 4x).  The fetch side
+//            runs one chunk ahead ACROSS work items: the next item's first chunk streams in while this item's outputs are
+//            stored (its halo table is built an item ahead, double buffered).
+//   reads  = each lane reads the 3x3 patch of its tile (9 ds_read_b128: 4 channels of each of the 9 pixels), forms B^T d B
+//            with 12 vector subtractions, reads the filter pieces one position ahead of their use (sched_barrier keeps hipcc
+//            from sinking them in front of every MFMA group) and issues 72 MFMAs per chunk.  Halo rows are stored
+//            even-x-first, sub-blocks padded to 8 rows, pieces XOR-swizzled with (row ^ row >> 1) & 3, lanes mapped to tiles
+//            by a bit permutation: found by exhaustive search against ds_read_b128's four 16-lane groups, all 27 reads per
+//            chunk are bank-conflict free (scripts/probes/wino_lds.py re-derives and checks it; SQ_LDS_BANK_CONFLICT = 0).
+//   store  = A^T M A on the accumulators (3 adds per output element), ReLU, 16-byte stores straight from registers: a lane
+//            holds 4 consecutive couts of its tile's pixels; no LDS staging, nothing to wait for.
 // Weights: rs_pack_wino_phase_weight turns the phase pack [4][Cout][2][2][Cin] into U = G g G^T, [4][9][Cout][Cin].
+// Which layers: decided on the layer's GEOMETRY alone (>= 8 tiles per image side), never on the batch size -- the two forms
+// differ in fp32 summation order, and a tile's probabilities must not depend on the batch it travels in.
+//
+// Measured (MI355X, bs 16 at 512^2, scripts/bench_wino.py; generic phase kernel -> this kernel): dec0 0.68 -> 0.40 ms, dec1
+// 1.24 -> 0.79, dec2 0.76 -> 0.48, dec3 2.39 -> 1.68, dec4 1.21 -> 0.79: 1.43-1.7x for 9/16 of the MFMA work, i.e. the matrix
+// cores are 72-78 % busy here against 90 % in the generic kernel (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03).  What the rest is:
+// the CU's LDS-DMA path (~23 B/clk) carries 12 B/clk here -- 55 KB per chunk, two thirds of it filters -- and the waves that
+// issue those pieces stall on it in phase with each other (one barrier per chunk).  Variants measured on the way
+// (profiles/r03/wino_variants.txt): 32x32x2 MFMAs with 144 accumulator registers at one wave per SIMD (104 TFLOP/s executed
+// on dec3), the same with two dedicated DMA-producer waves and persistent blocks (101), with wave pairs splitting each
+// chunk's channels and an LDS reduction at the end (110), this one (116); front-loading the DMA pieces: no change.
 #define RS_CONV_INSTANTIATE  // (for the LDS-DMA helpers of the header; no kernel of it is instantiated here)
 #include "conv_igemm_dma_kernel.h"
 
@@ -238,7 +249,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
 #pragma unroll
         for (int c = 0; c < 3; ++c) P[r][c] = *reinterpret_cast<const f32x4*>(L + addrA[r][c]);
       const bool more = g + 1 < total;
-      constexpr int NMMA = 72, PSTEP = (NMMA / (3 * NI)) >= 1 ? NMMA / (3 * NI) : 1;  // front-loaded: the rest of the chunk covers the DMA latency
+      // LDS-DMA pieces of the NEXT chunk, spread evenly over this chunk's MFMAs: the CU's DMA path moves ~23 B/clk and this
+      // kernel needs ~12 B/clk of it (55 KB per 4608 MFMA cycles); issued in a burst the pieces queue up and hold the issuing
+      // waves (front-loading them was measured: no gain)
+      constexpr int NMMA = 72, PSTEP = NMMA / NI >= 1 ? NMMA / NI : 1;
       // filter pieces are fetched one transformed position ahead of the MFMAs that use them (the first pair goes out before
       // the transform's vector ops): in source order hipcc otherwise parks an LDS round trip in front of every group of 8 MFMAs
       f32x4 Bq[9][2];

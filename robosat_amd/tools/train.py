@@ -11,6 +11,14 @@ Differences by design:
     ``DataParallel`` wrapper produces, so files are interchangeable; only rank 0 writes.
   * the per-step ``loss.item()`` and the 4 host syncs per sample of ``Metrics.add`` are gone: loss and confusion
     counts accumulate on the device and are read once per epoch.
+  * losses under data parallelism: the reference evaluates ONE loss over the gathered global batch (train.py:180-186); here
+    every rank evaluates its shard and the gradients are averaged.  For Lovasz (a mean over images) that is the same number;
+    weighted CrossEntropy / Focal exchange their normaliser (the sum of target weights, one scalar all-reduce) so that it is
+    the same number there too (robosat_amd/losses.py); mIoULoss2d's ``max(miou, nll)`` picks its branch per shard, which
+    can differ from the global choice on a step where the two branches are close.
+  * extension keys, all optional: dataset ``[common] image_dirs / image_modes / mean / std`` (band layout: robosat_amd/bands.py;
+    default = the reference's one RGB directory), model ``[model] in_channels``, ``compute_dtype``, ``pretrained``,
+    ``device_augment``, ``grad_dtype`` (bf16 gradient exchange), ``graph`` (the step as one hipGraph replay).
 """
 
 import argparse

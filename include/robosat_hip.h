@@ -302,6 +302,18 @@ int rs_pack_wino_phase_weight(const float* w_phase, float* u, int Cout, int Cin,
 int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1, const float* src2, const float* u, float* out,
                              rs_stream_t stream);
 
+/* The stride-1 3x3 / pad-1 convolutions of the fp32 predict path -- Bottleneck.conv2 (torchvision resnet50 via unet.py:94,
+ * 122-130) with its eval-mode BatchNorm folded into scale / shift, and dec5's ConvRelu (unet.py:32-44,139) -- as a Winograd
+ * F(2x2, 3x3) convolution: 16 multiplies per 2x2 outputs instead of 36 (conv_wino33_f32.hip).  `d`: kh = kw = 3, stride 1,
+ * pad 1, ups 0, C2 = 0, Ho = Hs, Wo = Ws; out = relu?(conv(src) * scale + shift), scale / shift optional.  `u` = [16][Cout][Cin]
+ * from rs_pack_wino33_weight(KRSC fp32 weight).  rs_conv2d_wino33_ok: 1 if this form runs `d` (H, W >= 15, Cin % 16 == 0 and
+ * >= 32, Cout % 16 == 0): a function of the layer's geometry only, never of N (see rs_conv2d_phase_wino_ok). */
+int rs_conv2d_wino33_ok(const rs_conv_desc* d);
+const char* rs_conv2d_wino33_name(const rs_conv_desc* d);
+int rs_pack_wino33_weight(const float* w_krsc, float* u, int Cout, int Cin, rs_stream_t stream);
+int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift, float* out,
+                         rs_stream_t stream);
+
 /* ... and its data gradient: d loss / d (pre-upsample input) is ONE 4x4 / stride-2 / pad-1 convolution over dz with
  * pre-summed taps (rs_conv2d_fwd[_bf16] with kh = kw = 4 and these weights, [Cin][4][4][Cout]): the gradient lands at
  * the source resolution with 4/9 of the multiply-adds and the 2x2 sum of interpolate's backward already inside;

@@ -1,0 +1,365 @@
+// conv_wino33_f32.hip -- the stride-1 3x3 / pad-1 convolutions of the fp32 PREDICT path (the Bottleneck conv2 of every
+// ResNet-50 block but the three strided ones, reference torchvision Bottleneck via robosat/unet.py:94,122-130, and dec5's
+// ConvRelu, unet.py:32-44,139) as a WINOGRAD F(2x2, 3x3) convolution: each 2x2 block of outputs comes from a 4x4 input patch
+// with 16 multiplies instead of 36,
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
+//     A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. 16 GEMMs [tiles x Cin] . [Cin x Cout] instead of 9 four times as tall: 4/9 of the multiply-adds.  Same reasoning and
+// same machinery as the DecoderBlock's Winograd form (conv_wino_f32.hip, which has the long version): the fp32 matrix cores
+// (157 TFLOP/s, v_mfma_f32_16x16x4_f32) are what bounds these layers at 0.75-0.84 of their peak in the generic kernel, the
+// vector ALU and the LDS have slack for the transforms.  Input and output transforms have +-1 coefficients, the filter
+// transform halves: nothing that matters in fp32 (the parity tests hold it to the generic kernel's bar).
+//
+//   block  = 8 waves, persistent (one per CU), work items = (16*TG tiles, 16*CG couts); a wave owns 16 tiles x 16 couts and
+//            keeps 16 accumulators (one per transformed position): 64 registers, two waves per SIMD.
+//   LDS    = per 16-channel chunk the block's source halo ((2*8 + 2)^2 pixels per 8x8 patch of tiles, 64 bytes each) + the
+//            transformed filters U[16][couts][16 ch] by LDS-DMA, double buffered, fetched one chunk ahead across work items.
+//   reads  = 16 ds_read_b128 for the lane's 4x4 patch, 32 vector add/sub for B^T d B, filter pieces one position ahead, 64
+//            MFMAs per chunk; rows even-x-first at pitch 18, pieces XOR-swizzled with (row ^ row >> 1) & 3, lanes -> tiles by
+//            a bit permutation: conflict-free for all 32 reads (exhaustive search; scripts/probes/wino_lds.py checks it).
+//   store  = A^T M A (+ the eval-mode BatchNorm's scale / shift, ReLU) from registers: 4 consecutive couts per lane.
+// Only the EVAL epilogue exists (predict, serve): the train-mode forward needs the raw output + BatchNorm partial sums and
+// stays on the generic kernel.  Chosen by layer geometry (>= 8 tiles per image side, i.e. H, W >= 15), never by batch size.
+#define RS_CONV_INSTANTIATE  // (for the LDS-DMA helpers of the header; no kernel of it is instantiated here)
+#include "conv_igemm_dma_kernel.h"
+
+namespace {
+
+struct Wino33Args {
+  const float* src;
+  const float* u;      // [16][Cout][Cin]
+  const float* scale;  // optional [Cout]
+  const float* shift;  // optional [Cout]
+  float* out;          // [N][H][W][Cout]
+  int N, H, W, Cin, Cout;
+  int BBY, BBX;  // 8x8 tile patches per image
+  int nsub;      // N * BBY * BBX
+  int ncb;       // cout blocks: Cout / BN
+  int relu;
+};
+
+constexpr int kPB = 8, kHW = 2 * kPB + 2, kPITCH = kHW, kHALF = kHW / 2;
+constexpr int kSBROWS = (kHW * kPITCH + 7) / 8 * 8;  // rows per sub-block, padded to the swizzle's period
+
+__device__ __forceinline__ int w33_lane_tile(int l) { return (l & 1) | (((l >> 1) & 1) << 2) | (((l >> 2) & 1) << 1) | (l & 8); }
+__device__ __forceinline__ int w33_swz(int row) { return (row ^ (row >> 1)) & 3; }
+
+template <int TG, int CG>
+__global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Args p) {
+  constexpr int NW = TG * CG;
+  static_assert(NW == 8, "8 waves");
+  constexpr int BMT = 16 * TG, BN = 16 * CG;
+  constexpr int SB = BMT / (kPB * kPB);
+  static_assert(SB * kPB * kPB == BMT, "whole sub-blocks per block");
+  constexpr int AROWS = SB * kSBROWS;
+  constexpr int IA = (AROWS + 15) / 16, IB = 16 * BN / 16;
+  constexpr int AROWS_PAD = IA * 16;
+  constexpr int NI = (IA + IB + NW - 1) / NW;
+  constexpr int STAGE = (AROWS_PAD + 16 * BN) * 64;
+  constexpr int KC = 16;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * AROWS_PAD * 4];
+  int* tabs = reinterpret_cast<int*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave % TG, cg = wave / TG;
+  const int per_img = p.BBY * p.BBX;
+  const int nk = p.Cin / KC;
+  const int ntiles = ((p.nsub + SB - 1) / SB) * p.ncb;
+  const int first = rs_xcd_remap(blockIdx.x, gridDim.x);
+  const int nitems = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
+  const unsigned int lds0 = __builtin_amdgcn_readfirstlane(rb_lds_addr(smem));
+  const long img = (long)p.H * p.W * p.Cin;
+
+  auto decode = [&](int it, int& mblk, int& nblk) __attribute__((always_inline)) {
+    mblk = it / p.ncb;
+    nblk = it - mblk * p.ncb;
+  };
+  auto build_table = [&](int seq) __attribute__((always_inline)) {
+    int mblk, nblk;
+    decode(first + seq * (int)gridDim.x, mblk, nblk);
+    const int sub0 = mblk * SB, nfirst = sub0 / per_img;
+    int* tab = tabs + (seq & 1) * AROWS_PAD;
+    for (int rho = tid; rho < AROWS_PAD; rho += 64 * NW) {
+      int v = -1;
+      if (rho < AROWS) {
+        const int sb = rho / kSBROWS, rem = rho - sb * kSBROWS;
+        const int hy = rem / kPITCH, xs = rem - hy * kPITCH;
+        const int hx = hy >= kHW ? -1 : (xs < kHALF ? 2 * xs : 2 * (xs - kHALF) + 1);
+        const int sub = sub0 + sb;
+        if (hx >= 0 && sub < p.nsub) {
+          const int n = sub / per_img, r2 = sub - n * per_img;
+          const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
+          const int y = 2 * bby * kPB - 1 + hy, x = 2 * bbx * kPB - 1 + hx;
+          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) v = ((n - nfirst) * p.H + y) * p.W + x;
+        }
+      }
+      tab[rho] = v;
+    }
+  };
+
+  // ---- fetch side (see conv_wino_f32.hip): one chunk ahead, across work items --------------------------------------------
+  const int ra = lane >> 2, pp = lane & 3;
+  int doff[NI];
+  int f_seq = 0, f_kc = 0, f_g = 0;
+  __amdgpu_buffer_rsrc_t rsrc = rb_make_rsrc(p.src, 0);
+  const __amdgpu_buffer_rsrc_t rsrcu = rb_make_rsrc(p.u, (long)16 * p.Cout * p.Cin * 4);
+  auto fetch_item = [&]() __attribute__((always_inline)) {
+    int mblk, nblk;
+    decode(first + f_seq * (int)gridDim.x, mblk, nblk);
+    const int nfirst = __builtin_amdgcn_readfirstlane((mblk * SB) / per_img);
+    rsrc = rb_make_rsrc(p.src + nfirst * img, (long)(p.N - nfirst) * img * 4);
+    const int* tab = tabs + (f_seq & 1) * AROWS_PAD;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int ii = wave + NW * j;
+      if (ii < IA) {
+        const int rho = 16 * ii + ra;
+        const int pix = tab[rho];
+        doff[j] = pix < 0 ? kDmaOOB : pix * (p.Cin * 4) + ((pp ^ w33_swz(rho)) & 3) * 16;
+      } else {
+        const int w = 16 * (ii - IA) + ra;  // filter row: xi * BN + cout
+        const int xi = w / BN, co = w - xi * BN;
+        doff[j] = ((xi * p.Cout + nblk * BN + co) * p.Cin) * 4 + ((pp ^ w33_swz(w)) & 3) * 16;
+      }
+    }
+  };
+  auto fetch_chunk = [&](auto interleave) __attribute__((always_inline)) {
+    if (f_kc == 0) fetch_item();
+    const unsigned int fL = lds0 + (f_g & 1) * STAGE;
+    const int fs = f_kc * KC * 4;
+    interleave([&](int j) __attribute__((always_inline)) {
+      const int ii = wave + NW * j;  // wave-uniform
+      if (ii < IA) rb_dma16s(rsrc, fL + ii * 1024, doff[j], fs);
+      else if (ii < IA + IB) rb_dma16s(rsrcu, fL + ii * 1024, doff[j], fs);
+    });
+    ++f_g;
+    if (++f_kc == nk) {
+      f_kc = 0;
+      ++f_seq;
+    }
+  };
+
+  // ---- fragment addressing: lane = tile (lane & 15) of the wave's 16, 16-byte piece (lane >> 4) ---------------------------
+  const int l15 = lane & 15, pc = lane >> 4;
+  const int t = 16 * tg + w33_lane_tile(l15);
+  const int tsb = t / (kPB * kPB), tq = t - tsb * (kPB * kPB);
+  const int tty = tq / kPB, ttx = tq - tty * kPB;
+  int addrA[4][4];
+  {
+    const int rho0 = tsb * kSBROWS + 2 * tty * kPITCH + ttx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int rho = rho0 + r * kPITCH + (c >> 1) + (c & 1) * kHALF;  // x = 2 ttx + c: even x first, then odd x
+        addrA[r][c] = rho * 64 + ((pc ^ w33_swz(rho)) & 3) * 16;
+      }
+  }
+  const int addrB = AROWS_PAD * 64 + (16 * cg + l15) * 64 + ((pc ^ w33_swz(l15)) & 3) * 16;  // + xi * BN * 64 (BN, 16 cg: multiples of 8)
+
+  build_table(0);
+  __syncthreads();
+  fetch_chunk([&](auto issue) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) issue(j);
+  });
+  const int total = nitems * nk;
+
+  int g = 0;
+  for (int seq = 0; seq < nitems; ++seq) {
+    f32x4 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < nk; ++kc, ++g) {
+      rb_dma_wait();
+      __syncthreads();
+      const unsigned char* L = smem + (g & 1) * STAGE;
+      f32x4 V[16];
+      {
+        f32x4 P[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) P[r][c] = *reinterpret_cast<const f32x4*>(L + addrA[r][c]);
+        f32x4 T[4][4];  // B^T d B: along x, then along y ([d0 - d2, d1 + d2, d2 - d1, d1 - d3] each way)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T[r][0] = P[r][0] - P[r][2];
+          T[r][1] = P[r][1] + P[r][2];
+          T[r][2] = P[r][2] - P[r][1];
+          T[r][3] = P[r][1] - P[r][3];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          V[0 * 4 + c] = T[0][c] - T[2][c];
+          V[1 * 4 + c] = T[1][c] + T[2][c];
+          V[2 * 4 + c] = T[2][c] - T[1][c];
+          V[3 * 4 + c] = T[1][c] - T[3][c];
+        }
+      }
+      const bool more = g + 1 < total;
+      constexpr int NMMA = 64, PSTEP = NMMA / NI >= 1 ? NMMA / NI : 1;
+      f32x4 Bq[16];
+      Bq[0] = *reinterpret_cast<const f32x4*>(L + addrB);
+      __builtin_amdgcn_sched_barrier(0);
+      auto mfmas = [&](auto issue) __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          if (x + 1 < 16) {
+            Bq[x + 1] = *reinterpret_cast<const f32x4*>(L + addrB + (x + 1) * BN * 64);
+            __builtin_amdgcn_sched_barrier(0);  // (keep the read in front of the MFMAs below)
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int q = x * 4 + k;
+            if (q % PSTEP == 0 && q / PSTEP < NI) issue(q / PSTEP);
+            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bq[x][k], V[x][k], acc[x], 0, 0, 0);
+          }
+        }
+      };
+      if (more) {
+        fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); });
+      } else {
+        mfmas([](int) {});
+      }
+      if (kc == 0 && seq + 1 < nitems) build_table(seq + 1);
+    }
+
+    // ---- Y = A^T M A (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3 each way), scale / shift, ReLU, store --------------------------
+    int mblk, nblk;
+    decode(first + seq * (int)gridDim.x, mblk, nblk);
+    const int sub = mblk * SB + tsb;
+    if (sub < p.nsub) {
+      const int n = sub / per_img, r2 = sub - n * per_img;
+      const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
+      const int a0 = 2 * (bby * kPB + tty), b0 = 2 * (bbx * kPB + ttx);
+      const int co = nblk * BN + 16 * cg + 4 * pc;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + co);
+      f32x4 R[2][4];  // rows transformed: R[u][b] = sum_a A^T[u][a] M[a][b]
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        R[0][b] = (acc[0 * 4 + b] + acc[1 * 4 + b]) + acc[2 * 4 + b];
+        R[1][b] = (acc[1 * 4 + b] - acc[2 * 4 + b]) - acc[3 * 4 + b];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int a = a0 + u, b = b0 + v;
+          if (a >= p.H || b >= p.W) continue;
+          f32x4 y = v == 0 ? (R[u][0] + R[u][1]) + R[u][2] : (R[u][1] - R[u][2]) - R[u][3];
+          y = y * sc + sh;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = y;
+        }
+    }
+  }
+}
+
+// U = G g G^T per (cout, cin): KRSC [Cout][3][3][Cin] -> [16][Cout][Cin]
+__global__ void pack_wino33_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [Cout][Cin]
+  if (i >= total) return;
+  const int ci = (int)(i % Cin), co = (int)(i / Cin);
+  const float* g = w + (long)co * 9 * Cin + ci;
+  float gg[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gg[r][c] = g[(long)(r * 3 + c) * Cin];
+  float t[4][3];  // G g
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    t[0][c] = gg[0][c];
+    t[1][c] = 0.5f * ((gg[0][c] + gg[1][c]) + gg[2][c]);
+    t[2][c] = 0.5f * ((gg[0][c] - gg[1][c]) + gg[2][c]);
+    t[3][c] = gg[2][c];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v[4] = {t[r][0], 0.5f * ((t[r][0] + t[r][1]) + t[r][2]), 0.5f * ((t[r][0] - t[r][1]) + t[r][2]), t[r][2]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[((long)(r * 4 + c) * Cout + co) * Cin + ci] = v[c];
+  }
+}
+
+int w33_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return cus;
+  }();
+  return n;
+}
+
+// 0: cannot run; 1: can and should; (there is no "can but should not": the form needs >= 8 tiles per image side to run at all)
+int w33_plan(const rs_conv_desc* d, int* cgroups) {
+  if (!d || d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->C1 < 32 || (d->C1 % 16) || d->C2 != 0 || d->Cout <= 0 || (d->Cout % 16)) return 0;
+  if (!(d->ups == 0 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->Hs && d->Wo == d->Ws && !d->stem)) return 0;
+  if ((d->Hs + 1) / 2 < kPB || (d->Ws + 1) / 2 < kPB) return 0;
+  *cgroups = (d->Cout % 32 == 0) ? 2 : 1;
+  const int sb = 16 * (8 / *cgroups) / (kPB * kPB);
+  if ((long)(sb + 1) * d->Hs * d->Ws * d->C1 * 4 >= (1L << 31)) return 0;
+  if ((long)16 * d->Cout * d->C1 * 4 >= (1L << 31)) return 0;
+  if ((long)d->N * d->Ho * d->Wo * d->Cout >= (1L << 62)) return 0;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int rs_conv2d_wino33_ok(const rs_conv_desc* d) {
+  int cgn;
+  return w33_plan(d, &cgn);
+}
+
+extern "C" const char* rs_conv2d_wino33_name(const rs_conv_desc* d) {
+  int cgn;
+  if (!w33_plan(d, &cgn)) return "";
+  return cgn == 2 ? "conv_wino_f32<3x3,p8,64x32>" : "conv_wino_f32<3x3,p8,128x16>";
+}
+
+extern "C" int rs_pack_wino33_weight(const float* w_krsc, float* u, int Cout, int Cin, rs_stream_t stream) {
+  if (!w_krsc || !u || Cout <= 0 || Cin <= 0) return RS_EINVAL;
+  const long total = (long)Cout * Cin;
+  pack_wino33_weight_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w_krsc, u, Cout, Cin, total);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
+                                    float* out, rs_stream_t stream) {
+  int cgn;
+  if (!w33_plan(d, &cgn) || !src || !u || !out) return RS_EINVAL;
+  Wino33Args a;
+  a.src = src;
+  a.u = u;
+  a.scale = scale;
+  a.shift = shift;
+  a.out = out;
+  a.N = d->N;
+  a.H = d->Hs;
+  a.W = d->Ws;
+  a.Cin = d->C1;
+  a.Cout = d->Cout;
+  a.BBY = rs_cdiv((d->Hs + 1) / 2, kPB);
+  a.BBX = rs_cdiv((d->Ws + 1) / 2, kPB);
+  a.nsub = d->N * a.BBY * a.BBX;
+  a.ncb = d->Cout / (16 * cgn);
+  a.relu = d->relu;
+  const int sb = 16 * (8 / cgn) / (kPB * kPB);
+  const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
+  if (items >= (1L << 31)) return RS_EINVAL;
+  const int grid = (int)(items < w33_cus() ? items : w33_cus());
+  hipStream_t s = (hipStream_t)stream;
+  if (cgn == 2) conv_wino33_f32_kernel<4, 2><<<grid, 512, 0, s>>>(a);
+  else conv_wino33_f32_kernel<8, 1><<<grid, 512, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}

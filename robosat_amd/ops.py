@@ -386,6 +386,54 @@ def conv2d_phase_wino(src1, u, src2=None, relu=False):
     return out
 
 
+def _conv33_desc(src, cout, relu):
+    n, h, w, c = src.shape
+    return ConvDesc(n, h, w, c, 0, 0, 3, 3, 1, 1, h, w, cout, int(relu), 0)
+
+
+def wino33_ok(src, cout):
+    """Whether the fp32 Winograd F(2x2, 3x3) kernel runs a stride-1 3x3 / pad-1 convolution of ``src`` to ``cout`` channels
+    (``rs_conv2d_wino33_ok``: the layer's geometry only, never the batch size); ROBOSAT_WINOGRAD=0 switches it off."""
+
+    import os
+
+    if src.dtype != torch.float32 or os.environ.get("ROBOSAT_WINOGRAD", "1") == "0":
+        return False
+    return _lib.lib().rs_conv2d_wino33_ok(ctypes.byref(_conv33_desc(src, cout, False))) == 1
+
+
+def pack_wino33_weight(w_krsc):
+    """fp32 KRSC [Cout,3,3,Cin] -> U = G g G^T, [16,Cout,Cin]: the transformed filters of the F(2x2, 3x3) form."""
+
+    cout, kh, kw, cin = w_krsc.shape
+    assert kh == 3 and kw == 3
+    u = torch.empty((16, cout, cin), device=w_krsc.device, dtype=torch.float32)
+    check(_lib.lib().rs_pack_wino33_weight(_dev(w_krsc, "w"), _dev(u, "u"), cout, cin, _stream()), "rs_pack_wino33_weight")
+    return u
+
+
+def conv2d_wino33(src, u, scale=None, shift=None, relu=False):
+    """relu?(conv3x3(src, pad 1) * scale + shift) in fp32 as a Winograd F(2x2, 3x3) convolution (``rs_conv2d_fwd_wino33``):
+    the eval-mode Bottleneck conv2 / dec5 of the predict path; 4/9 of the direct form's multiply-adds."""
+
+    n, h, w, c = src.shape
+    cout = u.shape[1]
+    assert tuple(u.shape) == (16, cout, c)
+    d = _conv33_desc(src, cout, relu)
+    out = torch.empty((n, h, w, cout), device=src.device, dtype=torch.float32)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv2d_fwd_wino33(ctypes.byref(d), _dev(src, "src"), _dev(u, "u"), _dev(scale, "scale"), _dev(shift, "shift"),
+                                         _dev(out, "out"), _stream())
+    check(rc, "rs_conv2d_fwd_wino33")
+    if PROFILE is not None:
+        ev1.record()
+        name = _lib.lib().rs_conv2d_wino33_name(ctypes.byref(d)).decode()
+        _record(name, conv_flops(d), (d.C1, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, conv_bytes(d, 4), conv_flops(d) * 4.0 / 9.0)
+    return out
+
+
 def conv_tile_name(d, bf16=False, phase=False):
     """Report name of the kernel a convolution launch runs, 1:1 with the launched symbol:
     ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel)."""

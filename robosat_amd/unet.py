@@ -92,6 +92,17 @@ class _Conv(nn.Module):
             self._phase_wino = c
         return c[1]
 
+    def wino33(self):
+        """The transformed filters U = G g G^T of the fp32 Winograd F(2x2, 3x3) form (``rs_pack_wino33_weight``), cached like
+        ``phase``."""
+
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0])
+        c = getattr(self, "_wino33", None)
+        if c is None or c[0] != key:
+            c = (key, ops.pack_wino33_weight(self.krsc()))
+            self._wino33 = c
+        return c[1]
+
     def dgrad_phase(self, dtype=torch.float32):
         """Weights of the phase form's data gradient (one 4x4 / stride-2 convolution over dz, ``rs_pack_dgrad_phase_weight_dt``),
         cached like ``phase``."""
@@ -205,6 +216,15 @@ class DecoderBlock(nn.Module):
     def __init__(self, num_in, num_out):
         super().__init__()
         self.block = ConvRelu(num_in, num_out)
+
+
+def conv3x3_eval(conv, x, dt, scale=None, shift=None):
+    """relu(conv3x3(x, pad 1) * scale + shift) of the eval-mode forward: a stride-1 Bottleneck conv2 with its folded BatchNorm,
+    or dec5.  fp32 and large enough: the Winograd F(2x2, 3x3) kernel; else the generic implicit GEMM."""
+
+    if dt == torch.float32 and conv.stride == 1 and ops.wino33_ok(x, conv.cout):
+        return ops.conv2d_wino33(x, conv.wino33(), scale=scale, shift=shift, relu=True)
+    return ops.conv2d(x, conv.krsc(dt), stride=conv.stride, pad=1, scale=scale, shift=shift, relu=True)
 
 
 def decoder_block(conv, skip, prev, dt):
@@ -508,7 +528,7 @@ class UNet(nn.Module):
                 sc, sh = blk.bn1.folded()
                 o = ops.conv2d(h, blk.conv1.krsc(dt), scale=sc, shift=sh, relu=True)
                 sc, sh = blk.bn2.folded()
-                o = ops.conv2d(o, blk.conv2.krsc(dt), stride=blk.stride, pad=1, scale=sc, shift=sh, relu=True)
+                o = conv3x3_eval(blk.conv2, o, dt, scale=sc, shift=sh)
                 if blk.downsample is not None:
                     sc, sh = blk.downsample[1].folded()
                     idt = ops.conv2d(h, blk.downsample[0].krsc(dt), stride=blk.stride, scale=sc, shift=sh)
@@ -528,7 +548,7 @@ class UNet(nn.Module):
         dec2 = up(self.dec2, enc2, dec1)
         dec3 = up(self.dec3, enc1, dec2)
         dec4 = up(self.dec4, dec3)
-        dec5 = ops.conv2d(dec4, self.dec5.block.krsc(dt), pad=1, relu=True)
+        dec5 = conv3x3_eval(self.dec5.block, dec4, dt)
 
         wf = self.final.weight.detach().reshape(self.num_classes, -1)
         if argmax:

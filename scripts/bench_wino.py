@@ -49,3 +49,36 @@ for name, c1, c2, cout, hs in layers:
         name, c1, c2, cout, hs, res["phase"], flops * 4 / 9 / res["phase"] / 1e9,
         "{:7.3f} ms ({:6.1f} TF exec, x{:.2f})".format(res["wino"], flops / 4 / res["wino"] / 1e9, res["phase"] / res["wino"]) if res["wino"] else "   n/a", err))
 print("sum: phase {:.3f} ms, wino {:.3f} ms".format(tot["phase"], tot["wino"]))
+
+# the eval-mode stride-1 3x3 convolutions: generic implicit GEMM vs Winograd F(2x2, 3x3)
+tot = {"gen": 0.0, "wino": 0.0}
+for name, c, hs, count in (("layer1.conv2", 64, s // 4, 3), ("layer2.conv2", 128, s // 8, 3), ("layer3.conv2", 256, s // 16, 5),
+                           ("layer4.conv2", 512, s // 32, 2), ("dec5", 32, s, 1)):
+    x = torch.randn(a.batch, hs, hs, c, device=dev)
+    w = torch.randn(c, 3, 3, c, device=dev) * (2.0 / (9 * c)) ** 0.5
+    sc, sh = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
+    u = ops.pack_wino33_weight(w)
+    flops = 2.0 * a.batch * c * c * 9 * hs * hs
+    res = {}
+    for kind, fn in (("gen", lambda: ops.conv2d(x, w, pad=1, scale=sc, shift=sh, relu=True)),
+                     ("wino", (lambda: ops.conv2d_wino33(x, u, scale=sc, shift=sh, relu=True)) if ops.wino33_ok(x, c) else None)):
+        if fn is None:
+            res[kind] = None
+            continue
+        for _ in range(2):
+            out = fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[kind] = e0.elapsed_time(e1) / a.iters
+        tot[kind] += res[kind] * count
+    if res["wino"] is None:
+        tot["wino"] += res["gen"] * count
+    err = float((ops.conv2d(x, w, pad=1, scale=sc, shift=sh, relu=True) - ops.conv2d_wino33(x, u, scale=sc, shift=sh, relu=True)).abs().max()) if res["wino"] else float("nan")
+    print("{:13s} {:4d}->{:<4d} @{:<4d} x{}  generic {:7.3f} ms ({:6.1f} TF)  wino {} | max|diff| {:.2e}".format(
+        name, c, c, hs, count, res["gen"], flops / res["gen"] / 1e9,
+        "{:7.3f} ms ({:6.1f} TF exec, x{:.2f})".format(res["wino"], flops * 4 / 9 / res["wino"] / 1e9, res["gen"] / res["wino"]) if res["wino"] else "   n/a", err))
+print("sum over the pass: generic {:.3f} ms, wino {:.3f} ms".format(tot["gen"], tot["wino"]))

@@ -68,7 +68,50 @@ def check(pb, tg, cg):
     return worst, 2 * (apad + 9 * bn) * 64 + 2 * apad * 4
 
 
+def check33(tg, cg):
+    """conv_wino33_f32.hip: 8x8 patches of tiles, halo 18 x 18 at pitch 18, 4x4 patch reads, 16 filter positions."""
+    pb, hw, half, pitch = 8, 18, 9, 18
+    sbrows = (hw * pitch + 7) // 8 * 8
+    bmt, bn = 16 * tg, 16 * cg
+    sb = bmt // (pb * pb)
+    arows = sb * sbrows
+    apad = (arows + 15) // 16 * 16
+    worst = 0
+
+    def lane_tile33(l):
+        return (l & 1) | (((l >> 1) & 1) << 2) | (((l >> 2) & 1) << 1) | (l & 8)
+
+    for wtg in range(tg):
+        for r in range(4):
+            for c in range(4):
+                def addr(lane):
+                    l15, pc = lane & 15, lane >> 4
+                    t = 16 * wtg + lane_tile33(l15)
+                    tsb, tq = divmod(t, pb * pb)
+                    tty, ttx = divmod(tq, pb)
+                    rho = tsb * sbrows + 2 * tty * pitch + ttx + r * pitch + (c >> 1) + (c & 1) * half
+                    rem = rho - tsb * sbrows
+                    hy, xs = divmod(rem, pitch)
+                    hx = 2 * xs if xs < half else 2 * (xs - half) + 1
+                    assert (hy, hx) == (2 * tty + r, 2 * ttx + c) and rho < arows
+                    return rho * 64 + ((pc ^ swz(rho)) & 3) * 16
+                worst = max(worst, degree(addr))
+    for wcg in range(cg):
+        for x in range(16):
+            def addrb(lane):
+                l15, pc = lane & 15, lane >> 4
+                row = x * bn + 16 * wcg + l15
+                assert swz(row) == swz(l15)
+                return apad * 64 + row * 64 + ((pc ^ swz(row)) & 3) * 16
+            worst = max(worst, degree(addrb))
+    return worst, 2 * (apad + 16 * bn) * 64 + 2 * apad * 4
+
+
 if __name__ == "__main__":
+    for cfg in ((4, 2), (8, 1)):
+        w, lds = check33(*cfg)
+        print("3x3  TG {} CG {}: worst conflict degree {}, LDS bytes {}".format(*cfg, w, lds))
+        assert w == 1
     for cfg in ((8, 4, 2), (8, 8, 1), (4, 4, 2), (4, 8, 1)):
         w, lds = check(*cfg)
         print("PB {} TG {} CG {}: worst conflict degree {}, LDS bytes {}".format(*cfg, w, lds))

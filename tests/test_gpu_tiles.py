@@ -359,3 +359,56 @@ def test_winograd_declines_what_it_cannot_run():
     assert ops.wino_ok(small, None, 64, force=True) and not ops.wino_ok(small, None, 64)
     # the choice is the layer's geometry, never the batch size: a tile's output must not depend on its batch neighbours
     assert ops.wino_ok(torch.zeros(1, 16, 16, 64, device=DEV), None, 64) and ops.wino_ok(torch.zeros(16, 16, 16, 64, device=DEV), None, 64)
+
+
+# ---- fp32 Winograd F(2x2, 3x3): the eval-mode stride-1 3x3 convolutions (conv_wino33_f32.hip) ---------------------------------------
+WINO33 = {"conv_wino_f32<3x3,p8,64x32>", "conv_wino_f32<3x3,p8,128x16>"}
+COVERED |= WINO33
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,want,epi", [
+    (2, 64, 64, 16, 16, "64x32", "bn"),      # one 8x8 patch of tiles per image, folded BatchNorm + ReLU (Bottleneck.conv2)
+    (3, 48, 96, 20, 36, "64x32", "bn"),      # ragged patches (10 x 18 tiles), 16-channel chunks that are not 32-multiples
+    (2, 32, 32, 40, 24, "64x32", "relu"),    # dec5's shape class: two chunks, ReLU only
+    (5, 64, 48, 15, 17, "128x16", "none"),   # odd sizes (last tile row / column past the image), Cout % 32 != 0, blocks that straddle images
+    (1, 128, 64, 64, 48, "64x32", "bn"),     # many patches per image
+])
+def test_winograd_3x3_vs_fp32_reference(n, cin, cout, h, w, want, epi):
+    """relu(conv3x3(x, pad 1) * scale + shift) through the Winograd F(2x2, 3x3) kernel against plain PyTorch fp32 and against
+    the generic implicit-GEMM kernel on the same launch (2e-4 of the output scale, the generic kernel's own bar)."""
+    from robosat_amd import ops
+
+    x = rnd(n, cin, h, w, seed=61)
+    wt = rnd(cout, cin, 3, 3, seed=62) * (2.0 / (cin * 9)) ** 0.5
+    sc = (rnd(cout, seed=63) * 0.2 + 1.0) if epi == "bn" else None
+    sh = rnd(cout, seed=64) * 0.3 if epi == "bn" else None
+    ref = F.conv2d(x, wt, padding=1)
+    if epi == "bn":
+        ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if epi != "none":
+        ref = F.relu(ref)
+    s = nhwc(x, torch.float32)
+    wk = krsc(wt, torch.float32)
+    assert ops.wino33_ok(s, cout)
+    dsc, dsh = (sc.to(DEV), sh.to(DEV)) if epi == "bn" else (None, None)
+    ops.PROFILE = []
+    try:
+        got = ops.conv2d_wino33(s, ops.pack_wino33_weight(wk), scale=dsc, shift=dsh, relu=epi != "none")
+        torch.cuda.synchronize()
+        name = ops.PROFILE[0][0]
+    finally:
+        ops.PROFILE = None
+    assert name == "conv_wino_f32<3x3,p8,{}>".format(want) and name in COVERED, name
+    close(nchw(got), ref, torch.float32, "winograd 3x3 vs fp32 reference")
+    if cin % 32 == 0 and cout % 32 == 0:
+        generic = ops.conv2d(s, wk, pad=1, scale=dsc, shift=dsh, relu=epi != "none")
+        assert float((got - generic).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_winograd_3x3_declines_what_it_cannot_run():
+    from robosat_amd import ops
+
+    assert not ops.wino33_ok(torch.zeros(4, 8, 8, 64, device=DEV), 64)          # < 8 tiles per side
+    assert not ops.wino33_ok(torch.zeros(4, 32, 32, 16, device=DEV), 64)        # one chunk only
+    assert not ops.wino33_ok(torch.zeros(4, 32, 32, 64, device=DEV, dtype=BF), 64)
+    assert ops.wino33_ok(torch.zeros(1, 16, 16, 64, device=DEV), 64) and ops.wino33_ok(torch.zeros(16, 16, 16, 64, device=DEV), 64)

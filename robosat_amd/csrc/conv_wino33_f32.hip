@@ -125,8 +125,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       }
     }
   };
-  auto fetch_chunk = [&](auto interleave) __attribute__((always_inline)) {
-    if (f_kc == 0) fetch_item();
+  // (`past`: beyond the block's last chunk the previous pieces are issued again into the free stage; see conv_wino_f32.hip)
+  auto fetch_chunk = [&](auto interleave, bool past) __attribute__((always_inline)) {
+    if (!past && f_kc == 0) fetch_item();
     const unsigned int fL = lds0 + (f_g & 1) * STAGE;
     const int fs = f_kc * KC * 4;
     interleave([&](int j) __attribute__((always_inline)) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       else if (ii < IA + IB) rb_dma16s(rsrcu, fL + ii * 1024, doff[j], fs);
     });
     ++f_g;
-    if (++f_kc == nk) {
+    if (!past && ++f_kc == nk) {
       f_kc = 0;
       ++f_seq;
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   fetch_chunk([&](auto issue) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) issue(j);
-  });
+  }, false);
   const int total = nitems * nk;
 
   int g = 0;
@@ -220,11 +221,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
           }
         }
       };
-      if (more) {
-        fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); });
-      } else {
-        mfmas([](int) {});
-      }
+      fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); }, !more);
       if (kc == 0 && seq + 1 < nitems) build_table(seq + 1);
     }
 
@@ -262,6 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
         }
     }
   }
+  rb_dma_wait();  // (the re-issued pieces of the last chunk: landed before this block's LDS is handed to the next one)
 }
 
 // U = G g G^T per (cout, cin): KRSC [Cout][3][3][Cin] -> [16][Cout][Cin]

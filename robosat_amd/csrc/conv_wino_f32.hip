@@ -180,11 +180,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       }
     }
   };
-  auto fetch_chunk = [&](auto interleave) __attribute__((always_inline)) {  // issue chunk (f_seq, f_kc) into stage f_g & 1, then advance
+  // issue chunk (f_seq, f_kc) into stage f_g & 1, then advance.  Past the block's last chunk (`past`: once, during its very
+  // last MFMAs) the previous chunk's pieces are simply issued again into the free stage -- nobody reads them, and the MFMA
+  // loop needs no second, fetch-less copy of itself (which cost registers: hipcc kept the two copies' live ranges apart).
+  auto fetch_chunk = [&](auto interleave, bool past) __attribute__((always_inline)) {
     const int c0 = f_kc * KC;
     const bool src_first = c0 < p.C1;
-    if (f_kc == 0) fetch_item();
-    if (c0 == 0 || c0 == p.C1) set_source(src_first);
+    if (!past) {
+      if (f_kc == 0) fetch_item();
+      if (c0 == 0 || c0 == p.C1) set_source(src_first);
+    }
     const unsigned int fL = lds0 + (f_g & 1) * STAGE;
     const int fsa = (src_first ? c0 : c0 - p.C1) * 4, fsu = c0 * 4;
     interleave([&](int j) __attribute__((always_inline)) {
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       }
     });
     ++f_g;
-    if (++f_kc == nk) {
+    if (!past && ++f_kc == nk) {
       f_kc = 0;
       ++f_seq;
     }
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
   fetch_chunk([&](auto issue) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) issue(j);
-  });
+  }, false);
   const int total = nitems * nk;
   const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
 
@@ -294,11 +299,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
             }
         }
       };
-      if (more) {
-        fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); });
-      } else {
-        mfmas([](int) {});
-      }
+      fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); }, !more);
+
       if (kc == 0 && seq + 1 < nitems) build_table(seq + 1);  // (its buffer held item seq - 1's table: the fetch side left it a whole item ago)
     }
 
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
         }
     }
   }
+  rb_dma_wait();  // (the re-issued pieces of the last chunk: landed before this block's LDS is handed to the next one)
 }
 
 // U = G g G^T per (parity, cout, cin): phase pack [4][Cout][2][2][Cin] -> [4][9][Cout][Cin]

@@ -16,8 +16,9 @@ def leg(name, d):
     par = d.get("parity")
     if par:
         extra += " | parity max|dp| {:.2e}".format(par["max_abs_vs_oracle"])
-    print("{:34s} {:9.1f} tiles/s  {:8.3f} ms/step (min {} med {} max {}, n {}){}".format(
-        name, d["value"], d["ms_per_step"], sm.get("min"), sm.get("median"), sm.get("max"), sm.get("n"), extra))
+    stall = " STALLED x{} (slowest: step {})".format(sm.get("stalled_steps"), sm.get("slowest_step_index")) if sm.get("stalled_steps") else ""
+    print("{:34s} {:9.1f} tiles/s  {:8.3f} ms/step (min {} med {} max {}, n {}){}{}".format(
+        name, d["value"], d["ms_per_step"], sm.get("min"), sm.get("median"), sm.get("max"), sm.get("n"), stall, extra))
 
 
 def main():

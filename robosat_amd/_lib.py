@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_void_p
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librobosat_hip.so")
+# (ROBOSAT_HIP_LIB: another build of the same ABI, for A/B runs of a kernel change on one box -- never a different backend)
+LIB_PATH = os.environ.get("ROBOSAT_HIP_LIB") or os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
 ABI_VERSION = 18

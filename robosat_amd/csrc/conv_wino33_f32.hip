@@ -38,6 +38,18 @@ struct Wino33Args {
   int relu;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 adds / subtractions per instruction (v_pk_add_f32; hipcc emits it for a + b but mostly not for a - b)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 constexpr int kPB = 8, kHW = 2 * kPB + 2, kPITCH = kHW, kHALF = kHW / 2;
 constexpr int kSBROWS = (kHW * kPITCH + 7) / 8 * 8;  // rows per sub-block, padded to the swizzle's period
 
@@ -180,25 +192,37 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       const unsigned char* L = smem + (g & 1) * STAGE;
       f32x4 V[16];
       {
-        f32x4 P[4][4];
+        // (the transform on 2-float halves: hipcc turns those into v_pk_add_f32 -- two lanes' worth of fp32 adds per
+        //  instruction -- where the 4-float form came out as scalar v_sub_f32)
+        f32x2 Pl[4][4], Ph[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) P[r][c] = *reinterpret_cast<const f32x4*>(L + addrA[r][c]);
-        f32x4 T[4][4];  // B^T d B: along x, then along y ([d0 - d2, d1 + d2, d2 - d1, d1 - d3] each way)
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(L + addrA[r][c]);
+            Pl[r][c] = f32x2{q[0], q[1]};
+            Ph[r][c] = f32x2{q[2], q[3]};
+          }
+        f32x2 Tl[4][4], Th[4][4];  // B^T d B: along x, then along y ([d0 - d2, d1 + d2, d2 - d1, d1 - d3] each way)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          T[r][0] = P[r][0] - P[r][2];
-          T[r][1] = P[r][1] + P[r][2];
-          T[r][2] = P[r][2] - P[r][1];
-          T[r][3] = P[r][1] - P[r][3];
+          Tl[r][0] = pk_sub(Pl[r][0], Pl[r][2]);
+          Tl[r][1] = pk_add(Pl[r][1], Pl[r][2]);
+          Tl[r][2] = pk_sub(Pl[r][2], Pl[r][1]);
+          Tl[r][3] = pk_sub(Pl[r][1], Pl[r][3]);
+          Th[r][0] = pk_sub(Ph[r][0], Ph[r][2]);
+          Th[r][1] = pk_add(Ph[r][1], Ph[r][2]);
+          Th[r][2] = pk_sub(Ph[r][2], Ph[r][1]);
+          Th[r][3] = pk_sub(Ph[r][1], Ph[r][3]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          V[0 * 4 + c] = T[0][c] - T[2][c];
-          V[1 * 4 + c] = T[1][c] + T[2][c];
-          V[2 * 4 + c] = T[2][c] - T[1][c];
-          V[3 * 4 + c] = T[1][c] - T[3][c];
+          const f32x2 l0 = pk_sub(Tl[0][c], Tl[2][c]), l1 = pk_add(Tl[1][c], Tl[2][c]), l2 = pk_sub(Tl[2][c], Tl[1][c]), l3 = pk_sub(Tl[1][c], Tl[3][c]);
+          const f32x2 h0 = pk_sub(Th[0][c], Th[2][c]), h1 = pk_add(Th[1][c], Th[2][c]), h2 = pk_sub(Th[2][c], Th[1][c]), h3 = pk_sub(Th[1][c], Th[3][c]);
+          V[0 * 4 + c] = f32x4{l0[0], l0[1], h0[0], h0[1]};
+          V[1 * 4 + c] = f32x4{l1[0], l1[1], h1[0], h1[1]};
+          V[2 * 4 + c] = f32x4{l2[0], l2[1], h2[0], h2[1]};
+          V[3 * 4 + c] = f32x4{l3[0], l3[1], h3[0], h3[1]};
         }
       }
       const bool more = g + 1 < total;

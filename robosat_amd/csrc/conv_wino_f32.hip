@@ -79,6 +79,12 @@ __device__ __forceinline__ int wino_lane_tile(int l) {
   if constexpr (PB == 8) return ((l & 1) << 1) | (((l >> 1) & 1) << 2) | ((l >> 2) & 1) | (l & 8);
   return ((l & 1) << 1) | (((l >> 1) & 1) << 3) | ((l >> 2) & 1) | (((l >> 3) & 1) << 2);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {  // a - b on two floats: v_pk_add_f32 with the second operand negated
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ int wino_swz(int row) { return (row ^ (row >> 1)) & 3; }  // 16-byte piece c of a row is stored at c ^ swz(row)
 
 // TG tile groups (16 tiles each) x CG cout groups (32 couts each) = 8 waves per block
@@ -264,21 +270,30 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
 #pragma unroll
       for (int m = 0; m < 2; ++m) Bq[0][m] = *reinterpret_cast<const f32x4*>(L + addrB + (16 * m) * 64);
       __builtin_amdgcn_sched_barrier(0);
-      // V = B^T d B: along x, then along y ([d0 - d1, d1, d2 - d1] each way)
+      // V = B^T d B: along x, then along y ([d0 - d1, d1, d2 - d1] each way), on 2-float halves with v_pk_add_f32 (two fp32
+      // subtractions per instruction; written as 4-float vector code hipcc emits scalar v_sub_f32: measured -4 % on the 3x3 form)
       f32x4 V[9];
       {
-        f32x4 T[3][3];
+        f32x2 Tl[3][3], Th[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          T[r][0] = P[r][0] - P[r][1];
-          T[r][1] = P[r][1];
-          T[r][2] = P[r][2] - P[r][1];
+          const f32x2 l0 = {P[r][0][0], P[r][0][1]}, h0 = {P[r][0][2], P[r][0][3]};
+          const f32x2 l1 = {P[r][1][0], P[r][1][1]}, h1 = {P[r][1][2], P[r][1][3]};
+          const f32x2 l2 = {P[r][2][0], P[r][2][1]}, h2 = {P[r][2][2], P[r][2][3]};
+          Tl[r][0] = pk_sub(l0, l1);
+          Tl[r][1] = l1;
+          Tl[r][2] = pk_sub(l2, l1);
+          Th[r][0] = pk_sub(h0, h1);
+          Th[r][1] = h1;
+          Th[r][2] = pk_sub(h2, h1);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          V[0 * 3 + c] = T[0][c] - T[1][c];
-          V[1 * 3 + c] = T[1][c];
-          V[2 * 3 + c] = T[2][c] - T[1][c];
+          const f32x2 a = pk_sub(Tl[0][c], Tl[1][c]), b = pk_sub(Tl[2][c], Tl[1][c]);
+          const f32x2 d = pk_sub(Th[0][c], Th[1][c]), e = pk_sub(Th[2][c], Th[1][c]);
+          V[0 * 3 + c] = f32x4{a[0], a[1], d[0], d[1]};
+          V[1 * 3 + c] = f32x4{Tl[1][c][0], Tl[1][c][1], Th[1][c][0], Th[1][c][1]};
+          V[2 * 3 + c] = f32x4{b[0], b[1], e[0], e[1]};
         }
       }
       auto mfmas = [&](auto issue) __attribute__((always_inline)) {

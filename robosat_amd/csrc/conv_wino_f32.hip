@@ -88,12 +88,13 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {  // a - b on two flo
 __device__ __forceinline__ int wino_swz(int row) { return (row ^ (row >> 1)) & 3; }  // 16-byte piece c of a row is stored at c ^ swz(row)
 
 // TG tile groups (16 tiles each) x CG cout groups (32 couts each) = 8 waves per block
-template <int PB, int TG, int CG>
+// NM = MFMA tiles of 16 couts per wave (a wave owns 16 tiles x 16*NM couts)
+template <int PB, int TG, int CG, int NM = 2>
 __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p) {
   using G = WinoGeom<PB>;
   constexpr int NW = TG * CG;
   static_assert(NW == 8, "8 waves");
-  constexpr int BMT = 16 * TG, BN = 32 * CG;
+  constexpr int BMT = 16 * TG, BN = 16 * NM * CG;
   constexpr int SB = BMT / (PB * PB);
   static_assert(SB * PB * PB == BMT, "whole sub-blocks per block");
   constexpr int AROWS = SB * G::SBROWS;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       }
   }
   // filter rows xi * BN + 32 cg + 16 m + l15: BN and 16 are multiples of 8, so the swizzle only sees l15
-  const int addrB = AROWS_PAD * 64 + (32 * cg + l15) * 64 + ((pc ^ wino_swz(l15)) & 3) * 16;  // + (xi * BN + 16 m) * 64
+  const int addrB = AROWS_PAD * 64 + (16 * NM * cg + l15) * 64 + ((pc ^ wino_swz(l15)) & 3) * 16;  // + (xi * BN + 16 m) * 64
 
   build_table(0);
   __syncthreads();
@@ -244,11 +245,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
 
   int g = 0;
   for (int seq = 0; seq < nitems; ++seq) {
-    f32x4 acc[9][2];
+    f32x4 acc[9][NM];
 #pragma unroll
     for (int x = 0; x < 9; ++x)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < NM; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kc = 0; kc < nk; ++kc, ++g) {
       rb_dma_wait();
@@ -263,12 +264,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       // LDS-DMA pieces of the NEXT chunk, spread evenly over this chunk's MFMAs: the CU's DMA path moves ~23 B/clk and this
       // kernel needs ~12 B/clk of it (55 KB per 4608 MFMA cycles); issued in a burst the pieces queue up and hold the issuing
       // waves (front-loading them was measured: no gain)
-      constexpr int NMMA = 72, PSTEP = NMMA / NI >= 1 ? NMMA / NI : 1;
+      constexpr int NMMA = 36 * NM, PSTEP = NMMA / NI >= 1 ? NMMA / NI : 1;
       // filter pieces are fetched one transformed position ahead of the MFMAs that use them (the first pair goes out before
       // the transform's vector ops): in source order hipcc otherwise parks an LDS round trip in front of every group of 8 MFMAs
-      f32x4 Bq[9][2];
+      f32x4 Bq[9][NM];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) Bq[0][m] = *reinterpret_cast<const f32x4*>(L + addrB + (16 * m) * 64);
+      for (int m = 0; m < NM; ++m) Bq[0][m] = *reinterpret_cast<const f32x4*>(L + addrB + (16 * m) * 64);
       __builtin_amdgcn_sched_barrier(0);
       // V = B^T d B: along x, then along y ([d0 - d1, d1, d2 - d1] each way), on 2-float halves with v_pk_add_f32 (two fp32
       // subtractions per instruction; written as 4-float vector code hipcc emits scalar v_sub_f32: measured -4 % on the 3x3 form)
@@ -301,14 +302,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
         for (int x = 0; x < 9; ++x) {
           if (x + 1 < 9) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) Bq[x + 1][m] = *reinterpret_cast<const f32x4*>(L + addrB + ((x + 1) * BN + 16 * m) * 64);
+            for (int m = 0; m < NM; ++m) Bq[x + 1][m] = *reinterpret_cast<const f32x4*>(L + addrB + ((x + 1) * BN + 16 * m) * 64);
             __builtin_amdgcn_sched_barrier(0);  // (keep these reads in front of the MFMAs below: hipcc sinks them to their first use)
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const int q = (x * 4 + k) * 2 + m;  // MFMA index within the chunk (compile-time)
+            for (int m = 0; m < NM; ++m) {
+              const int q = (x * 4 + k) * NM + m;  // MFMA index within the chunk (compile-time)
               if (q % PSTEP == 0 && q / PSTEP < NI) issue(q / PSTEP);
               acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bq[x][m][k], V[x][k], acc[x][m], 0, 0, 0);
             }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       const int n = sub / per_img, r2 = sub - n * per_img;
       const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
       const int a0 = 2 * (bby * PB + tty), b0 = 2 * (bbx * PB + ttx);
-      float* obase = p.out + nblk * BN + 32 * cg + 4 * pc;
+      float* obase = p.out + nblk * BN + 16 * NM * cg + 4 * pc;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
           if (a >= p.Hs || b >= p.Ws) continue;
           float* o = obase + ((long)(n * Ho + 2 * a + py) * Wo + 2 * b + px) * p.Cout;
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < NM; ++m) {
             f32x4 y = (acc[u * 3 + v][m] + acc[u * 3 + v + 1][m]) + (acc[(u + 1) * 3 + v][m] + acc[(u + 1) * 3 + v + 1][m]);
             if (p.relu) {
 #pragma unroll
@@ -374,10 +375,16 @@ int wino_cus() {
   return n;
 }
 
+bool wino_wide() {  // (A/B knob while the wide block is being measured: ROBOSAT_WINO_WIDE=0 keeps 64 tiles x 64 couts)
+  static const bool w = !(getenv("ROBOSAT_WINO_WIDE") && atoi(getenv("ROBOSAT_WINO_WIDE")) == 0);
+  return w;
+}
+
 struct WinoPlan {
   int pb, wgn;  // 8 | 4; 2 (64 couts per block) | 1 (32)
   int sb;       // sub-blocks per block
   bool worth;   // enough work items to fill the chip (else the generic phase kernel is the faster choice)
+  bool wide;    // 128 tiles x 64 couts per block instead of 64 x 64 (see wino_plan)
 };
 
 bool wino_plan(const rs_conv_desc* d, WinoPlan* pl) {
@@ -402,6 +409,17 @@ bool wino_plan(const rs_conv_desc* d, WinoPlan* pl) {
   // full 8x8 patch of tiles per image side at least (Hs, Ws >= 15): with fewer, a block's tiles straddle images and the
   // persistent one-block-per-CU grid is short of work items at any batch size (`center` at 512^2: 0.32 vs 0.21 ms).
   pl->worth = pl->pb == 8;
+  // Block shape for the 64-cout layers: 128 tiles x 64 couts (a wave = 16 tiles x 64 couts: twice the MFMAs per transformed
+  // patch and per filter byte; +3-5 % on dec1-dec3) when that still leaves two work items per CU, else 64 tiles x 64 couts
+  // (dec0 at bs 16: 128 wide items on 256 CUs would halve the chip).  Either shape accumulates every output in the same order
+  // -- they differ in which wave computes what --, so the choice may depend on the batch size without making a tile's
+  // output depend on it.
+  pl->wide = false;
+  if (pl->pb == 8 && pl->wgn == 2 && wino_wide()) {
+    const long nsub = (long)d->N * rs_cdiv(ty, 8) * rs_cdiv(tx, 8);
+    pl->wide = (nsub + 1) / 2 * (d->Cout / 64) * 4 >= 2L * wino_cus();
+    if (pl->wide) pl->sb = 2;
+  }
   return true;
 }
 
@@ -416,7 +434,7 @@ extern "C" int rs_conv2d_phase_wino_ok(const rs_conv_desc* d) {
 extern "C" const char* rs_conv2d_phase_wino_name(const rs_conv_desc* d) {
   WinoPlan pl;
   if (!wino_plan(d, &pl)) return "";
-  if (pl.pb == 8) return pl.wgn == 2 ? "conv_wino_f32<phase,p8,64x64>" : "conv_wino_f32<phase,p8,128x32>";
+  if (pl.pb == 8) return pl.wide ? "conv_wino_f32<phase,p8,128x64>" : (pl.wgn == 2 ? "conv_wino_f32<phase,p8,64x64>" : "conv_wino_f32<phase,p8,128x32>");
   return pl.wgn == 2 ? "conv_wino_f32<phase,p4,64x64>" : "conv_wino_f32<phase,p4,128x32>";
 }
 
@@ -454,7 +472,8 @@ extern "C" int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1
   // persistent: one block per CU (its LDS stages fill the CU), items dealt round-robin
   const int grid = (int)(items < wino_cus() ? items : wino_cus());
   hipStream_t s = (hipStream_t)stream;
-  if (pl.pb == 8 && pl.wgn == 2) conv_wino_f32_kernel<8, 4, 2><<<grid, 512, 0, s>>>(a);
+  if (pl.wide) conv_wino_f32_kernel<8, 8, 1, 4><<<grid, 512, 0, s>>>(a);  // 128 tiles x 64 couts
+  else if (pl.pb == 8 && pl.wgn == 2) conv_wino_f32_kernel<8, 4, 2><<<grid, 512, 0, s>>>(a);
   else if (pl.pb == 8) conv_wino_f32_kernel<8, 8, 1><<<grid, 512, 0, s>>>(a);
   else if (pl.wgn == 2) conv_wino_f32_kernel<4, 4, 2><<<grid, 512, 0, s>>>(a);
   else conv_wino_f32_kernel<4, 8, 1><<<grid, 512, 0, s>>>(a);

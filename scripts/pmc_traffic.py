@@ -29,9 +29,9 @@ def bench_name(k):
         return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "f" else "bf16",
                                                   "phase," if m.group(5) == "1" else "", m.group(2), m.group(3), m.group(4))
     # per-instantiation names, spelled as bench.py reports them (ops.wgrad_kernel_name / conv_tile_name / rs_conv2d_phase_wino_name)
-    m = re.search(r"conv_wino_f32_kernel<(\d+), (\d+), (\d+)>", k)
+    m = re.search(r"conv_wino_f32_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?>", k)
     if m:
-        return "conv_wino_f32<phase,p{},{}x{}>".format(m.group(1), 16 * int(m.group(2)), 32 * int(m.group(3)))
+        return "conv_wino_f32<phase,p{},{}x{}>".format(m.group(1), 16 * int(m.group(2)), 16 * int(m.group(4) or 2) * int(m.group(3)))
     m = re.search(r"conv_wino33_f32_kernel<(\d+), (\d+)>", k)
     if m:
         return "conv_wino_f32<3x3,p8,{}x{}>".format(16 * int(m.group(1)), 16 * int(m.group(2)))

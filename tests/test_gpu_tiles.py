@@ -305,7 +305,8 @@ def test_bench_symbols_are_covered(tmp_path):
 
 
 # ---- fp32 Winograd form of DecoderBlock (conv_wino_f32.hip) --------------------------------------------------------------------
-WINO = {"conv_wino_f32<phase,p8,64x64>", "conv_wino_f32<phase,p8,128x32>", "conv_wino_f32<phase,p4,64x64>", "conv_wino_f32<phase,p4,128x32>"}
+WINO = {"conv_wino_f32<phase,p8,64x64>", "conv_wino_f32<phase,p8,128x64>", "conv_wino_f32<phase,p8,128x32>",
+        "conv_wino_f32<phase,p4,64x64>", "conv_wino_f32<phase,p4,128x32>"}
 COVERED |= WINO
 
 
@@ -316,6 +317,7 @@ COVERED |= WINO
     (5, 32, 32, 96, 8, 8, "p4,128x32"),      # 4x4-tile patches, 8 per block, blocks that straddle images, Cout % 64 != 0
     (3, 64, 0, 64, 9, 13, "p4,64x64"),       # odd sizes: ragged last tile row / column (positions past the image), center's class
     (1, 32, 16, 64, 64, 48, "p8,64x64"),     # many patches per image
+    (8, 32, 0, 128, 64, 60, "p8,128x64"),    # enough work items for the 128-tile block (two patches per block, ragged last patch row)
 ])
 def test_winograd_phase_form_vs_fp32_reference(n, c1, c2, cout, h, w, want):
     """relu(conv3x3(interpolate(cat[a, b], x2), pad 1)) through the Winograd F(2x2, 2x2) kernel against plain PyTorch fp32 --
@@ -347,6 +349,9 @@ def test_winograd_phase_form_vs_fp32_reference(n, c1, c2, cout, h, w, want):
     got2 = ops.conv2d_phase_wino(s1, ops.pack_wino_phase_weight(wp), src2=s2, relu=False)
     ref2 = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, padding=1)
     close(nchw(got2), ref2, torch.float32, "winograd, no relu")
+    if want == "p8,128x64":  # the two block shapes of a 64-cout layer accumulate every output in the same order: bit-identical
+        small = ops.conv2d_phase_wino(s1[:1], ops.pack_wino_phase_weight(wp), src2=None if s2 is None else s2[:1], relu=True)
+        assert torch.equal(small[0], got[0])  # (N = 1: too few work items for the wide block -> the 64 x 64 one ran)
 
 
 def test_winograd_declines_what_it_cannot_run():

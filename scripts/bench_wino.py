@@ -13,8 +13,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--wino-only", action="store_true", help="time the Winograd kernels only and print a bit checksum of their outputs (A/B of block shapes)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+torch.manual_seed(0)
 s = a.size
 layers = [("center", 2048, 0, 256, s // 64), ("dec0", 2048, 256, 256, s // 32), ("dec1", 1024, 256, 256, s // 16),
           ("dec2", 512, 256, 64, s // 8), ("dec3", 256, 64, 128, s // 4), ("dec4", 128, 0, 32, s // 2)]
@@ -26,6 +28,24 @@ for name, c1, c2, cout, hs in layers:
     wp = ops.pack_phase_weight(w)
     u = ops.pack_wino_phase_weight(wp)
     flops = 2.0 * a.batch * cout * (c1 + c2) * 9 * (2 * hs) ** 2
+    if a.wino_only:
+        fn = lambda: ops.conv2d_phase_wino(x1, u, src2=x2, relu=True)
+        if not ops.wino_ok(x1, x2, cout, force=True):
+            continue
+        ops.PROFILE = []
+        out = fn()
+        torch.cuda.synchronize()
+        kname, ops.PROFILE = ops.PROFILE[0][0], None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        tot["wino"] += ms
+        print("{:7s} {:32s} {:7.3f} ms ({:6.1f} TF exec) bits {}".format(name, kname, ms, flops / 4 / ms / 1e9, int(out.view(torch.int32).long().sum())))
+        continue
     res = {}
     for kind, fn in (("phase", lambda: ops.conv2d_phase(x1, wp, src2=x2, relu=True)),
                      ("wino", (lambda: ops.conv2d_phase_wino(x1, u, src2=x2, relu=True)) if ops.wino_ok(x1, x2, cout, force=True) else None)):
@@ -59,6 +79,24 @@ for name, c, hs, count in (("layer1.conv2", 64, s // 4, 3), ("layer2.conv2", 128
     sc, sh = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
     u = ops.pack_wino33_weight(w)
     flops = 2.0 * a.batch * c * c * 9 * hs * hs
+    if a.wino_only:
+        fn = lambda: ops.conv2d_wino33(x, u, scale=sc, shift=sh, relu=True)
+        if not ops.wino33_ok(x, c):
+            continue
+        ops.PROFILE = []
+        out = fn()
+        torch.cuda.synchronize()
+        kname, ops.PROFILE = ops.PROFILE[0][0], None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        tot["wino"] += ms * count
+        print("{:13s} {:32s} {:7.3f} ms x{} ({:6.1f} TF exec) bits {}".format(name, kname, ms, count, flops * 4 / 9 / ms / 1e9, int(out.view(torch.int32).long().sum())))
+        continue
     res = {}
     for kind, fn in (("gen", lambda: ops.conv2d(x, w, pad=1, scale=sc, shift=sh, relu=True)),
                      ("wino", (lambda: ops.conv2d_wino33(x, u, scale=sc, shift=sh, relu=True)) if ops.wino33_ok(x, c) else None)):

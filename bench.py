@@ -564,7 +564,8 @@ def main():
             # `roofline.frac` is on the FLOPs the kernels EXECUTE; SURVEY.md section 8d's algorithmic count rides along as
             # `roofline.algorithmic` (its 100 %-of-peak ceiling of 941 tiles/s can be exceeded: see `flops_basis`)
             "flops_basis": "executed (the DecoderBlock phase form runs 4/9 of the section-8d algorithmic multiply-adds: conv3x3 over a "
-                           "nearest-x2 upsample == four 2x2 convolutions on the source grid with pre-summed taps)",
+                           "nearest-x2 upsample == four 2x2 convolutions on the source grid with pre-summed taps; its fp32 Winograd "
+                           "F(2x2,2x2) form 1/4; the fp32 eval stride-1 3x3 layers as Winograd F(2x2,3x3) 4/9)",
             "roofline": roof, "parity": parity(),
         }
     del step  # (the cached blocks stay with the allocator: the next leg reuses them instead of a new round of hipFree / hipMalloc)

@@ -313,6 +313,20 @@ const char* rs_conv2d_wino33_name(const rs_conv_desc* d);
 int rs_pack_wino33_weight(const float* w_krsc, float* u, int Cout, int Cin, rs_stream_t stream);
 int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift, float* out,
                          rs_stream_t stream);
+/* dec5 + self.final (+ softmax / quantise / argmax) of the fp32 predict path in ONE launch (reference unet.py:139-141:
+ * `dec5 = self.dec5(dec4); return self.final(dec5)`; tools/predict.py:87-103; tools/serve.py:160-164): rs_conv2d_fwd_wino33 on
+ * a 32-cout layer whose block keeps its 32 channels on the CU, applies the 1x1 convolution final_w [C][32] + final_b [C] (C <= 8)
+ * and then does what rs_final_conv1x1_dt (mode 0 logits / 1 softmax -> `out` fp32 NCHW [N][C][H][W]),
+ * rs_final_conv1x1_quantize_dt (mode 2 -> `qout`, needs `anchors` and `overlap`) or rs_final_conv1x1_argmax_dt (mode 3 ->
+ * `qout` [N][H][W]) do with a pixel's logits -- same operations in the same order; the logits themselves differ from the
+ * two-launch form by fp32 summation order over the 32 channels.  The layer's own output is never written (537 MB per
+ * bs-16 512^2 batch that the two-launch form writes and reads back).  rs_conv2d_wino33_head_ok: 1 if this form runs `d`
+ * with C classes (rs_conv2d_wino33_ok, Cout == 32, 1 <= C <= 8). */
+int rs_conv2d_wino33_head_ok(const rs_conv_desc* d, int C);
+const char* rs_conv2d_wino33_head_name(void);
+int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
+                              const float* final_w, const float* final_b, int C, int mode, const double* anchors, int overlap,
+                              float* out, uint8_t* qout, rs_stream_t stream);
 
 /* ... and its data gradient: d loss / d (pre-upsample input) is ONE 4x4 / stride-2 / pad-1 convolution over dz with
  * pre-summed taps (rs_conv2d_fwd[_bf16] with kh = kw = 4 and these weights, [Cin][4][4][Cout]): the gradient lands at

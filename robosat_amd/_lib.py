@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROBOSAT_HIP_LIB") or os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 18
+ABI_VERSION = 19
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -102,6 +102,9 @@ SIGNATURES = {
     "rs_conv2d_wino33_name": (c_char_p, [POINTER(ConvDesc)]),
     "rs_pack_wino33_weight": (c_int, [P, P, c_int, c_int, P]),
     "rs_conv2d_fwd_wino33": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    "rs_conv2d_wino33_head_ok": (c_int, [POINTER(ConvDesc), c_int]),
+    "rs_conv2d_wino33_head_name": (c_char_p, []),
+    "rs_conv2d_fwd_wino33_head": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_int, c_int, P, c_int, P, P, P]),
     "rs_pack_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_combine_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_split_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, c_int, P]),

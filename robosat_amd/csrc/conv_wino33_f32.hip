@@ -22,6 +22,7 @@
 // stays on the generic kernel.  Chosen by layer geometry (>= 8 tiles per image side, i.e. H, W >= 15), never by batch size.
 #define RS_CONV_INSTANTIATE  // (for the LDS-DMA helpers of the header; no kernel of it is instantiated here)
 #include "conv_igemm_dma_kernel.h"
+#include "final_head.h"
 
 namespace {
 
@@ -36,6 +37,14 @@ struct Wino33Args {
   int nsub;      // N * BBY * BBX
   int ncb;       // cout blocks: Cout / BN
   int relu;
+  // HEAD instantiation only -- dec5 + `self.final` (+ softmax / quantise / argmax) in one launch (reference unet.py:139-141,
+  // tools/predict.py:87-103): the block's 32 couts never leave the CU, `out` is not written
+  const float* hw;         // final.weight [hC][32]
+  const float* hb;         // final.bias [hC] or null
+  const double* hanchors;  // np.linspace(0, 1, 256) (mode 2)
+  float* hout;             // NCHW fp32 logits / probabilities (modes 0, 1)
+  unsigned char* hq;       // quantised probabilities (mode 2) / class indices (mode 3)
+  int hC, hmode, hov;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -56,10 +65,11 @@ constexpr int kSBROWS = (kHW * kPITCH + 7) / 8 * 8;  // rows per sub-block, padd
 __device__ __forceinline__ int w33_lane_tile(int l) { return (l & 1) | (((l >> 1) & 1) << 2) | (((l >> 2) & 1) << 1) | (l & 8); }
 __device__ __forceinline__ int w33_swz(int row) { return (row ^ (row >> 1)) & 3; }
 
-template <int TG, int CG>
+template <int TG, int CG, bool HEAD = false>
 __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Args p) {
   constexpr int NW = TG * CG;
   static_assert(NW == 8, "8 waves");
+  static_assert(!HEAD || (TG == 4 && CG == 2), "the fused head: one 8x8 patch of tiles x all 32 couts per block");
   constexpr int BMT = 16 * TG, BN = 16 * CG;
   constexpr int SB = BMT / (kPB * kPB);
   static_assert(SB * kPB * kPB == BMT, "whole sub-blocks per block");
@@ -70,8 +80,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   constexpr int STAGE = (AROWS_PAD + 16 * BN) * 64;
   constexpr int KC = 16;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * AROWS_PAD * 4];
+  // HEAD: + the class weights [8][32] and biases [8], + the exchange of the two cout groups' partial logits [tile][pixel][8]
+  //       (two exchange buffers: an item's second half runs behind the first barrier of the block's NEXT item)
+  constexpr int HEADW = kHeadMaxC * 32 + kHeadMaxC, XCH = BMT * 4 * kHeadMaxC;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * AROWS_PAD * 4 + (HEAD ? (HEADW + 2 * XCH) * 4 : 0)];
   int* tabs = reinterpret_cast<int*>(smem + 2 * STAGE);
+  float* hws = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * AROWS_PAD * 4);
+  float* xch = hws + HEADW;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,6 +187,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   }
   const int addrB = AROWS_PAD * 64 + (16 * cg + l15) * 64 + ((pc ^ w33_swz(l15)) & 3) * 16;  // + xi * BN * 64 (BN, 16 cg: multiples of 8)
 
+  if constexpr (HEAD) {
+    for (int f = threadIdx.x; f < HEADW; f += 64 * NW) {
+      const int c = f < kHeadMaxC * 32 ? f / 32 : f - kHeadMaxC * 32;
+      hws[f] = c >= p.hC ? 0.f : (f < kHeadMaxC * 32 ? p.hw[f] : (p.hb ? p.hb[c] : 0.f));
+    }
+  }
   build_table(0);
   __syncthreads();
   fetch_chunk([&](auto issue) __attribute__((always_inline)) {
@@ -179,6 +200,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
     for (int j = 0; j < NI; ++j) issue(j);
   }, false);
   const int total = nitems * nk;
+
+  // HEAD: the cg = 0 lanes' pixel of the previous item, waiting for the other cout group's half (finish_head)
+  float hmine[kHeadMaxC];
+  long hpix = -1;
+  int hbuf = 0;
+  auto finish_head = [&]() __attribute__((always_inline)) {
+    if constexpr (HEAD) {
+      if (cg == 0) {
+        const float* xrow = xch + hbuf * XCH + (16 * tg + l15) * (4 * kHeadMaxC) + pc * kHeadMaxC;
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(xrow), o1 = *reinterpret_cast<const f32x4*>(xrow + 4);
+        float lg[kHeadMaxC];
+#pragma unroll
+        for (int c = 0; c < kHeadMaxC; ++c) lg[c] = (hmine[c] + (c < 4 ? o0[c] : o1[c - 4])) + hws[kHeadMaxC * 32 + c];
+        if (hpix >= 0) rs_final_epilogue_rt(lg, p.hC, hpix, (long)p.H * p.W, p.hmode, p.hanchors, p.hq, p.hout, p.W, p.hov);
+      }
+    }
+  };
 
   int g = 0;
   for (int seq = 0; seq < nitems; ++seq) {
@@ -189,6 +227,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
     for (int kc = 0; kc < nk; ++kc, ++g) {
       rb_dma_wait();
       __syncthreads();
+      if (HEAD && kc == 0 && seq > 0) finish_head();  // (behind this barrier the other cout group's partial logits are in LDS)
       const unsigned char* L = smem + (g & 1) * STAGE;
       f32x4 V[16];
       {
@@ -253,11 +292,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
     int mblk, nblk;
     decode(first + seq * (int)gridDim.x, mblk, nblk);
     const int sub = mblk * SB + tsb;
-    if (sub < p.nsub) {
-      const int n = sub / per_img, r2 = sub - n * per_img;
-      const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
-      const int a0 = 2 * (bby * kPB + tty), b0 = 2 * (bbx * kPB + ttx);
-      const int co = nblk * BN + 16 * cg + 4 * pc;
+    const bool live = sub < p.nsub;
+    const int n = sub / per_img, r2 = sub - n * per_img;
+    const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
+    const int a0 = 2 * (bby * kPB + tty), b0 = 2 * (bbx * kPB + ttx);
+    const int co = nblk * BN + 16 * cg + 4 * pc;
+    f32x4 Y[2][2];
+    if (live || HEAD) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + co);
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + co);
@@ -271,17 +312,69 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-          const int a = a0 + u, b = b0 + v;
-          if (a >= p.H || b >= p.W) continue;
           f32x4 y = v == 0 ? (R[u][0] + R[u][1]) + R[u][2] : (R[u][1] - R[u][2]) - R[u][3];
           y = y * sc + sh;
           if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
           }
-          *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = y;
+          Y[u][v] = y;
         }
     }
+    if constexpr (!HEAD) {
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const int a = a0 + u, b = b0 + v;
+            if (a >= p.H || b >= p.W) continue;
+            *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = Y[u][v];
+          }
+      }
+    } else {
+      // ---- self.final on the block's 32 channels: this lane's 4 couts -> the wave's 16 (lanes l15 + 16 pc) -> both cout
+      //      groups (waves tg and tg + TG, through LDS) + bias; then one pixel per lane of the cg = 0 waves (pixel pc of tile
+      //      l15).  The order of the sums is fixed by the layout, not by the batch.
+      float part[4][kHeadMaxC];
+#pragma unroll
+      for (int c = 0; c < kHeadMaxC; ++c) {
+        if (c < p.hC) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(hws + c * 32 + 16 * cg + 4 * pc);
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            const f32x4 y = Y[px >> 1][px & 1];
+            float v = fmaf(y[3], wv[3], fmaf(y[2], wv[2], fmaf(y[1], wv[1], y[0] * wv[0])));
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            part[px][c] = v;
+          }
+        } else {
+#pragma unroll
+          for (int px = 0; px < 4; ++px) part[px][c] = 0.f;
+        }
+      }
+      // the cg = 1 half goes to LDS; the cg = 0 lanes keep their pixel's half and finish it behind the next barrier (the first
+      // chunk of the block's next item, or the one after the loop): no barrier of its own, and the softmax + stores run
+      // beside the other waves' MFMAs
+      hbuf = seq & 1;
+      if (cg == 1 && pc == 0) {
+        float* xrow = xch + hbuf * XCH + (16 * tg + l15) * (4 * kHeadMaxC);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          *reinterpret_cast<f32x4*>(xrow + px * kHeadMaxC) = f32x4{part[px][0], part[px][1], part[px][2], part[px][3]};
+          *reinterpret_cast<f32x4*>(xrow + px * kHeadMaxC + 4) = f32x4{part[px][4], part[px][5], part[px][6], part[px][7]};
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kHeadMaxC; ++c) hmine[c] = pc == 0 ? part[0][c] : (pc == 1 ? part[1][c] : (pc == 2 ? part[2][c] : part[3][c]));
+      const int a = a0 + (pc >> 1), b = b0 + (pc & 1);
+      hpix = (live && a < p.H && b < p.W) ? (long)(n * p.H + a) * p.W + b : -1;
+    }
+  }
+  if constexpr (HEAD) {
+    __syncthreads();
+    if (nitems > 0) finish_head();
   }
   rb_dma_wait();  // (the re-issued pieces of the last chunk: landed before this block's LDS is handed to the next one)
 }
@@ -349,6 +442,14 @@ extern "C" const char* rs_conv2d_wino33_name(const rs_conv_desc* d) {
   return cgn == 2 ? "conv_wino_f32<3x3,p8,64x32>" : "conv_wino_f32<3x3,p8,128x16>";
 }
 
+// dec5 + self.final: the Winograd form must run the layer as ONE cout block of 32 (dec5: num_filters = 32, unet.py:104-108)
+extern "C" int rs_conv2d_wino33_head_ok(const rs_conv_desc* d, int C) {
+  int cgn;
+  return w33_plan(d, &cgn) && cgn == 2 && d->Cout == 32 && C >= 1 && C <= kHeadMaxC;
+}
+
+extern "C" const char* rs_conv2d_wino33_head_name(void) { return "conv_wino_f32<3x3+final,p8,64x32>"; }
+
 extern "C" int rs_pack_wino33_weight(const float* w_krsc, float* u, int Cout, int Cin, rs_stream_t stream) {
   if (!w_krsc || !u || Cout <= 0 || Cin <= 0) return RS_EINVAL;
   const long total = (long)Cout * Cin;
@@ -376,6 +477,11 @@ extern "C" int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, con
   a.nsub = d->N * a.BBY * a.BBX;
   a.ncb = d->Cout / (16 * cgn);
   a.relu = d->relu;
+  a.hw = a.hb = nullptr;
+  a.hanchors = nullptr;
+  a.hout = nullptr;
+  a.hq = nullptr;
+  a.hC = a.hmode = a.hov = 0;
   const int sb = 16 * (8 / cgn) / (kPB * kPB);
   const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
   if (items >= (1L << 31)) return RS_EINVAL;
@@ -383,5 +489,47 @@ extern "C" int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, con
   hipStream_t s = (hipStream_t)stream;
   if (cgn == 2) conv_wino33_f32_kernel<4, 2><<<grid, 512, 0, s>>>(a);
   else conv_wino33_f32_kernel<8, 1><<<grid, 512, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}
+
+// rs_conv2d_fwd_wino33 on a 32-cout layer + `self.final` (1x1, C classes, bias) + what rs_final_conv1x1_dt /
+// rs_final_conv1x1_quantize_dt / rs_final_conv1x1_argmax_dt do with the logits, in one launch: mode 0 logits / 1 softmax ->
+// `out` fp32 NCHW [N][C][H][W]; 2 -> `qout` = quantised probabilities of the un-buffered crop (`anchors`, `overlap`);
+// 3 -> `qout` = class indices [N][H][W].  The layer's own output never reaches memory.
+extern "C" int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
+                                         const float* final_w, const float* final_b, int C, int mode, const double* anchors,
+                                         int overlap, float* out, uint8_t* qout, rs_stream_t stream) {
+  if (!rs_conv2d_wino33_head_ok(d, C) || !src || !u || !final_w || mode < 0 || mode > 3) return RS_EINVAL;
+  if (mode <= 1 ? !out : !qout) return RS_EINVAL;
+  if (mode == 2 && (!anchors || C < 2 || overlap < 0 || 2 * overlap >= d->Hs || 2 * overlap >= d->Ws)) return RS_EINVAL;
+  if (mode == 3 && C < 2) return RS_EINVAL;
+  Wino33Args a;
+  a.src = src;
+  a.u = u;
+  a.scale = scale;
+  a.shift = shift;
+  a.out = nullptr;
+  a.N = d->N;
+  a.H = d->Hs;
+  a.W = d->Ws;
+  a.Cin = d->C1;
+  a.Cout = d->Cout;
+  a.BBY = rs_cdiv((d->Hs + 1) / 2, kPB);
+  a.BBX = rs_cdiv((d->Ws + 1) / 2, kPB);
+  a.nsub = d->N * a.BBY * a.BBX;
+  a.ncb = 1;
+  a.relu = d->relu;
+  a.hw = final_w;
+  a.hb = final_b;
+  a.hanchors = anchors;
+  a.hout = out;
+  a.hq = qout;
+  a.hC = C;
+  a.hmode = mode;
+  a.hov = overlap;
+  const long items = a.nsub;
+  if (items >= (1L << 31)) return RS_EINVAL;
+  const int grid = (int)(items < w33_cus() ? items : w33_cus());
+  conv_wino33_f32_kernel<4, 2, true><<<grid, 512, 0, (hipStream_t)stream>>>(a);
   return RS_LAUNCH_RESULT();
 }

@@ -434,6 +434,52 @@ def conv2d_wino33(src, u, scale=None, shift=None, relu=False):
     return out
 
 
+def wino33_head_ok(src, cout, classes):
+    """Whether dec5 + ``self.final`` run as one launch (``rs_conv2d_wino33_head_ok``: the Winograd 3x3 form on a 32-cout
+    layer, <= 8 classes); ROBOSAT_FUSED_HEAD=0 keeps the two launches (A/B runs)."""
+
+    import os
+
+    if not wino33_ok(src, cout) or os.environ.get("ROBOSAT_FUSED_HEAD", "1") == "0":
+        return False
+    return _lib.lib().rs_conv2d_wino33_head_ok(ctypes.byref(_conv33_desc(src, cout, True)), int(classes)) == 1
+
+
+def conv2d_wino33_head(src, u, final_w, final_b, mode="logits", overlap=0, relu=True):
+    """``final(relu(conv3x3(src, pad 1)))`` in one launch (``rs_conv2d_fwd_wino33_head``; reference unet.py:139-141) and, by
+    ``mode``, what the ``final_conv1x1*`` functions return: "logits" / "softmax" -> fp32 NCHW [N,C,H,W]; "quantize" ->
+    uint8 quantised probabilities of the crop without the ``overlap`` border; "argmax" -> uint8 [N,H,W] class indices."""
+
+    n, h, w, c = src.shape
+    cout, classes = u.shape[1], final_w.shape[0]
+    assert tuple(u.shape) == (16, cout, c) and tuple(final_w.shape) == (classes, cout)
+    d = _conv33_desc(src, cout, relu)
+    m = {"logits": 0, "softmax": 1, "quantize": 2, "argmax": 3}[mode]
+    out = qout = anchors = None
+    if m <= 1:
+        out = torch.empty((n, classes, h, w), device=src.device, dtype=torch.float32)
+    elif m == 2:
+        shape = (n, h - 2 * overlap, w - 2 * overlap) + ((classes - 1,) if classes > 2 else ())
+        qout = torch.empty(shape, device=src.device, dtype=torch.uint8)
+        anchors = _anchors(src.device)
+    else:
+        qout = torch.empty((n, h, w), device=src.device, dtype=torch.uint8)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv2d_fwd_wino33_head(
+        ctypes.byref(d), _dev(src, "src"), _dev(u, "u"), None, None, _dev(final_w, "final_w"), _dev(final_b, "final_b"), classes, m,
+        _dev(anchors, "anchors", torch.float64), int(overlap), _dev(out, "out"), _dev(qout, "qout", torch.uint8), _stream())
+    check(rc, "rs_conv2d_fwd_wino33_head")
+    if PROFILE is not None:
+        ev1.record()
+        fl = conv_flops(d) + 2.0 * n * h * w * cout * classes  # (the 1x1 rides along: < 1 % of the launch)
+        nbytes = 4 * (n * h * w * c + 9 * cout * c + classes * cout) + (4 * classes if m <= 1 else 1) * n * h * w
+        _record(_lib.lib().rs_conv2d_wino33_head_name().decode(), fl, (d.C1, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                nbytes, conv_flops(d) * 4.0 / 9.0 + 2.0 * n * h * w * cout * classes)
+    return out if m <= 1 else qout
+
+
 def conv_tile_name(d, bf16=False, phase=False):
     """Report name of the kernel a convolution launch runs, 1:1 with the launched symbol:
     ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel)."""

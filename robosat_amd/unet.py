@@ -548,9 +548,13 @@ class UNet(nn.Module):
         dec2 = up(self.dec2, enc2, dec1)
         dec3 = up(self.dec3, enc1, dec2)
         dec4 = up(self.dec4, dec3)
-        dec5 = conv3x3_eval(self.dec5.block, dec4, dt)
-
         wf = self.final.weight.detach().reshape(self.num_classes, -1)
+        if dt == torch.float32 and ops.wino33_head_ok(dec4, self.dec5.block.cout, self.num_classes):
+            # dec5 + final (+ softmax / quantise / argmax) in one launch: dec5's output never leaves the CU (unet.py:139-141)
+            mode = "argmax" if argmax else ("quantize" if quantize_overlap is not None else ("softmax" if softmax else "logits"))
+            return ops.conv2d_wino33_head(dec4, self.dec5.block.wino33(), wf, self.final.bias.detach(), mode,
+                                          overlap=quantize_overlap or 0)
+        dec5 = conv3x3_eval(self.dec5.block, dec4, dt)
         if argmax:
             return ops.final_conv1x1_argmax(dec5, wf, self.final.bias.detach())
         if quantize_overlap is not None:

@@ -410,6 +410,82 @@ def test_winograd_3x3_vs_fp32_reference(n, cin, cout, h, w, want, epi):
         assert float((got - generic).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
 
 
+COVERED |= {"conv_wino_f32<3x3+final,p8,64x32>"}
+
+
+@pytest.mark.parametrize("n,h,w,classes", [(2, 32, 48, 2), (3, 17, 31, 4), (1, 64, 64, 5), (2, 40, 24, 8)])
+def test_fused_dec5_final_head_vs_two_launches(n, h, w, classes):
+    """dec5 + final (+ softmax / quantise / argmax) in one launch (conv_wino33_f32<.., HEAD>) against the two-launch form
+    (Winograd dec5, then final_conv1x1*) and against plain PyTorch fp32: reference unet.py:139-141, tools/predict.py:87-103."""
+    from robosat_amd import ops
+
+    x = rnd(n, 32, h, w, seed=71)
+    wt = rnd(32, 32, 3, 3, seed=72) * (2.0 / (32 * 9)) ** 0.5
+    wf = rnd(classes, 32, seed=73) * 0.5
+    bf = rnd(classes, seed=74) * 0.2
+    s, u = nhwc(x, torch.float32), ops.pack_wino33_weight(krsc(wt, torch.float32))
+    dwf, dbf = wf.to(DEV).contiguous(), bf.to(DEV).contiguous()
+    assert ops.wino33_head_ok(s, 32, classes)
+    ref_logits = F.conv2d(F.relu(F.conv2d(x, wt, padding=1)), wf.view(classes, 32, 1, 1), bf)
+    dec5 = ops.conv2d_wino33(s, u, relu=True)
+    ops.PROFILE = []
+    try:
+        logits = ops.conv2d_wino33_head(s, u, dwf, dbf, "logits")
+        torch.cuda.synchronize()
+        name = ops.PROFILE[0][0]
+    finally:
+        ops.PROFILE = None
+    assert name == "conv_wino_f32<3x3+final,p8,64x32>" and name in COVERED
+    two = ops.final_conv1x1(dec5, dwf, dbf, softmax=False)
+    assert logits.shape == two.shape == (n, classes, h, w)
+    scale = max(1.0, float(ref_logits.abs().max()))
+    assert float((logits.cpu() - ref_logits).abs().max()) <= 2e-5 * scale
+    assert float((logits - two).abs().max()) <= 5e-6 * scale  # (summation order over the 32 channels)
+    probs = ops.conv2d_wino33_head(s, u, dwf, dbf, "softmax")
+    assert float((probs - ops.final_conv1x1(dec5, dwf, dbf, softmax=True)).abs().max()) <= 5e-6
+    assert float((probs.cpu() - torch.softmax(ref_logits, 1)).abs().max()) <= 2e-5
+    # argmax: equal wherever the two best logits are not within rounding of each other
+    am, am2 = ops.conv2d_wino33_head(s, u, dwf, dbf, "argmax"), ops.final_conv1x1_argmax(dec5, dwf, dbf)
+    top2 = torch.topk(two, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * scale
+    assert am.shape == (n, h, w) and bool((am == am2)[clear].all()) and float(clear.float().mean()) > 0.99
+    # quantised probabilities of the crop: the same bytes except where a probability sits within rounding of a bin edge
+    for ov in (0, 3):
+        q, q2 = ops.conv2d_wino33_head(s, u, dwf, dbf, "quantize", overlap=ov), ops.final_conv1x1_quantize(dec5, dwf, dbf, ov)
+        assert q.shape == q2.shape and q.dtype == torch.uint8
+        diff = (q.int() - q2.int()).abs()
+        diff = torch.minimum(diff, 256 - diff)  # (bin 256 wraps to 0)
+        assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) <= 2e-3
+
+
+def test_fused_head_is_what_the_fp32_predict_pass_runs():
+    """UNet.eval() in fp32 ends in the fused launch (and ROBOSAT_FUSED_HEAD=0 restores the two launches): the probabilities of
+    the two forms agree to fp32 rounding."""
+    import os
+    from robosat_amd import ops
+    from robosat_amd.unet import UNet
+
+    torch.manual_seed(3)
+    net = UNet(3, pretrained=False).to(DEV).eval()
+    x = torch.randn(2, 3, 128, 192, device=DEV)
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            fused = net.predict_probs(x)
+        torch.cuda.synchronize()
+        names = [r[0] for r in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert names[-1] == "conv_wino_f32<3x3+final,p8,64x32>", names[-3:]
+    os.environ["ROBOSAT_FUSED_HEAD"] = "0"
+    try:
+        with torch.no_grad():
+            two = net.predict_probs(x)
+    finally:
+        del os.environ["ROBOSAT_FUSED_HEAD"]
+    assert fused.shape == two.shape and float((fused - two).abs().max()) <= 5e-6
+
+
 def test_winograd_3x3_declines_what_it_cannot_run():
     from robosat_amd import ops
 

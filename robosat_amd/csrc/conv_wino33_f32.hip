@@ -82,7 +82,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
 
   // HEAD: + the class weights [8][32] and biases [8], + the exchange of the two cout groups' partial logits [tile][pixel][8]
   //       (two exchange buffers: an item's second half runs behind the first barrier of the block's NEXT item)
-  constexpr int HEADW = kHeadMaxC * 32 + kHeadMaxC, XCH = BMT * 4 * kHeadMaxC;
+  // (exchange rows of 36 floats: 16 lanes' 16-byte accesses at a 144-byte pitch fall into 16 different bank groups)
+  constexpr int HEADW = kHeadMaxC * 32 + kHeadMaxC, XROW = 4 * kHeadMaxC + 4, XCH = BMT * XROW;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * AROWS_PAD * 4 + (HEAD ? (HEADW + 2 * XCH) * 4 : 0)];
   int* tabs = reinterpret_cast<int*>(smem + 2 * STAGE);
   float* hws = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * AROWS_PAD * 4);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   auto finish_head = [&]() __attribute__((always_inline)) {
     if constexpr (HEAD) {
       if (cg == 0) {
-        const float* xrow = xch + hbuf * XCH + (16 * tg + l15) * (4 * kHeadMaxC) + pc * kHeadMaxC;
+        const float* xrow = xch + hbuf * XCH + (16 * tg + l15) * XROW + pc * kHeadMaxC;
         const f32x4 o0 = *reinterpret_cast<const f32x4*>(xrow), o1 = *reinterpret_cast<const f32x4*>(xrow + 4);
         float lg[kHeadMaxC];
 #pragma unroll
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       // beside the other waves' MFMAs
       hbuf = seq & 1;
       if (cg == 1 && pc == 0) {
-        float* xrow = xch + hbuf * XCH + (16 * tg + l15) * (4 * kHeadMaxC);
+        float* xrow = xch + hbuf * XCH + (16 * tg + l15) * XROW;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           *reinterpret_cast<f32x4*>(xrow + px * kHeadMaxC) = f32x4{part[px][0], part[px][1], part[px][2], part[px][3]};

@@ -151,6 +151,50 @@ def test_dispatcher_choices_for_the_benchmark_layers():
         assert cfg(*args) == want, (args, cfg(*args), want)
 
 
+def test_winograd_forms_are_chosen_by_geometry_pinned():
+    """rs_conv2d_phase_wino_ok / _name, rs_conv2d_wino33_ok / _name, rs_conv2d_wino33_head_ok are pure host logic: pin which
+    fp32 layers of the predict pass run which Winograd block shape, that a layer's FORM never depends on
+    the batch size (a tile's probabilities must not depend on its batch neighbours) and that the one batch-dependent choice
+    -- 128 x 64 vs 64 x 64 blocks, which accumulate identically -- follows the two-work-items-per-CU rule (256 CUs assumed
+    when no device is visible)."""
+    from robosat_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("librobosat_hip.so not built (run __graft_entry__.build())")
+    lib = _lib.lib()
+
+    def phase(n, hs, c1, c2, cout):
+        d = _lib.ConvDesc(n, hs, hs, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * hs, cout, 1, 0)
+        return lib.rs_conv2d_phase_wino_ok(ctypes.byref(d)), lib.rs_conv2d_phase_wino_name(ctypes.byref(d)).decode()
+
+    # the DecoderBlocks of a 512^2 pass at bs 16 (ok: 1 = runs and should, 2 = runs but the generic kernel is the better choice)
+    assert phase(16, 8, 2048, 0, 256) == (2, "conv_wino_f32<phase,p4,64x64>")       # center: < 8 tiles per side
+    assert phase(16, 16, 2048, 256, 256) == (1, "conv_wino_f32<phase,p8,64x64>")    # dec0: 1 024 items -> the 64-tile block
+    assert phase(16, 32, 1024, 256, 256) == (1, "conv_wino_f32<phase,p8,128x64>")   # dec1
+    assert phase(16, 64, 512, 256, 64) == (1, "conv_wino_f32<phase,p8,128x64>")     # dec2
+    assert phase(16, 128, 256, 64, 128) == (1, "conv_wino_f32<phase,p8,128x64>")    # dec3
+    assert phase(16, 256, 128, 0, 32) == (1, "conv_wino_f32<phase,p8,128x32>")      # dec4: 32 couts
+    for hs, c1, c2, cout in ((16, 2048, 256, 256), (64, 512, 256, 64), (256, 128, 0, 32), (8, 2048, 0, 256)):
+        assert len({phase(n, hs, c1, c2, cout)[0] for n in (1, 2, 16, 64)}) == 1      # the form: geometry only
+    assert phase(1, 64, 512, 256, 64)[1] == "conv_wino_f32<phase,p8,64x64>"         # one tile: too few items for the wide block
+    assert phase(16, 2, 64, 0, 64)[0] == 0 and phase(16, 16, 24, 0, 64)[0] == 0      # tiny layer / Cin % 16 != 0: not runnable
+
+    def w33(n, h, c, cout, stride=1):
+        d = _lib.ConvDesc(n, h, h, c, 0, 0, 3, 3, stride, 1, h // stride, h // stride, cout, 1, 0)
+        return lib.rs_conv2d_wino33_ok(ctypes.byref(d)), lib.rs_conv2d_wino33_name(ctypes.byref(d)).decode(), d
+
+    for h, c in ((128, 64), (64, 128), (32, 256), (16, 512), (512, 32)):           # layer1-4 conv2, dec5
+        assert w33(16, h, c, c)[:2] == (1, "conv_wino_f32<3x3,p8,64x32>") and w33(1, h, c, c)[0] == 1
+    assert w33(16, 128, 64, 48)[:2] == (1, "conv_wino_f32<3x3,p8,128x16>")          # Cout % 32 != 0
+    assert w33(16, 128, 128, 128, stride=2)[0] == 0 and w33(16, 8, 512, 512)[0] == 0 and w33(16, 64, 16, 64)[0] == 0
+    # dec5 + final as one launch: the 32-cout layer only, up to 8 classes
+    assert lib.rs_conv2d_wino33_head_ok(ctypes.byref(w33(16, 512, 32, 32)[2]), 2) == 1
+    assert lib.rs_conv2d_wino33_head_ok(ctypes.byref(w33(1, 64, 32, 32)[2]), 8) == 1
+    assert lib.rs_conv2d_wino33_head_ok(ctypes.byref(w33(16, 512, 32, 32)[2]), 9) == 0
+    assert lib.rs_conv2d_wino33_head_ok(ctypes.byref(w33(16, 128, 64, 64)[2]), 2) == 0
+    assert lib.rs_conv2d_wino33_head_name().decode() == "conv_wino_f32<3x3+final,p8,64x32>"
+
+
 def test_pretrained_encoder_loads_a_legacy_torchvision_state_dict(tmp_path, monkeypatch):
     """resnet50-19c8e357.pth (torchvision 0.3.0's download, reference unet.py:94) has no ``num_batches_tracked`` keys:
     the encoder must load it like nn.BatchNorm2d's version shim does, find it through $ROBOSAT_RESNET50_WEIGHTS, and a

@@ -3,6 +3,7 @@ exports every symbol declared in include/robosat_hip.h (no kernel is launched he
 
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -149,6 +150,41 @@ def test_dispatcher_choices_for_the_benchmark_layers():
     ]
     for args, want in fp32 + bf16:
         assert cfg(*args) == want, (args, cfg(*args), want)
+
+
+def test_profiler_symbols_map_to_the_bench_names():
+    """bench.py looks `roofline.traffic` up in profiles/pmc_traffic.json by ITS kernel names; scripts/pmc_traffic.py derives
+    them from the symbols rocprofv3 prints (demangled or not).  A kernel whose template list changes must keep mapping to the
+    name the bench reports, or the traffic field silently becomes null."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    try:
+        from pmc_traffic import bench_name
+    finally:
+        sys.path.pop(0)
+
+    ns = "void (anonymous namespace)::"
+    table = {
+        ns + "conv_wino_f32_kernel<8, 8, 1, 4>((anonymous namespace)::WinoArgs)": "conv_wino_f32<phase,p8,128x64>",
+        ns + "conv_wino_f32_kernel<8, 4, 2, 2>((anonymous namespace)::WinoArgs)": "conv_wino_f32<phase,p8,64x64>",
+        ns + "conv_wino_f32_kernel<8, 8, 1, 2>((anonymous namespace)::WinoArgs)": "conv_wino_f32<phase,p8,128x32>",
+        ns + "conv_wino_f32_kernel<4, 4, 2, 2>((anonymous namespace)::WinoArgs)": "conv_wino_f32<phase,p4,64x64>",
+        ns + "conv_wino33_f32_kernel<4, 2, false>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3,p8,64x32>",
+        ns + "conv_wino33_f32_kernel<8, 1, false>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3,p8,128x16>",
+        ns + "conv_wino33_f32_kernel<4, 2, true>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
+        ns + "conv_igemm_dma<float, 128, 128, 2, 2, 64, false, 0>(ConvArgsT<float>)": "conv_igemm_f32<128x128,r64>",
+        ns + "conv_igemm_dma<float, 64, 64, 2, 2, 128, true, 0>(ConvArgsT<float>)": "conv_igemm_f32<phase,64x64,r128>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi128ELi128ELi2ELi2ELi64ELb0ELi2EEEv9ConvArgsTIT_E": "conv_igemm_bf16<128x128,r64>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi256ELi2ELi4ELi128ELb1ELi0EEEv9ConvArgsTIT_E": "conv_igemm_bf16<phase,256x256,r128>",
+        ns + "conv_igemm_f32<128, 64, 2, 2, 1>((anonymous namespace)::ConvArgs)": "conv_igemm_f32<128x64,stem>",
+        ns + "conv_thin_bf16<1>((anonymous namespace)::ThinConvArgs)": "conv_thin_bf16<phase>",
+        ns + "conv_wgrad_thin_bf16<4, 1>((anonymous namespace)::ThinArgs)": "conv_wgrad_thin_bf16<128,ups>",
+        ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",
+        ns + "conv_wgrad_bf16<128, 128, 2, 2, 64, true>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase,128x128>",
+        "_ZN12_GLOBAL__N_126bn_bwd_apply_stream_kernelIDF16bLb0ELb0EEEvPKT_S3_S3_PKfS5_PS1_S6_li": "bn_bwd_apply_stream_kernel",
+        "(anonymous namespace)::reduce_lanes_kernel(float const*, float*, long, int, int)": "reduce_lanes_kernel",
+    }
+    for symbol, want in table.items():
+        assert bench_name(symbol) == want, (symbol, bench_name(symbol), want)
 
 
 def test_winograd_forms_are_chosen_by_geometry_pinned():

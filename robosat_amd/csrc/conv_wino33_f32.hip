@@ -65,7 +65,10 @@ constexpr int kSBROWS = (kHW * kPITCH + 7) / 8 * 8;  // rows per sub-block, padd
 __device__ __forceinline__ int w33_lane_tile(int l) { return (l & 1) | (((l >> 1) & 1) << 2) | (((l >> 2) & 1) << 1) | (l & 8); }
 __device__ __forceinline__ int w33_swz(int row) { return (row ^ (row >> 1)) & 3; }
 
-template <int TG, int CG, bool HEAD = false>
+// HEAD: 0 = the layer alone; 1 / 2 / 3 = + self.final and logits-or-softmax / quantised probabilities / argmax (one
+// instantiation per output kind: each carries only its own epilogue code -- the kernel's instructions are fetched cold on
+// every launch, which a single-tile `rs serve` request pays for in full)
+template <int TG, int CG, int HEAD = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Args p) {
   constexpr int NW = TG * CG;
   static_assert(NW == 8, "8 waves");
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
         float lg[kHeadMaxC];
 #pragma unroll
         for (int c = 0; c < kHeadMaxC; ++c) lg[c] = (hmine[c] + (c < 4 ? o0[c] : o1[c - 4])) + hws[kHeadMaxC * 32 + c];
-        if (hpix >= 0) rs_final_epilogue_rt(lg, p.hC, hpix, (long)p.H * p.W, p.hmode, p.hanchors, p.hq, p.hout, p.W, p.hov);
+        if (hpix >= 0)
+          rs_final_epilogue_rt(lg, p.hC, hpix, (long)p.H * p.W, HEAD == 1 ? (p.hmode & 1) : HEAD, p.hanchors, p.hq, p.hout, p.W, p.hov);
       }
     }
   };
@@ -531,6 +535,9 @@ extern "C" int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src
   const long items = a.nsub;
   if (items >= (1L << 31)) return RS_EINVAL;
   const int grid = (int)(items < w33_cus() ? items : w33_cus());
-  conv_wino33_f32_kernel<4, 2, true><<<grid, 512, 0, (hipStream_t)stream>>>(a);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode <= 1) conv_wino33_f32_kernel<4, 2, 1><<<grid, 512, 0, s>>>(a);
+  else if (mode == 2) conv_wino33_f32_kernel<4, 2, 2><<<grid, 512, 0, s>>>(a);
+  else conv_wino33_f32_kernel<4, 2, 3><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }

@@ -74,6 +74,12 @@ def parse():
                     help="weak: --batch / --train-batch tiles PER GPU (default); strong: they are the GLOBAL batch, split over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU-oracle sample")
     ap.add_argument("--layers-json", type=str, default="", help="also dump the per-layer roofline table here")
+    ap.add_argument("--full-json", type=str, default="",
+                    help="where the FULL record goes (per-kernel tables, every step time, counter provenance); default "
+                         "gpurun_out/bench_full.json.  stdout carries the compact line (<= 4 KB) only")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="train legs at ONE rank: run the data-parallel GradReducer anyway, over a world-size-1 RCCL group (the "
+                         "backend == nccl branch, its stream ordering and the in-place AVG on arena views execute for real)")
     return ap.parse_args()
 
 
@@ -281,7 +287,7 @@ class Leg:
             phase, dtype, batch, size, classes, channels, loss, tag)
 
 
-def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtype="fp32"):
+def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtype="fp32", force_reducer=False):
     """Builds the model for `leg`, runs `warmup` untimed + `steps` timed steps bracketed by barrier + synchronize, and
     returns (max-over-ranks seconds, per-step milliseconds of this rank from HIP events between the steps, the EAGER step
     function, a callable producing rank 0's parity record, whether the timed steps were hipGraph replays)."""
@@ -308,12 +314,14 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
         # 23.5 ms eager (profiles/r03/host_sensitivity.txt) -- the graph executor serialises the weight-gradient branch.
         graphed = not dist and warmup + PREWARM_STEPS >= 3 and os.environ.get("ROBOSAT_TRAIN_GRAPH", "0") == "1"
         opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True, capturable=graphed)
-        if dist:
+        if dist or force_reducer:
             from robosat_amd import parallel
 
             parallel.broadcast_module(net)  # (the replicas are seeded identically; this is what `rs train` does)
-            # bucketed RCCL all-reduce overlapped with the backward kernels
-            net.grad_reducer = GradReducer(wire_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32)
+            # bucketed RCCL all-reduce overlapped with the backward kernels (--force-reducer: over a group of one rank too)
+            net.grad_reducer = GradReducer(wire_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32,
+                                           force=force_reducer)
+            run_phase.reducer = net.grad_reducer
 
         def step():  # the eager step (what the roofline pass brackets launch by launch)
             opt.zero_grad()
@@ -396,6 +404,17 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
 
     run_phase.peak_gb = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)  # (read by the caller right after)
     return el, step_ms, step, parity, bool(train and graphed and stepper.captured)
+
+
+def reducer_record():
+    """What the last train leg's GradReducer was and did: backend, group size, collectives issued (so a reader can tell the
+    RCCL branch executed inside the timed steps), wire dtype."""
+
+    rd = getattr(run_phase, "reducer", None)
+    if rd is None:
+        return None
+    return {"backend": rd.backend, "world": rd.world, "forced": rd.force, "collectives_issued": rd.issued,
+            "wire": "bf16" if rd.wire_dtype == torch.bfloat16 else "fp32"}
 
 
 def step_stats(step_ms):
@@ -501,6 +520,88 @@ def miou_vs_cpu_ref(device, seed=31, n_train=24, n_val=8, size=128, batch=4, epo
                     "bf16 MI355X path vs fp32 CPU oracle, same initial weights and batches".format(epochs, lr, n_train, size, size, n_val)}
 
 
+COMPACT_LIMIT = 4096  # bytes of the stdout line: the driver keeps an 8 KB tail of the run's output
+
+
+def _short(text, n):
+    return text if len(text) <= n else text[:n - 1] + "~"
+
+
+def _compact_roofline(r):
+    """The contract's roofline object (bound / achieved / peak / unit / frac / traffic) + what names it; the per-kernel
+    table, the counter provenance and the second roof's figures stay in the full record."""
+
+    if not r:
+        return r
+    out = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms") if k in r}
+    if "algorithmic" in r:
+        out["algorithmic_tflops"] = r["algorithmic"]["tflops"]
+    if "hbm" in r:
+        out["hbm_frac"] = r["hbm"]["frac"]
+    if "all_convs" in r:
+        out["all_convs"] = {k: r["all_convs"][k] for k in ("executed_frac", "roofline_frac", "ms", "executed_tflops") if k in r["all_convs"]}
+    return out
+
+
+def _compact_leg(leg, with_roofline=True):
+    out = {k: leg[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "value_median", "dtype", "hipgraph", "peak_hbm_gb",
+                               "scaling", "reducer") if k in leg}
+    if "step_ms" in leg:
+        out["step_ms"] = {k: leg["step_ms"][k] for k in ("min", "median", "max", "n", "stalled_steps")}
+    if "config" in leg:
+        out["config"] = {"workload": _short(leg["config"]["workload"], 120), "parallelism": _short(leg["config"]["parallelism"], 64)}
+    if with_roofline and "roofline" in leg:
+        out["roofline"] = _compact_roofline(leg["roofline"])
+    if leg.get("parity"):
+        out["parity"] = {k: v for k, v in leg["parity"].items() if k != "what"}
+    if leg.get("cpu_baseline"):
+        out["cpu_baseline"] = dict(leg["cpu_baseline"], sample=_short(leg["cpu_baseline"]["sample"], 150))
+    return out
+
+
+def compact_line(line, full_path=""):
+    """What goes to stdout: every field of the bench contract for the headline leg, and for `train` and each of `legs`
+    value / ms_per_step / step_ms min-median-max / roofline (dominant kernel + all_convs) / parity / cpu_baseline -- at most
+    COMPACT_LIMIT bytes, so that the driver's 8 KB tail holds the whole line.  Everything else (per-kernel tables, all step
+    times, counter provenance, the long descriptions) is in the full record at `full_path`."""
+
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data", "hipgraph") if k in line}
+    out.update(_compact_leg(line))
+    out["flops_basis"] = "executed"
+    if "train" in line:
+        out["train"] = _compact_leg(line["train"])
+    if "legs" in line:
+        out["legs"] = {name: _compact_leg(leg, with_roofline=False) for name, leg in line["legs"].items()}
+        for leg in out["legs"].values():
+            leg.pop("config", None)
+            leg.pop("unit", None)
+    if "miou" in line:
+        out["miou"] = {k: v for k, v in line["miou"].items() if k != "what"}
+    if full_path:
+        out["full_record"] = full_path
+    # belt and braces: should a future field push the line over the limit, drop the least important groups first
+    for victim in ("legs", "miou", "full_record"):
+        if len(json.dumps(out)) <= COMPACT_LIMIT:
+            break
+        out.pop(victim, None)
+    return out
+
+
+def write_full_record(line, path):
+    """The full record next to the compact line: `path`, else gpurun_out/bench_full.json under the repo (scratch on the GPU
+    box, merged back by gpurun).  Returns the path written, or "" when nothing could be written (read-only tree)."""
+
+    path = path or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as fp:
+            json.dump(line, fp, indent=1)
+        return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError:
+        return ""
+
+
 def main():
     args = parse()
     from robosat_amd import launch, parallel
@@ -514,14 +615,17 @@ def main():
         print("bench.py: --gpus {} but the launcher started {} rank(s); reporting n_gpus = {}".format(args.gpus, world, world),
               file=sys.stderr)
     dist = world > 1
-    if dist:
+    if dist or args.force_reducer:
         import torch.distributed as td
 
+        if not dist:  # a process group of ONE rank over RCCL: the reducer's nccl branch on a single GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
         parallel.init_process_group(world, rank)
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if dist:
+    if dist or args.force_reducer:
         # Create the communicator now and push whatever RCCL wrote through C stdio (it prints a version banner on first
         # use) out of the buffer, so that the JSON line below stays the LAST line of stdout.
         import ctypes
@@ -542,7 +646,8 @@ def main():
         return batch // world
 
     main_leg = Leg(args.phase, args.dtype, per_rank(args.batch), args.size, args.classes, args.channels, args.loss)
-    el, step_ms, step, parity, hipgraph = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity, args.grad_dtype)
+    el, step_ms, step, parity, hipgraph = run_phase(main_leg, args.steps, args.warmup, device, dist, rank, args.no_parity, args.grad_dtype,
+                                                    args.force_reducer)
     line = None
     # every rank runs the two untimed roofline passes: a train step contains the gradient all-reduce, so rank 0 alone
     # would wait for its peers forever
@@ -568,6 +673,8 @@ def main():
                            "F(2x2,2x2) form 1/4; the fp32 eval stride-1 3x3 layers as Winograd F(2x2,3x3) 4/9)",
             "roofline": roof, "parity": parity(),
         }
+        if args.phase == "train" and reducer_record() is not None:
+            line["reducer"] = reducer_record()
     del step  # (the cached blocks stay with the allocator: the next leg reuses them instead of a new round of hipFree / hipMalloc)
     if EMPTY_CACHE_BETWEEN_LEGS:
         torch.cuda.empty_cache()
@@ -577,7 +684,8 @@ def main():
     if args.phase == "predict" and not args.no_train_leg:
         tleg = Leg("train", "bf16", per_rank(args.train_batch), args.size, args.classes, args.channels, args.loss)
         ts, tw = max(1, args.train_steps), max(3, min(args.warmup, 5))
-        tel, tstep_ms, tstep, tparity, tgraph = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity, args.grad_dtype)
+        tel, tstep_ms, tstep, tparity, tgraph = run_phase(tleg, ts, tw, device, dist, rank, args.no_parity, args.grad_dtype,
+                                                          args.force_reducer)
         troof, _ = roofline(tstep)
         if rank == 0:
             line["train"] = {"value": round(world * tleg.batch * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
@@ -587,6 +695,8 @@ def main():
                              "hipgraph": tgraph, "peak_hbm_gb": run_phase.peak_gb,
                              "scaling": args.scaling, "config": workload(tleg, world, baseline_config(tleg)),
                              "roofline": troof, "parity": tparity()}
+            if reducer_record() is not None:  # which exchange ran inside the timed steps
+                line["train"]["reducer"] = reducer_record()
         del tstep
         if EMPTY_CACHE_BETWEEN_LEGS:
             torch.cuda.empty_cache()
@@ -619,14 +729,14 @@ def main():
             if "train" in line:  # the train leg's own CPU number (the oracle's fwd + Lovasz + bwd + Adam), shorter sample
                 line["train"]["cpu_baseline"] = cpu_baseline(args.classes, args.size, args.cpu_seconds * 0.7, "train", args.loss,
                                                              args.channels)
-    if dist:
+    if dist or args.force_reducer:
         import ctypes
 
         td.barrier()
         td.destroy_process_group()
         ctypes.CDLL(None).fflush(None)  # anything RCCL still holds in C stdio goes out BEFORE the JSON line
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(compact_line(line, write_full_record(line, args.full_json))), flush=True)
 
 
 if __name__ == "__main__":

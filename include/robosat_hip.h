@@ -170,7 +170,10 @@ int rs_nll_loss_bwd(const float* logits, const long long* targets, const float* 
                     rs_stream_t stream);
 
 /* mIoULoss2d (losses.py:53-83): max(1 - mean_{c,n} softIoU, weighted NLL), gradient through the larger branch.
- * stats needs 3 + 2*N*C floats (loss, sum w, chosen branch, per-(n,c) gradient coefficients). */
+ * stats needs 5 + 2*N*C floats: loss, sum w, chosen branch (0 miou / 1 nll), per-(n,c) gradient coefficients, then the
+ * miou branch's value and the nll branch's numerator sum_i w_i l_i.  rs_miou_loss_bwd reads [1] (the NLL denominator) and
+ * [2] (the branch) back: data-parallel ranks overwrite them with the global batch's (the reference evaluates
+ * max(miou, nll) ONCE over the gathered batch, losses.py:83 under tools/train.py:69). */
 long rs_miou_loss_workspace_bytes(int N, int C);
 int rs_miou_loss_fwd(const float* logits, const long long* targets, const float* weight, float* loss, float* stats, int N,
                      int C, int H, int W, void* workspace, rs_stream_t stream);
@@ -230,6 +233,10 @@ int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stre
  * rs_cast_f32_to_bf16, summed by RCCL, and comes back through this call with scale = 1 / world into the fp32 arena the
  * optimizer reads.  src / dst 16-byte aligned. */
 int rs_cast_bf16_to_f32_scaled(const rs_bf16* src, float* dst, long n, float scale, rs_stream_t stream);
+/* dst = bf16(src * scale): the way OUT of the same exchange with scale = 1 / world, so that every rank puts an already
+ * averaged contribution on the wire and the ring's bf16 partial sums stay at the magnitude of one gradient (summing WORLD
+ * unscaled values and dividing afterwards loses mantissa and overflows earlier).  src / dst 16-byte aligned. */
+int rs_cast_f32_to_bf16_scaled(const float* src, rs_bf16* dst, long n, float scale, rs_stream_t stream);
 int rs_pack_dgrad_weight_bf16(const float* w_krsc, rs_bf16* out, int Cout, int kh, int kw, int Cin, rs_stream_t stream);
 
 /* The 7x7/2 stem (resnet.conv1, unet.py:122) in bf16: x NHWC4 bf16 [N][H][W][4] (rs_nchw_to_nhwc4_bf16), weights packed

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROBOSAT_HIP_LIB") or os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 19
+ABI_VERSION = 20
 RS_F32, RS_BF16 = 0, 1
 
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "rs_conv2d_wgrad_bf16": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "rs_cast_f32_to_bf16": (c_int, [P, P, c_long, P]),
     "rs_cast_bf16_to_f32_scaled": (c_int, [P, P, c_long, c_float, P]),
+    "rs_cast_f32_to_bf16_scaled": (c_int, [P, P, c_long, c_float, P]),
     "rs_weight_prep_bf16": (c_int, [P, c_int, c_int, P]),
     "rs_pack_dgrad_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "rs_maxpool2d_fwd_dt": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -271,25 +271,26 @@ int launch_maxpool(const void* x, void* y, uint8_t* argmax, int H, int W, int C,
 }
 
 // fp32 -> bf16 (round to nearest even), 8 elements per thread; tail handled element-wise
-__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+template <bool SCALED>
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n, float scale) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i + 8 <= n) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(src + i), b = *reinterpret_cast<const f32x4*>(src + i + 4);
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[e] = (bf16_t)a[e];
-      o[4 + e] = (bf16_t)b[e];
+      o[e] = (bf16_t)(SCALED ? a[e] * scale : a[e]);
+      o[4 + e] = (bf16_t)(SCALED ? b[e] * scale : b[e]);
     }
     *reinterpret_cast<bf16x8*>(dst + i) = o;
   } else {
-    for (long j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+    for (long j = i; j < n; ++j) dst[j] = (bf16_t)(SCALED ? src[j] * scale : src[j]);
   }
 }
 
 }  // namespace
 
-extern "C" int rs_abi_version(void) { return 19; }
+extern "C" int rs_abi_version(void) { return 20; }
 
 extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;
@@ -344,7 +345,13 @@ extern "C" int rs_cast_bf16_to_f32_scaled(const rs_bf16* src, float* dst, long n
 
 extern "C" int rs_cast_f32_to_bf16(const float* src, rs_bf16* dst, long n, rs_stream_t stream) {
   if (!src || !dst || n <= 0) return RS_EINVAL;
-  cast_f32_bf16_kernel<<<rs_cdiv(rs_cdiv(n, 8), 256), 256, 0, (hipStream_t)stream>>>(src, reinterpret_cast<bf16_t*>(dst), n);
+  cast_f32_bf16_kernel<false><<<rs_cdiv(rs_cdiv(n, 8), 256), 256, 0, (hipStream_t)stream>>>(src, reinterpret_cast<bf16_t*>(dst), n, 1.f);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_cast_f32_to_bf16_scaled(const float* src, rs_bf16* dst, long n, float scale, rs_stream_t stream) {
+  if (!src || !dst || n <= 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return RS_EINVAL;
+  cast_f32_bf16_kernel<true><<<rs_cdiv(rs_cdiv(n, 8), 256), 256, 0, (hipStream_t)stream>>>(src, reinterpret_cast<bf16_t*>(dst), n, scale);
   return RS_LAUNCH_RESULT();
 }
 

@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256) void miou_partial_kernel(const float* __restri
   }
 }
 
-// stats: [0] loss, [1] sum w, [2] branch (0 = miou, 1 = nll), [3 + n*C + c] = g for m=1, [3 + N*C + n*C + c] = g for m=0
+// stats: [0] loss, [1] sum w, [2] branch (0 = miou, 1 = nll), [3 + n*C + c] = g for m=1, [3 + N*C + n*C + c] = g for m=0,
+// [3 + 2*N*C] = the miou branch's value, [4 + 2*N*C] = the nll branch's numerator sum_i w_i l_i (data-parallel ranks
+// exchange these two and [1] to take the reference's ONE branch decision over the global batch: robosat_amd/losses.py)
 __global__ void miou_finalize_kernel(const double* __restrict__ partial, int N, int C, int nblk, float* __restrict__ loss,
                                      float* __restrict__ stats) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -289,6 +291,8 @@ __global__ void miou_finalize_kernel(const double* __restrict__ partial, int N, 
   stats[0] = loss[0];
   stats[1] = (float)sw;
   stats[2] = use_nll ? 1.f : 0.f;
+  stats[3 + 2 * N * C] = miou;
+  stats[4 + 2 * N * C] = (float)sl;
 }
 
 template <int C>

@@ -113,9 +113,36 @@ def run_per_gpu(nprocs, args, module=None, script=None):
     return spawn_ranks(argv, nprocs)
 
 
-def check_ranks_fit_devices(world, device_count, backend):
-    """RCCL refuses two ranks on one device; say so before the communicator does (with a stack of C++ frames)."""
+def check_ranks_fit_devices(world, device_count, backend, local_world=None, local_rank=None):
+    """RCCL refuses two ranks on one device; say so before the communicator does (with a stack of C++ frames).
 
-    if backend == "nccl" and world > max(1, device_count):
-        raise RuntimeError("{} ranks but {} visible GPU(s): RCCL needs one device per rank (lower ROBOSAT_GPUS / "
-                           "--nproc-per-node, or ROBOSAT_DIST_BACKEND=gloo for a shared-device test)".format(world, device_count))
+    What must fit is the NODE-LOCAL rank count (``LOCAL_WORLD_SIZE``, set by torchrun and by ``spawn_ranks``), not the job's
+    world size: a 2-node job (WORLD_SIZE 16, 8 local GPUs) is fine, and so is a job that isolates one GPU per rank with
+    ``HIP_VISIBLE_DEVICES`` (every rank sees ONE device and its LOCAL_RANK maps onto it: ``local % device_count`` below the
+    call sites).  Rejected: more local ranks than visible devices when the ranks can see more than one device (two of them
+    would resolve to the same index) -- and, with one visible device, only when nothing says the ranks were isolated."""
+
+    if backend != "nccl":
+        return
+    device_count = max(1, device_count)
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world <= device_count:
+        return
+    if device_count == 1 and _one_device_per_rank():
+        return
+    raise RuntimeError("{} local ranks but {} visible GPU(s): RCCL needs one device per rank (lower ROBOSAT_GPUS / "
+                       "--nproc-per-node, or ROBOSAT_DIST_BACKEND=gloo for a shared-device test)".format(local_world, device_count))
+
+
+def _one_device_per_rank():
+    """Whether this rank's single visible device was picked FOR it (a per-rank ``HIP_VISIBLE_DEVICES`` /
+    ``ROCR_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` naming exactly one device): the launcher isolated the GPUs."""
+
+    for key in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(key, "").strip()
+        if v and len([x for x in v.split(",") if x.strip()]) == 1:
+            return True
+    return False

@@ -524,6 +524,15 @@ def cast_bf16(t):
     return out
 
 
+def cast_bf16_scaled(t, scale):
+    """bf16(t * scale): a gradient bucket on its way to a bf16 exchange, already divided by the world size."""
+
+    out = torch.empty(t.shape, device=t.device, dtype=BF16)
+    check(_lib.lib().rs_cast_f32_to_bf16_scaled(_dev(t, "src"), _dev(out, "dst", BF16), t.numel(), ctypes.c_float(scale), _stream()),
+          "rs_cast_f32_to_bf16_scaled")
+    return out
+
+
 def cast_f32_scaled(src_bf16, dst_f32, scale):
     """dst (fp32, in place) = float(src bf16) * scale: the way back from a bf16 gradient exchange (``GradReducer``)."""
 
@@ -939,7 +948,7 @@ def miou_loss_fwd(logits, targets, weight):
     n, c, h, w = logits.shape
     lib = _lib.lib()
     loss = torch.empty((), device=logits.device, dtype=torch.float32)
-    stats = torch.empty(3 + 2 * n * c, device=logits.device, dtype=torch.float32)
+    stats = torch.empty(5 + 2 * n * c, device=logits.device, dtype=torch.float32)
     rc = lib.rs_miou_loss_fwd(_dev(logits, "logits"), _dev(targets, "targets", torch.int64), _dev(weight, "weight"),
                               _dev(loss, "loss"), _dev(stats, "stats"), n, c, h, w,
                               _workspace(lib.rs_miou_loss_workspace_bytes(n, c), logits.device), _stream())

@@ -82,25 +82,44 @@ class GradReducer:
     weight-gradient kernels) stays fp32; what is rounded is each rank's contribution to the sum and the partial sums on the
     ring.  Default: fp32 on the wire, bit-identical replicas, the reference's arithmetic."""
 
-    def __init__(self, group=None, wire_dtype=torch.float32):
+    def __init__(self, group=None, wire_dtype=torch.float32, force=False):
+        """``force``: issue the collectives even in a group of ONE rank (a world-size-1 RCCL communicator is legal: the
+        all-reduce is then an in-place copy on RCCL's stream).  That is how the ``backend == "nccl"`` branch -- the
+        communicator stream's ordering after the side stream, the in-place AVG on views of one arena, the bf16 wire -- runs
+        on a one-GPU box (tests/test_gpu_parallel.py, ``bench.py --force-reducer``); a real job never sets it."""
+
         self.group = group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         if wire_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("GradReducer: gradients travel as fp32 or bf16")
         self.wire_dtype = wire_dtype
+        self.force = bool(force)
+        self.issued = 0  # collectives issued so far (tests: the branch really ran)
         self._pending = []
 
     def reduce_async(self, flat):
         """Enqueue an in-place average of ``flat`` (a contiguous 1-D fp32 view), ordered after torch's current stream."""
 
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
+        self.issued += 1
         if self.wire_dtype == torch.bfloat16 and flat.is_cuda:
             from . import ops
 
-            wire = ops.cast_bf16(flat)
+            # every rank puts ALREADY AVERAGED contributions on the wire (x 1/world inside the cast): the ring's partial sums
+            # then stay at the magnitude of one gradient however many ranks there are -- summing WORLD unscaled bf16 values and
+            # dividing afterwards loses mantissa to the larger partial sums and overflows earlier (ADVICE r3)
+            wire = ops.cast_bf16_scaled(flat, 1.0 / self.world)
             work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.backend == "nccl":
+                # `wire` was allocated under the current (side) stream and is consumed on RCCL's communicator stream:
+                # ProcessGroupNCCL records that itself unless TORCH_NCCL_AVOID_RECORD_STREAMS=1 -- then the reference kept in
+                # _pending until the cast back is what holds the memory; say it explicitly as well
+                try:
+                    wire.record_stream(torch.cuda.current_stream(wire.device))
+                except RuntimeError:
+                    pass
             self._pending.append((work, flat, wire))
         elif self.backend == "nccl":
             work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -115,7 +134,7 @@ class GradReducer:
             if wire is not None:
                 from . import ops
 
-                ops.cast_f32_scaled(wire, flat, 1.0 / self.world)
+                ops.cast_f32_scaled(wire, flat, 1.0)  # (the contributions were scaled by 1/world on the way out)
             elif flat is not None:
                 flat.div_(self.world)
         self._pending = []

@@ -14,8 +14,8 @@ Differences by design:
   * losses under data parallelism: the reference evaluates ONE loss over the gathered global batch (train.py:180-186); here
     every rank evaluates its shard and the gradients are averaged.  For Lovasz (a mean over images) that is the same number;
     weighted CrossEntropy / Focal exchange their normaliser (the sum of target weights, one scalar all-reduce) so that it is
-    the same number there too (robosat_amd/losses.py); mIoULoss2d's ``max(miou, nll)`` picks its branch per shard, which
-    can differ from the global choice on a step where the two branches are close.
+    the same number there too (robosat_amd/losses.py); mIoULoss2d exchanges its two branch values and takes
+    ``max(miou, nll)`` once over the global batch (three scalars, one all-reduce).
   * extension keys, all optional: dataset ``[common] image_dirs / image_modes / mean / std`` (band layout: robosat_amd/bands.py;
     default = the reference's one RGB directory), model ``[model] in_channels``, ``compute_dtype``, ``pretrained``,
     ``device_augment``, ``grad_dtype`` (bf16 gradient exchange), ``graph`` (the step as one hipGraph replay).
@@ -173,6 +173,7 @@ def main(args):
         net.load_state_dict(chkpt["state_dict"])
         if args.resume:
             optimizer.load_state_dict(chkpt["optimizer"])
+            _reassert_optimizer_flags(optimizer, use_graph, device)
             resume = chkpt["epoch"]
     # replicas must start identical (each rank drew its own random decoder): rank 0's parameters and buffers everywhere
     parallel.broadcast_module(net)
@@ -188,6 +189,11 @@ def main(args):
         criterion = LovaszLoss2d().to(device)
     else:
         sys.exit("Error: Unknown [opt][loss] value !")
+    if world > 1 and hasattr(criterion, "global_batch"):
+        # batch-level terms (the weighted NLL's normaliser, mIoU's max(miou, nll) branch) over the GLOBAL batch, as the
+        # reference's one evaluation over the gathered logits (train.py:180-186): a small collective inside forward(), safe
+        # here because every rank runs the same number of equally sized batches (ShardedBatchSampler, drop_last)
+        criterion.global_batch = True
 
     # [model] device_augment = true (extension key): decoded-tile cache in HBM + flip / rot90 / ToTensor / Normalize in one
     # kernel instead of PIL work in DataLoader workers (same augmentation distribution, same seeded draws)
@@ -208,6 +214,9 @@ def main(args):
     from robosat_amd.graph import TrainStepGraph
 
     stepper = TrainStepGraph(net, criterion, optimizer, enabled=use_graph)
+    if master and device.type == "cuda":
+        print("Training step: {}".format("one hipGraph replay per batch after two eager batches ([model] graph = true)"
+                                         if stepper.enabled else "eager launches"), file=sys.stderr)
     history = collections.defaultdict(list)
     log = Log(os.path.join(model["common"]["checkpoint"], "log"), out=sys.stdout if master else None) if master else None
 
@@ -257,7 +266,9 @@ def main(args):
 
 def _portable_optimizer_state(optimizer):
     """``optimizer.state_dict()`` as a stock ``Adam`` writes it (train.py:143): the fused kernels keep every ``step``
-    counter on the device; the checkpoint carries them as host tensors so that any Adam can resume from it."""
+    counter on the device; the checkpoint carries them as host tensors so that any Adam can resume from it.  The
+    implementation flags of THIS run (`fused`, `capturable`, `foreach`) are not training state: they are saved as a stock
+    Adam's defaults, so that a resumed run -- here or in the reference -- uses what ITS configuration asks for."""
 
     state = optimizer.state_dict()
     # (state_dict() hands out the LIVE per-parameter dicts: copy before touching, or the next step finds its counters on the host)
@@ -265,7 +276,38 @@ def _portable_optimizer_state(optimizer):
     for st in state["state"].values():
         if torch.is_tensor(st.get("step")):
             st["step"] = st["step"].detach().to("cpu", copy=True)
+    groups = []
+    for g in state["param_groups"]:
+        g = dict(g)
+        if "capturable" in g:
+            g["capturable"] = False
+        if "fused" in g:
+            g["fused"] = None
+        groups.append(g)
+    state["param_groups"] = groups
     return state
+
+
+def _reassert_optimizer_flags(optimizer, use_graph, device):
+    """After ``optimizer.load_state_dict``: the run's own implementation flags back in place.
+
+    ``load_state_dict`` replaces the param groups with the SAVED ones, so a checkpoint written without ``[model] graph``
+    silently switched the hipGraph step off on resume (``capturable`` False -> TrainStepGraph disabled, no message), and one
+    written with it forced device-side step counters on an eager run (ADVICE r3).  The flags follow THIS run's configuration;
+    the step counters move to where the chosen implementation wants them (device for fused / capturable, host otherwise)."""
+
+    fused = device.type == "cuda"
+    for g in optimizer.param_groups:
+        g["capturable"] = bool(use_graph)
+        g["fused"] = True if fused else None
+        if fused:
+            g["foreach"] = None
+    for st in optimizer.state.values():
+        step = st.get("step")
+        if torch.is_tensor(step):
+            want = device if (fused or use_graph) else torch.device("cpu")
+            if step.device != want or step.dtype != torch.float32:
+                st["step"] = step.to(device=want, dtype=torch.float32)
 
 
 def _epoch_loop(loader, num_classes, device, net, criterion, master, optimizer, desc, stepper, training, metrics, running_loss):

@@ -23,7 +23,7 @@ def leg(name, d):
 
 def main():
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    leg("headline " + d["config"]["phase"] + " " + d["dtype"], d)
+    leg("headline " + d["config"].get("phase", "") + " " + d["dtype"], d)
     if "train" in d:
         leg("train bf16", d["train"])
     for k, v in (d.get("legs") or {}).items():

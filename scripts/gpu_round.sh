@@ -22,9 +22,9 @@ for STAGE in "$@"; do
   smoke)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   bench)
-    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers-json $OUT/layers_predict.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers-json $OUT/layers_predict.json --full-json $OUT/bench_default_full.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
     tail -1 $OUT/bench_default.log > $OUT/bench_default.json; python scripts/bench_brief.py $OUT/bench_default.json
-    timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --layers-json $OUT/layers_train.json > $OUT/bench_train.log 2>&1; echo "train bench exit $?"
+    timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --layers-json $OUT/layers_train.json --full-json $OUT/bench_train_full.json > $OUT/bench_train.log 2>&1; echo "train bench exit $?"
     tail -1 $OUT/bench_train.log > $OUT/bench_train_bf16_bs32.json; cut -c1-500 $OUT/bench_train_bf16_bs32.json ;;
   smi)
     # does a concurrent SMU poller (what the driver runs beside its bench: one sample every 5 s) move the train leg?  Same

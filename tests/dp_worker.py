@@ -142,8 +142,12 @@ def gpu_weighted_ce(rank, world):
     probs = [torch.tensor([0.9, 0.08, 0.02]), torch.tensor([0.1, 0.2, 0.7])]
     targets = torch.cat([torch.multinomial(probs[r % 2], n * h * w, True, generator=g).view(n, h, w) for r in range(world)])
     out = {}
-    for name, crit, ref in (("ce", losses.CrossEntropyLoss2d(weight=weight), lambda x: F.nll_loss(F.log_softmax(x, 1), targets, weight=weight)),
-                            ("focal", losses.FocalLoss2d(weight=weight),
+    def opted_in(crit):
+        crit.global_batch = True  # (what rs train / bench.py set on the ranks of a data-parallel job)
+        return crit
+
+    for name, crit, ref in (("ce", opted_in(losses.CrossEntropyLoss2d(weight=weight)), lambda x: F.nll_loss(F.log_softmax(x, 1), targets, weight=weight)),
+                            ("focal", opted_in(losses.FocalLoss2d(weight=weight)),
                              lambda x: F.nll_loss((1 - F.softmax(x, 1)) ** 2 * F.log_softmax(x, 1), targets, weight=weight))):
         x_ref = logits.clone().requires_grad_(True)
         want = ref(x_ref)
@@ -161,16 +165,129 @@ def gpu_weighted_ce(rank, world):
     return out
 
 
+def gpu_miou(rank, world):
+    """mIoULoss2d on shards that would pick DIFFERENT branches of the reference's ``max(miou, nll)`` (losses.py:83): rank 0's
+    logits are noise (NLL larger), rank 1's are confident and mostly right (soft-IoU term larger).  The reference evaluates
+    the max ONCE over the gathered batch; the ranks' averaged loss and gradients must equal that single evaluation (the
+    oracle's ``miou2d`` on the concatenated batch), and without the exchange they must not (or the case tests nothing)."""
+    from oracle import robosat_ref as R
+    from robosat_amd import losses
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    c, n, h, w = 3, 2, 32, 40
+    weight = torch.tensor([1.0, 2.0, 0.5])
+    g = torch.Generator().manual_seed(11)
+    targets = torch.randint(0, c, (world * n, h, w), generator=g)
+    logits = torch.randn(world * n, c, h, w, generator=g)
+    onehot = torch.nn.functional.one_hot(targets, c).permute(0, 3, 1, 2).float()
+    for r in range(1, world, 2):  # odd ranks: confident, 97 % right
+        sl = slice(r * n, (r + 1) * n)
+        flip = (torch.rand(n, 1, h, w, generator=g) < 0.03).float()
+        logits[sl] = 6.0 * (onehot[sl] * (1 - flip) + torch.roll(onehot[sl], 1, 1) * flip) + 0.1 * logits[sl]
+    x_ref = logits.clone().requires_grad_(True)
+    want = R.miou2d(x_ref, targets, weight=weight)
+    want.backward()
+    per_shard = [float(R.miou2d(logits[r * n:(r + 1) * n], targets[r * n:(r + 1) * n], weight=weight)) for r in range(world)]
+    out = {"want": float(want), "per_shard_oracle": per_shard}
+    for name, opt_in in (("global", True), ("per_shard", False)):
+        crit = losses.mIoULoss2d(weight=weight).to(dev)
+        crit.global_batch = opt_in
+        mine = logits[rank * n:(rank + 1) * n].to(dev).requires_grad_(True)
+        loss = crit(mine, targets[rank * n:(rank + 1) * n].to(dev))
+        loss.backward()
+        mean_loss = loss.detach().clone()
+        dist.all_reduce(mean_loss)
+        mean_loss /= world
+        got = mine.grad.cpu() / world
+        want_g = x_ref.grad[rank * n:(rank + 1) * n]
+        out[name] = {"loss": float(loss), "loss_err": abs(float(mean_loss) - float(want)) / abs(float(want)),
+                     "grad_err": float((got - want_g).abs().max() / want_g.abs().max())}
+    return out
+
+
+def gpu_rccl1(dtype):
+    """The RCCL branch of GradReducer on ONE MI355X: a process group of one rank over the nccl backend, the reducer forced
+    (``force=True``) so that every bucket really goes through ``ProcessGroupNCCL`` -- the communicator stream ordered after
+    the weight-gradient stream, five overlapping in-place AVG collectives on views of the one gradient arena, the bf16 wire's
+    cast / SUM / cast back, the single end-of-backward join.  With one rank the average is the identity, so the step's
+    gradients must be BIT-identical to the reducer-less step (bf16 wire: to the bf16 rounding of it)."""
+    import warnings
+
+    from robosat_amd import losses, parallel
+    from robosat_amd.autograd import GradArena
+    from robosat_amd.unet import UNet
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(3)
+    net = UNet(2, pretrained=False, compute_dtype=dtype).to(dev).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 3, 128, 128, generator=g).to(dev)
+    t = torch.randint(0, 2, (4, 128, 128), generator=g).to(dev)
+    crit = losses.LovaszLoss2d().to(dev)
+    params = [p for n, p in net.named_parameters() if not n.startswith("resnet.fc.")]
+
+    def grads(reducer, check_sync=False):
+        net.grad_reducer = reducer
+        for p in net.parameters():
+            p.grad = None
+        GradArena.TRACE = []
+        loss = crit(net(x), t)
+        torch.cuda.synchronize()
+        synced = []
+        if check_sync:  # torch warns on every call that makes the HOST wait for the device while this mode is on
+            torch.cuda.set_sync_debug_mode("warn")
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                loss.backward()
+            synced = [str(wn.message) for wn in caught if "synchroniz" in str(wn.message).lower()]
+        finally:
+            if check_sync:
+                torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        rec, = GradArena.TRACE
+        GradArena.TRACE = None
+        return torch.cat([p.grad.reshape(-1).float() for p in params]), rec, synced
+
+    local, rec0, _ = grads(None)
+    red = parallel.GradReducer(force=True)
+    grads(red)  # (the communicator is created lazily by the first collective: RCCL's own set-up may synchronise)
+    got, rec1, synced = grads(red, check_sync=True)
+    red16 = parallel.GradReducer(wire_dtype=torch.bfloat16, force=True)
+    wire, rec2, _ = grads(red16)
+    # a few optimizer steps with the reducer in the loop: training goes on, weights stay finite
+    net.grad_reducer = red
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    for _ in range(3):
+        opt.zero_grad()
+        crit(net(x), t).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    finite = all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    return {"backend": red.backend, "world": red.world, "issued_fp32": red.issued, "issued_bf16": red16.issued,
+            "bit_identical_fp32": bool(torch.equal(got, local)), "max_abs_diff_fp32": float((got - local).abs().max()),
+            "bit_identical_bf16_rounding": bool(torch.equal(wire, local.bfloat16().float())),
+            "bf16_rel_err": float((wire - local).norm() / local.norm()),
+            "joins": [rec0["joins"], rec1["joins"], rec2["joins"]], "flushes_on_side_stream": [rec1["flushes"], rec2["flushes"]],
+            "host_syncs_in_backward": synced, "finite_after_steps": finite, "grad_norm": float(local.norm())}
+
+
 def main():
     mode, outdir = sys.argv[1], sys.argv[2]
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     from robosat_amd import parallel
 
-    parallel.init_process_group(world, rank, backend="gloo")
+    parallel.init_process_group(world, rank, backend="nccl" if mode.startswith("gpu_rccl1") else "gloo")
     if mode == "cpu":
         res = cpu_logic(rank, world)
     elif mode == "gpu_wce":
         res = gpu_weighted_ce(rank, world)
+    elif mode == "gpu_miou":
+        res = gpu_miou(rank, world)
+    elif mode.startswith("gpu_rccl1"):
+        res = gpu_rccl1(torch.bfloat16 if mode.endswith("bf16") else torch.float32)
     elif mode == "fail":
         if rank == 1:
             sys.exit(3)  # a lost rank: the launcher must stop the survivor (who would wait forever below)

@@ -57,6 +57,42 @@ def test_two_rank_weighted_losses_are_the_global_batch_loss(tmp_path):
             assert r[name]["grad_err"] <= 1e-3, (name, r)
 
 
+def test_two_rank_miou_loss_takes_the_global_branch(tmp_path):
+    """``mIoULoss2d`` returns ``max(miou, nll)`` evaluated ONCE over the gathered batch in the reference
+    (losses.py:72-83 under DataParallel); shards that would choose different branches must still produce the single
+    global-batch loss / gradient once averaged -- and without the exchange they do not (the case is a real one)."""
+    rc, res = run_world2("gpu_miou", tmp_path, timeout=600)
+    assert rc == 0, res
+    a, b = res[0]["per_shard_oracle"]
+    print("mIoU loss: global-batch oracle {:.5f}; per-shard oracle values {:.5f} / {:.5f}".format(res[0]["want"], a, b))
+    for r in res:
+        assert r["global"]["loss_err"] <= 2e-5, r
+        assert r["global"]["grad_err"] <= 1e-3, r
+        assert r["per_shard"]["grad_err"] > 5e-2, r  # per-shard branches: a different gradient (rank 1 takes the IoU term)
+
+
+@pytest.mark.parametrize("mode", ["gpu_rccl1_fp32", "gpu_rccl1_bf16"])
+def test_rccl_branch_of_the_reducer_runs_on_one_gpu(tmp_path, mode):
+    """the ``backend == "nccl"`` branch of GradReducer executed for real -- a world-size-1 RCCL group, the
+    reducer forced on -- inside a full training step: gradients bit-identical to the reducer-less step (fp32 wire; the bf16
+    wire: to their bf16 rounding), one end-of-backward join, every bucket issued under the side stream, no host sync in the
+    backward, and training continues."""
+    rc, res = run_world2(mode, tmp_path, timeout=900, world=1)
+    assert rc == 0, res
+    r, = res
+    print(mode, r)
+    assert r["backend"] == "nccl" and r["world"] == 1
+    assert r["issued_fp32"] >= 5 and r["issued_bf16"] >= 5, r  # five buckets + the stem's rest, every step
+    assert r["grad_norm"] > 0
+    assert r["bit_identical_fp32"], r
+    assert r["bit_identical_bf16_rounding"], r
+    assert r["bf16_rel_err"] <= 4e-3, r
+    assert r["joins"] == [1, 1, 1], r
+    assert all(len(f) >= 5 and all(f) for f in r["flushes_on_side_stream"]), r
+    assert r["host_syncs_in_backward"] == [], r
+    assert r["finite_after_steps"]
+
+
 def _rs(args, env_extra, cwd):
     env = dict(os.environ)
     env.update(env_extra)

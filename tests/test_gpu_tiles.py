@@ -287,11 +287,20 @@ def test_bench_symbols_are_covered(tmp_path):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
+    full = str(tmp_path / "bench_full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "2",
-                        "--no-miou"],
+                        "--no-miou", "--full-json", full],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    # stdout: the compact line (what the driver's 8 KB tail must hold whole) -- the train leg's numbers included
+    compact = r.stdout.strip().splitlines()[-1]
+    assert len(compact) <= 4096, len(compact)
+    brief = json.loads(compact)
+    assert brief["train"]["value"] > 0 and brief["train"]["ms_per_step"] > 0 and "frac" in brief["train"]["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(brief["roofline"])
+    with open(full) as fp:  # the full record: per-kernel tables, every step time
+        line = json.load(fp)
+    assert line["train"]["value"] == brief["train"]["value"] and line["value"] == brief["value"]
     names = set(line["roofline"]["per_kernel"]) | set(line["train"]["roofline"]["per_kernel"])
     assert names, line
     missing = sorted(n for n in names if n not in COVERED)

@@ -404,3 +404,87 @@ def test_nccl_needs_a_device_per_rank():
     check_ranks_fit_devices(2, 1, "gloo")
     with pytest.raises(RuntimeError, match="one device per rank"):
         check_ranks_fit_devices(2, 1, "nccl")
+
+
+def test_resume_reasserts_this_runs_optimizer_flags():
+    """`optimizer.load_state_dict` replaces the param groups with the SAVED ones, which silently dropped
+    `[model] graph = true` (capturable) on --resume from a checkpoint saved without it, and forced it the other way round.
+    Checkpoints carry stock-Adam flags; after the load the run's own configuration is put back."""
+    import copy
+
+    from robosat_amd.graph import capturable
+    from robosat_amd.tools.train import _portable_optimizer_state, _reassert_optimizer_flags
+
+    p = [torch.nn.Parameter(torch.randn(4, 3))]
+    p[0].grad = torch.randn_like(p[0])
+    for saved_capturable in (False, True):
+        opt = torch.optim.Adam(p, lr=1e-3)  # (CPU: fused / capturable steps are GPU-only; the flag is set on the groups below)
+        opt.step()
+        for g in opt.param_groups:
+            g["capturable"] = saved_capturable
+        saved = _portable_optimizer_state(opt)
+        assert all(g["capturable"] is False and g.get("fused") is None for g in saved["param_groups"])
+        for want in (False, True):
+            fresh = torch.optim.Adam(p, lr=1e-3, capturable=want)
+            fresh.load_state_dict(copy.deepcopy(saved))  # (as read from a file: torch's load aliases the step tensors it is given)
+            _reassert_optimizer_flags(fresh, want, torch.device("cpu"))
+            assert capturable(fresh) == want
+            assert all(st["step"].dtype == torch.float32 and float(st["step"]) == 1.0 for st in fresh.state.values())
+            if not want:  # (a capturable Adam only steps on the device: tests/test_gpu_cli.py resumes with [model] graph = true)
+                fresh.step()
+                assert all(float(st["step"]) == 2.0 for st in fresh.state.values())
+
+
+def test_rank_device_check_counts_local_ranks(monkeypatch):
+    """what must fit the visible devices is the NODE-LOCAL rank count, not the job's world size; a launcher that
+    isolates one GPU per rank (HIP_VISIBLE_DEVICES) is fine as well."""
+    from robosat_amd.launch import check_ranks_fit_devices
+
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    check_ranks_fit_devices(16, 8, "nccl", local_world=8, local_rank=3)       # two nodes x 8 GPUs
+    check_ranks_fit_devices(8, 8, "nccl")                                       # one node, env absent: world = local world
+    check_ranks_fit_devices(2, 1, "gloo")                                       # the shared-device tests
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        check_ranks_fit_devices(8, 4, "nccl", local_world=8, local_rank=0)      # two local ranks per device
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        check_ranks_fit_devices(2, 1, "nccl")                                   # one visible device, nothing isolates the ranks
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")
+    check_ranks_fit_devices(8, 1, "nccl")                                       # one GPU per rank, picked by the launcher
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    with pytest.raises(RuntimeError):
+        check_ranks_fit_devices(8, 2, "nccl")
+
+
+def test_bench_prints_a_compact_line_and_keeps_the_full_record(tmp_path):
+    """the driver keeps an 8 KB tail of the bench's stdout; the line must fit it whole -- the train leg's
+    value / ms_per_step / roofline included -- while per-kernel tables and step lists go to a side file."""
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r03", "bench_default.json")) as fp:
+        full = json.load(fp)  # a real full record (round 3, 12.7 KB)
+    assert len(json.dumps(full)) > 8192
+    full["train"]["reducer"] = {"backend": "nccl", "world": 1, "forced": True, "collectives_issued": 180, "wire": "fp32"}
+    path = bench.write_full_record(full, str(tmp_path / "sub" / "bench_full.json"))
+    assert path and json.load(open(path)) == full
+    line = bench.compact_line(full, path)
+    text = json.dumps(line)
+    assert len(text) <= bench.COMPACT_LIMIT, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert line["config"]["workload"].startswith("rs predict") and "model" not in line["config"]
+    t = line["train"]
+    assert t["value"] == full["train"]["value"] and t["ms_per_step"] == full["train"]["ms_per_step"]
+    assert t["step_ms"] == {k: full["train"]["step_ms"][k] for k in ("min", "median", "max", "n", "stalled_steps")}
+    assert t["roofline"]["frac"] == full["train"]["roofline"]["frac"] and "all_convs" in t["roofline"] and "per_kernel" not in t["roofline"]
+    assert t["reducer"]["collectives_issued"] == 180
+    assert set(line["legs"]) == set(full["legs"]) and all(leg["value"] > 0 for leg in line["legs"].values())
+    assert line["full_record"] == path

@@ -11,16 +11,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "dp_worker.py")
 
 
-def run_world2(mode, outdir, timeout=300):
+def run_world2(mode, outdir, timeout=300, world=2):
     from robosat_amd import launch
 
     env = dict(os.environ)
     env["ROBOSAT_DIST_BACKEND"] = "gloo"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    rc = launch.spawn_ranks([sys.executable, WORKER, mode, str(outdir)], 2, env=env, timeout=timeout)
+    rc = launch.spawn_ranks([sys.executable, WORKER, mode, str(outdir)], world, env=env, timeout=timeout)
     res = []
-    for r in range(2):
+    for r in range(world):
         path = os.path.join(str(outdir), "rank{}.json".format(r))
         res.append(json.load(open(path)) if os.path.exists(path) else None)
     return rc, res

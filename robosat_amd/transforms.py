@@ -61,6 +61,12 @@ class Resize:
 
     def __call__(self, image):
         h, w = self.size
+        if image.mode in ("RGBA", "LA") and image.size != (w, h):
+            # An alpha plane that carries DATA (robosat_amd.bands: IR in the A of an RGBA source).  PIL's filters treat A as
+            # coverage: Image.resize converts to premultiplied alpha, resamples and divides back, which rescales RGB by IR / 255
+            # (lossy) and zeroes it wherever IR == 0.  Resample every band on its own -- for the opaque modes the reference uses
+            # (RGB, L, P) this is exactly what PIL does anyway.
+            return Image.merge(image.mode, [band.resize((w, h), self.interpolation) for band in image.split()])
         return image.resize((w, h), self.interpolation)
 
 

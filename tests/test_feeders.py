@@ -232,3 +232,30 @@ def test_four_band_buffered_predict_tiles(tmp_path):
         w = want[tuple(tile.tolist())]
         got = u8.permute(2, 0, 1).float().div(255)
         assert torch.equal(got[:3], w["rgb"]) and torch.equal(got[3], w["ir"][0]), tile
+
+
+def test_resize_treats_an_alpha_plane_as_a_data_band():
+    """``image_modes = ["RGBA"]`` carries IR in the alpha plane.  PIL's own resize premultiplies by alpha (RGB 200
+    under alpha 10 comes back as 204, under alpha 0 as 0); the transform must resample the four bands independently, i.e. give
+    what resizing each band as an 'L' image gives -- also where the alpha plane holds zeros."""
+    from PIL import Image
+
+    from robosat_amd.transforms import Resize
+
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, size=(48, 48, 3), dtype=np.uint8)
+    ir = rng.integers(0, 256, size=(48, 48), dtype=np.uint8)
+    ir[:16] = 0        # a block of zero IR: premultiplied resampling would wipe RGB there
+    ir[16:24] = 10     # and a block of small IR: it would quantise RGB to multiples of ~25
+    img = Image.fromarray(np.dstack([rgb, ir]), mode="RGBA")
+    for size in ((32, 32), (64, 40)):
+        got = np.asarray(Resize(size, Image.BILINEAR)(img))
+        want = np.dstack([np.asarray(Image.fromarray(b).resize((size[1], size[0]), Image.BILINEAR)) for b in list(rgb.transpose(2, 0, 1)) + [ir]])
+        assert got.shape == want.shape and np.array_equal(got, want)
+        naive = np.asarray(img.resize((size[1], size[0]), Image.BILINEAR))
+        assert not np.array_equal(naive[..., :3], want[..., :3])  # (what PIL alone does with the alpha: the bug this guards)
+    # the reference's modes are untouched: same object semantics, same pixels as PIL
+    opaque = Image.fromarray(rgb, mode="RGB")
+    assert np.array_equal(np.asarray(Resize((32, 32), Image.BILINEAR)(opaque)), np.asarray(opaque.resize((32, 32), Image.BILINEAR)))
+    # same size: a copy, whatever the mode
+    assert np.array_equal(np.asarray(Resize((48, 48), Image.BILINEAR)(img)), np.asarray(img))

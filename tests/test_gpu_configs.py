@@ -2,8 +2,8 @@
 surface -- tile and row-size dispatch depends on M and the grid, so "same kernels as the small tests" is checked, not
 inferred:
 
-  configs[1]  rs predict bs 16, 3x512x512 fp32 (the headline benchmark shape) -> oracle parity on two of the 16 tiles
-              (<= 1e-3) and bit-for-bit batch independence;
+  configs[1]  rs predict bs 16, 3x512x512 fp32 (the headline benchmark shape) -> oracle parity on four of the 16 tiles
+              (<= 1e-3) and bit-for-bit batch independence of all 16;
   configs[2]  rs train bf16 bs 32, 3x512x512 (the train leg's shape) -> one full training step against the fp32 CPU
               oracle on the same seeded weights / batch: loss within 2 %, decoder + head gradients cosine >= 0.98, every
               gradient finite, mean cosine over all 168 tensors reported and held to >= 0.90;
@@ -14,7 +14,7 @@ inferred:
   configs[4]  4-band (RGB+IR) multi-class (4 classes) train with the Lovasz loss -> one full fp32 training step against
               the CPU oracle on the same seeded weights (loss, logits, every parameter gradient) at 2 x 4 x 128^2, and the
               configuration AS BASELINE WORDS IT -- bs 32, 4 x 512^2, 4 classes, bf16 -- as one training step against the
-              fp32 oracle (loss 2 %, decoder cosine >= 0.98, mean >= 0.90, worst tensor >= 0.70), with the Lovasz kernel
+              fp32 oracle (loss 2 %, decoder cosine >= 0.98, mean >= 0.90, worst tensor >= 0.85), with the Lovasz kernel
               alone held to 2e-5 / 2e-3 on 1 048 576 keys per image.
 """
 
@@ -111,12 +111,17 @@ def test_cfg2_predict_bs16_512_fp32_headline_shape():
     got = net.predict_probs(x.to(DEV))
     assert got.shape == (16, 2, 512, 512) and got.dtype == torch.float32
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    for i in (0, 15):
+    for i in (0, 5, 10, 15):  # a quarter of the batch through the CPU oracle (~4 s per tile)
         want = R.predict_probs(ref, x[i:i + 1])
         err = float((got[i:i + 1].cpu() - want).abs().max())
         print("cfg2 bs16 512^2 tile", i, "max|dprob| vs oracle", err)
         assert err <= 1e-3  # north_star tolerance (fp32)
-    pair = net.predict_probs(x[[5, 9]].to(DEV))  # same numbers whether a tile travels in a batch of 2 or of 16
+    # ... and ALL 16 tiles ride on those four: a tile's probabilities are bit-for-bit the same whether it travels alone, in a
+    # pair or in the batch of 16 (every output pixel's reduction order is fixed by the layer geometry, never by the batch)
+    for i in range(16):
+        alone = net.predict_probs(x[i:i + 1].to(DEV))
+        assert torch.equal(alone[0], got[i]), i
+    pair = net.predict_probs(x[[5, 9]].to(DEV))
     assert torch.equal(pair[0], got[5]) and torch.equal(pair[1], got[9])
     assert float((got.sum(1) - 1).abs().max()) <= 1e-5
 
@@ -127,7 +132,8 @@ def test_cfg3_train_bs32_512_bf16_step_vs_oracle():
     import psutil
 
     if psutil.virtual_memory().available < 64e9:  # the fp32 CPU oracle keeps ~1.2 GB of autograd state per 512^2 tile
-        pytest.skip("host has < 64 GB free for the bs-32 CPU oracle step")
+        # NOT a skip: a full-size training test that silently vanishes on a smaller box would read as green
+        pytest.xfail("host has < 64 GB free for the bs-32 CPU oracle step: configs[2] at full size NOT checked on this box")
     n, size = 32, 512
     x = seeded.synthetic_images(n, 3, size, size, 13)
     t = seeded.synthetic_targets(n, 2, size, size, 13)
@@ -167,8 +173,9 @@ def test_cfg3_train_bs32_512_bf16_step_vs_oracle():
     # 16 384 samples per channel in the deepest BatchNorm (vs 32 in the bs-2 128^2 calibration test): bf16 storage noise
     # averages out and the encoder's gradients line up with fp32 far better than at toy sizes
     assert mean >= 0.90, mean
-    # ... and no single tensor may point somewhere else: the WORST encoder gradient is bounded too
-    assert worst[1] >= 0.70, worst
+    # ... and no single tensor may point somewhere else: the WORST encoder gradient is bounded too, at what is measured
+    # (round 3: resnet.bn1.bias 0.871; the bar names the tensor when it fails)
+    assert worst[1] >= 0.85, "worst gradient cosine: {} {:.4f}".format(*worst)
 
 
 def test_cfg5_train_bs32_512_bf16_four_band_four_class_step_vs_oracle():
@@ -181,7 +188,7 @@ def test_cfg5_train_bs32_512_bf16_four_band_four_class_step_vs_oracle():
     import psutil
 
     if psutil.virtual_memory().available < 64e9:
-        pytest.skip("host has < 64 GB free for the bs-32 CPU oracle step")
+        pytest.xfail("host has < 64 GB free for the bs-32 CPU oracle step: configs[4] at full size NOT checked on this box")
     n, bands, k, size = 32, 4, 4, 512
     x = seeded.synthetic_images(n, bands, size, size, 15)
     t = seeded.synthetic_targets(n, k, size, size, 15)
@@ -234,4 +241,4 @@ def test_cfg5_train_bs32_512_bf16_four_band_four_class_step_vs_oracle():
         if name.startswith(("dec", "center", "final")):
             assert c >= 0.98, (name, c)
     assert mean >= 0.90, mean
-    assert worst[1] >= 0.70, worst
+    assert worst[1] >= 0.85, "worst gradient cosine: {} {:.4f}".format(*worst)  # (round 3 measured 0.895)

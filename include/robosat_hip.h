@@ -276,6 +276,9 @@ int rs_upsample2x_bwd_dt(const void* dup, void* d1, void* d2, const void* mask1,
  * rs_conv2d_bnstats_rows(d)); rs_bn_finalize_stats turns them into what rs_bn_train_stats returns, saving that
  * kernel's read pass over the activation.  Not for the stem. */
 long rs_conv2d_bnstats_rows(const rs_conv_desc* d);
+/* ... for activations of `dtype` (RS_F32 | RS_BF16): the bf16 halo-once forms of the kernel tile the output into 8 x 32
+ * pixel patches (one partial row per patch) where they run; rs_conv2d_bnstats_rows is the fp32 answer. */
+long rs_conv2d_bnstats_rows_dt(const rs_conv_desc* d, int dtype);
 int rs_conv2d_fwd_bnstats_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2, const void* weight,
                              void* out, float* stats_partial, rs_stream_t stream);
 int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float eps, float momentum, const float* gamma,

@@ -91,6 +91,7 @@ SIGNATURES = {
     "rs_bn_bwd_dt": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_long, c_int, P, P]),
     "rs_upsample2x_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_conv2d_bnstats_rows": (c_long, [POINTER(ConvDesc)]),
+    "rs_conv2d_bnstats_rows_dt": (c_long, [POINTER(ConvDesc), c_int]),
     "rs_conv2d_fwd_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P]),
     "rs_bn_finalize_stats": (c_int, [P, c_long, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rs_pack_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -102,9 +102,9 @@ extern "C" int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int to
 
 const char* const kTileNamesBf16[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
                                             "conv_igemm_bf16<64x64>", "", "conv_igemm_bf16<256x128>",
-                                            "conv_igemm_bf16<256x256>", "conv_thin_bf16"};
-const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 128};
-const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 32};
+                                            "conv_igemm_bf16<256x256>", "conv_thin_bf16", "conv_halo_bf16"};
+const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 128, 256};
+const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 32, 128};
 
 // Dispatcher overrides (rs_conv2d_set_tuning): process-global, for the parity tests (which must reach every tile with
 // small problems) and for A/B measurements.  -1 / 0 = the measured heuristics below.  Initialised from the environment
@@ -114,6 +114,8 @@ struct Tuning {
   int rowb = 0;   // forced K-chunk row bytes: 64 | 128
   int big = 1;    // 8-wave 256x256 tile allowed (bf16, no fused statistics)
   int min256 = 384;  // ... for launches with at least this many 256x256 blocks
+  int halo = 1;      // halo-once forms allowed (bf16; RS_CONV_HALO=0: the implicit-GEMM kernel everywhere, for A/B runs)
+  int halo_min = 192;  // ... for launches with at least this many blocks
 };
 Tuning& tuning() {
   static Tuning t = [] {
@@ -122,6 +124,8 @@ Tuning& tuning() {
     if (const char* e = getenv("RS_CONV_ROWB")) v.rowb = atoi(e);
     if (const char* e = getenv("RS_CONV_BIG")) v.big = atoi(e);
     if (const char* e = getenv("RS_CONV_MIN256")) v.min256 = atoi(e);
+    if (const char* e = getenv("RS_CONV_HALO")) v.halo = atoi(e);
+    if (const char* e = getenv("RS_CONV_HALO_MIN")) v.halo_min = atoi(e);
     return v;
   }();
   return t;
@@ -148,7 +152,7 @@ int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats
   const int ft = tu.tile;
   // a forced tile must be able to run the launch: N tiles whole (or the ragged 128-wide form below), 8 waves only in bf16
   // without fused statistics (the statistics' block reduction is laid out for 256 threads)
-  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && ft != TTHIN && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
+  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && ft != TTHIN && ft != THALO && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
       (ft != T256x256 || (es == 2 && !stats)))
     return ft;
   // 8-wave 256x256 tile (bf16, no fused statistics; one block per CU): half the LDS-DMA bytes per MFMA of the 128x128 tile,
@@ -229,6 +233,39 @@ int thin_mode(const rs_conv_desc* d, bool phase4, bool plain_epilogue) {
   return -1;
 }
 
+// Which halo-once form of the kernel runs this bf16 launch (HALO_NONE: none), and its N tile.  Geometry only -- never the
+// batch size beyond "enough blocks to fill the chip" -- : the rows of a block are an 8 x 32 patch of the grid they enumerate,
+// so that grid must tile into such patches; K-chunks are 128-byte rows.  A forced implicit-GEMM tile
+// (rs_conv2d_set_tuning) keeps the generic kernel; forcing THALO takes the halo form wherever it can run.
+int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out) {
+  const Tuning& tu = tuning();
+  if (!tu.halo || (tu.tile != -1 && tu.tile != THALO)) return HALO_NONE;
+  if ((d->C1 % 64) != 0 || (d->C2 % 64) != 0) return HALO_NONE;
+  int bn;
+  if (d->Cout % 128 == 0) bn = 128;
+  else if (d->Cout > 128 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5) bn = 128;  // ragged last N tile (cf. pick_tile)
+  else if (d->Cout % 64 == 0) bn = 64;
+  else return HALO_NONE;
+  if (csplit > 0 && (csplit % bn) != 0) return HALO_NONE;
+  int mode, gh, gw;  // the grid the block rows enumerate
+  if (phase4) {
+    mode = HALO_PHASE, gh = d->Hs, gw = d->Ws;
+  } else if (d->ups == 0 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->Hs && d->Wo == d->Ws) {
+    mode = HALO_33, gh = d->Ho, gw = d->Wo;
+  } else if (d->ups == 0 && d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->Hs == 2 * d->Ho && d->Ws == 2 * d->Wo && d->C2 == 0) {
+    mode = HALO_DG4, gh = d->Ho, gw = d->Wo;
+  } else {
+    return HALO_NONE;
+  }
+  if ((gh % 8) != 0 || (gw % 32) != 0) return HALO_NONE;
+  const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+  if ((long)d->Hs * d->Ws * cmax * 2 >= (1L << 31)) return HALO_NONE;  // 32-bit DMA offsets within one image
+  const long blocks = (long)d->N * (gh / 8) * (gw / 32) * rs_cdiv(d->Cout, bn) * (phase4 ? 4 : 1);
+  if (tu.tile != THALO && blocks < tu.halo_min) return HALO_NONE;
+  if (bn_out) *bn_out = bn;
+  return mode;
+}
+
 template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
@@ -303,12 +340,8 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.nk = a.ntaps * a.cpt;
   a.Kw = a.nk * kc;
   a.relu = d->relu;
+  a.tpx = a.tpi = 0;
 
-  const int tile = pick_tile(d, phase4, (int)ES, stats != nullptr);
-  if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
-  a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
-  const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
-  hipStream_t s = (hipStream_t)stream;
   // epilogue kind: forward with fused BatchNorm statistics takes no other epilogue input; the data gradient into a
   // BatchNorm takes residual / mask but no scale / shift / ReLU
   int epi = EPI_EVAL;
@@ -318,6 +351,32 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
     if (epi == EPI_STATS && (residual || relu_mask)) return RS_EINVAL;
     if (epi == EPI_BWD && (!bn_mean || !bn_invstd)) return RS_EINVAL;
   }
+  if constexpr (sizeof(T) == 2) {
+    int bn = 0;
+    const int hm = halo_mode(d, phase4, out2 ? csplit : 0, &bn);
+    if (hm != HALO_NONE) {
+      const int gh = hm == HALO_PHASE ? d->Hs : d->Ho, gw = hm == HALO_PHASE ? d->Ws : d->Wo;
+      const int ctot = d->C1 + d->C2;
+      a.cpt = ctot / 64;
+      a.nk = a.cpt * (hm == HALO_DG4 ? 4 : 1);                             // K-groups: parity planes x channel chunks
+      a.Kw = (hm == HALO_PHASE ? 4 : (hm == HALO_33 ? 9 : 16)) * ctot;      // elements per weight row
+      a.tpx = gw / 32;
+      a.tpi = a.tpx * (gh / 8);
+      a.ntiles = rs_cdiv(d->Cout, bn);
+      const int grid = d->N * a.tpi * a.ntiles * (phase4 ? 4 : 1);
+      hipStream_t hs = (hipStream_t)stream;
+      if (hm == HALO_33) rs_conv_launch_bf16_halo33(bn, epi, grid, hs, a);
+      else if (hm == HALO_PHASE) rs_conv_launch_bf16_halo_phase(bn, 0, grid, hs, a);
+      else rs_conv_launch_bf16_halo_dg4(bn, 0, grid, hs, a);
+      return RS_LAUNCH_RESULT();
+    }
+  }
+
+  const int tile = pick_tile(d, phase4, (int)ES, stats != nullptr);
+  if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
+  a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
+  const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
+  hipStream_t s = (hipStream_t)stream;
   launch(kc == kc128 ? 128 : 64, phase4, epi, tile, grid, s, a);
   return RS_LAUNCH_RESULT();
 }
@@ -349,6 +408,14 @@ extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* 
     if (tile) *tile = TTHIN;
     if (rowb) *rowb = d->C1 * 2;
     return 0;
+  }
+  if (es == 2) {  // halo-once forms: reported as THALO with the N tile in `rowb` (the K-chunk rows are always 128 bytes)
+    int bn = 0;
+    if (halo_mode(d, phase4 != 0, 0, &bn) != HALO_NONE) {
+      if (tile) *tile = THALO;
+      if (rowb) *rowb = bn;
+      return 0;
+    }
   }
   if (tile) *tile = pick_tile(d, phase4 != 0, es);
   if (rowb) *rowb = (can128 && pick_rowb(d, es, phase4 != 0) == 128) ? 128 : 64;
@@ -482,9 +549,15 @@ extern "C" int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const vo
 
 extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
-  // (with fused statistics the tile choice does not depend on the element size: every es-specific rule of pick_tile is
-  // switched off by `stats`, so this answer holds for the fp32 and the bf16 launch alike)
+  // (with fused statistics the implicit-GEMM tile choice does not depend on the element size: every es-specific rule of
+  // pick_tile is switched off by `stats`; the bf16 halo forms are asked for through rs_conv2d_bnstats_rows_dt)
   return rs_cdiv((long)d->N * d->Ho * d->Wo, kTileBM[pick_tile(d, false, 4, true)]);
+}
+
+extern "C" long rs_conv2d_bnstats_rows_dt(const rs_conv_desc* d, int dtype) {
+  if (!valid(d) || (dtype != RS_F32 && dtype != RS_BF16)) return RS_EINVAL;
+  if (dtype == RS_BF16 && halo_mode(d, false, 0, nullptr) != HALO_NONE) return (long)d->N * (d->Ho / 8) * (d->Wo / 32);  // one row per patch
+  return rs_conv2d_bnstats_rows(d);
 }
 
 extern "C" int rs_conv2d_dgrad_bnstats_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight,

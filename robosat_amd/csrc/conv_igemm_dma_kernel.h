@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -14,7 +15,15 @@ constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 dat
 // (index 4 is the fp32 stem kernel of conv_igemm.hip: the two files share the index space of rs_conv2d_tile_name)
 // T256x256: 8-wave blocks, one per CU, bf16 only (see pick_tile); T256x128: 8 waves as 4 x 2 (64x64 wave tiles)
 // TTHIN: the all-taps kernels of conv_thin_bf16.hip (the 32-channel decoder tail in bf16), reported through the same index space
-enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, TTHIN, NTILES };
+// THALO: the halo-once forms of this kernel (HALO template parameter below; bf16, 8 waves, a 2-D patch of 8 x 32 pixels
+// per block), reported through the same index space
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, TTHIN, THALO, NTILES };
+// HALO forms: the block's rows are a 2-D PATCH of the output grid; per K-group (one 128-byte channel chunk of one source
+// plane) the patch's source HALO lands in LDS once and every filter tap reads it at a row offset -- the implicit-GEMM
+// form above fetches each source pixel once per tap.  HALO_33: 3x3 / stride 1 / pad 1 (9 taps);  HALO_PHASE: one output
+// parity of the DecoderBlock phase form (2x2 taps on the source grid);  HALO_DG4: the 4x4 / stride-2 data gradient of the
+// phase form = four 2x2 convolutions, one per parity plane of dz, accumulated into the same output patch (16 taps).
+enum { HALO_NONE = 0, HALO_33 = 1, HALO_PHASE = 2, HALO_DG4 = 3 };
 
 template <typename T>
 struct ConvArgsT {
@@ -45,6 +54,7 @@ struct ConvArgsT {
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kh, kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4;
+  int tpx, tpi;  // HALO forms: patches per row of the grid the rows enumerate / per image (nk = K-groups: planes x chunks)
 };
 
 
@@ -59,6 +69,10 @@ RS_CONV_LAUNCHER(rs_conv_launch_bf16_plain_eval, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_plain_stats, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_plain_bwd, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_phase_eval, bf16_t);
+// halo-once forms (bf16): `tile` = BN (128 | 64), `rowb` = the epilogue kind (EPI_*) for the 3x3 form
+RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo33, bf16_t);
+RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_phase, bf16_t);
+RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_dg4, bf16_t);
 
 #ifdef RS_CONV_INSTANTIATE  // ---- kernel + launcher body: only in the instantiating translation units --------------------
 namespace {
@@ -152,6 +166,23 @@ __device__ __forceinline__ void rb_dma16s(__amdgpu_buffer_rsrc_t r, unsigned int
 }
 
 __device__ __forceinline__ void rb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void rb_dma_wait_n() {  // all but the N youngest of this wave's DMA instructions have landed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// f(std::integral_constant<int, 0>()), f(<1>), ...: an unrolled loop whose index is a constant EXPRESSION (the counted
+// s_waitcnt immediates of the halo forms depend on the tap)
+template <class F, int... I>
+__device__ __forceinline__ void rb_for_each(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>()), ...);
+}
+// halo pieces per wave are spread over the taps 0 .. ntap-2 of the PREVIOUS K-group: piece j goes with tap j*(ntap-1)/njh
+constexpr int halo_tap_of_piece(int j, int ntap, int njh) { return j * (ntap - 1) / njh; }
+constexpr int halo_pieces_at_tap(int t, int ntap, int njh) {
+  int n = 0;
+  for (int j = 0; j < njh; ++j) n += halo_tap_of_piece(j, ntap, njh) == t ? 1 : 0;
+  return n;
+}
 __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
   return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
@@ -159,7 +190,8 @@ __device__ __forceinline__ unsigned int rb_lds_addr(const void* p) {
 
 // (second launch bound = waves per SIMD the LDS footprint admits, capped at 4: the register allocation must not be what
 // limits the blocks per CU of the short-K layers, whose co-resident blocks are what hides a block's DMA round trips)
-constexpr int conv_waves_per_simd(int nw, int bm, int bn, int rowb, int es, int epi) {
+constexpr int conv_waves_per_simd(int nw, int bm, int bn, int rowb, int es, int epi, int halo = 0) {
+  if (halo) return 2;  // one 8-wave block per CU (the halo ring + weight ring fill the LDS)
   const int lds = 2 * (bm + bn) * rowb + 9 * bm * 4;
   const int blocks = 160 * 1024 / lds;
   const int w = blocks * nw / 4;
@@ -173,8 +205,8 @@ constexpr int conv_waves_per_simd(int nw, int bm, int bn, int rowb, int es, int 
 //   EPI_EVAL  : scale/shift, residual, ReLU, ReLU mask, two-destination store (predict, and every plain data gradient)
 //   EPI_STATS : raw output + per-tile BatchNorm partial sums (sum y, sum y^2): the train-mode forward
 //   EPI_BWD   : residual, ReLU mask, + partial sums (sum g, sum g * xhat) against bn_y: data gradient into a BatchNorm
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int EPI>
-__global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, BN, ROWB, (int)sizeof(T), EPI)) void conv_igemm_dma(
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int EPI, int HALO = HALO_NONE>
+__global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, BN, ROWB, (int)sizeof(T), EPI, HALO)) void conv_igemm_dma(
     const ConvArgsT<T> p) {
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
   static_assert(ROWB == 128 || ROWB == 64, "a K-chunk is a 128- or 64-byte row");
@@ -193,16 +225,31 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
   constexpr int KS = CPR / 2;         // k-steps per chunk (two pieces each: lanes 0-31 / 32-63)
   constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline buffer
   constexpr int LDO = BN + 4;         // epilogue staging row (floats)
-  constexpr int PIPE = NBUF * BUF, STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
+  // ---- halo forms: geometry of the patch, its halo, the weight ring (see the HALO enum)
+  constexpr bool HL = HALO != HALO_NONE;
+  constexpr int PWD = 32, PHT = BM / 32;           // patch: PHT rows x 32 pixels (a 32-pixel MFMA sub-tile = one patch row)
+  constexpr int HK = HALO == HALO_33 ? 3 : 2;      // taps per dimension of one K-group
+  constexpr int HNT = HK * HK;                     // taps per K-group
+  constexpr int HWD = PWD + HK - 1, HHT = PHT + HK - 1, HROWS = HHT * HWD;  // halo: HHT x HWD source pixels
+  constexpr int NJH = ((HROWS + RI - 1) / RI + NW - 1) / NW;  // halo DMA instructions per wave (every wave issues exactly NJH)
+  constexpr int HALOB = NJH * NW * 1024;           // bytes per halo buffer (two of them)
+  constexpr int DRING = HALO == HALO_33 ? 3 : 4;   // weight ring: HNT % DRING == 0, so a tap's slot is a compile-time constant
+  constexpr int BSLOT = BN * ROWB;                 // one (tap, chunk) of weights
+  constexpr int NBW = IB / NW;                     // weight DMA instructions per wave per step
+  constexpr int PIPE = HL ? 2 * HALOB + DRING * BSLOT : NBUF * BUF;
+  constexpr int STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
   constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
-  constexpr int TABN = (2 * kMaxK + 1) * BM;  // separable gather table (tap row | tap column) x tile row + output rows
+  constexpr int TABN = HL ? BM : (2 * kMaxK + 1) * BM;  // separable gather table (tap row | tap column) x tile row + output rows
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
   static_assert((IA % NW) == 0 && IB >= 1 && (BM % RI) == 0 && (BN % RI) == 0, "DMA instruction split");
+  static_assert(!HL || (sizeof(T) == 2 && NW == 8 && (IB % NW) == 0 && WM % 32 == 0 && HNT % DRING == 0 && (HALO == HALO_PHASE) == PHASE),
+                "halo forms: bf16, 8 waves, whole weight DMA instructions per wave");
+  static_assert(MAINB + TABN * 4 <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAINB + TABN * 4];
   int* taby = reinterpret_cast<int*>(smem + MAINB);  // [kh][BM]: ((n - nfirst)*Hs + iy) * Ws, or -1
   int* tabx = taby + kMaxK * BM;                     // [kw][BM]: ix, or -1
-  int* orow = tabx + kMaxK * BM;                     // [BM]: output pixel index of the row, or -1 past M
+  int* orow = HL ? taby : tabx + kMaxK * BM;         // [BM]: output pixel index of the row, or -1 past M (halo forms: the only table)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -227,14 +274,31 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
   const int HdWd = Hd * Wd;
   // (an integer division runs on the VALU: tell the compiler the quotient is wave-uniform, or the buffer descriptors built
   // from it end up in VGPRs and the LDS-DMA asm cannot take them)
-  const int nfirst = __builtin_amdgcn_readfirstlane(m0 / HdWd);
+  // halo forms: M tile mt = patch (image hn, origin (hy0, hx0) on the Hd x Wd grid); the descriptors start at that image
+  int hn = 0, hy0 = 0, hx0 = 0;
+  if constexpr (HL) {
+    hn = __builtin_amdgcn_readfirstlane(mt / p.tpi);
+    const int rem = mt - hn * p.tpi;
+    const int ty = __builtin_amdgcn_readfirstlane(rem / p.tpx);
+    hy0 = ty * PHT;
+    hx0 = (rem - ty * p.tpx) * PWD;
+  }
+  const int nfirst = HL ? hn : __builtin_amdgcn_readfirstlane(m0 / HdWd);
   const int ush = p.ups ? 1 : 0;
   const int upar = p.ups == 2 ? 1 : 0;
   const int pad_y = PHASE ? 1 - py : p.pad, pad_x = PHASE ? 1 - px : p.pad;
 
   // ---- separable gather table, relative to the tile's first image: source pixel of (row, tap (r, s)) =
   //      taby[r][row] + tabx[s][row] when both are >= 0, else the tap contributes zeros ------------------------------
-  for (int e = tid; e < (p.kh + p.kw + 1) * BM; e += NT) {
+  if constexpr (HL) {
+    for (int e = tid; e < BM; e += NT) {  // row e of the tile = patch pixel (e / 32, e % 32)
+      const int y = hy0 + e / PWD, x = hx0 + e % PWD;
+      int v = -1;
+      if (y < Hd && x < Wd) v = PHASE ? (hn * p.Ho + 2 * y + py) * p.Wo + 2 * x + px : (hn * Hd + y) * Wd + x;
+      orow[e] = v;
+    }
+  }
+  for (int e = tid; e < (HL ? 0 : (p.kh + p.kw + 1) * BM); e += NT) {
     const int t = e / BM, row = e - t * BM;
     const int m = m0 + row;
     int v = -1;
@@ -352,10 +416,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
   // ---- main loop: chunk k+1 streams HBM -> LDS by DMA while the MFMAs of chunk k run; one barrier per chunk.  Each wave
   //      first waits for ITS OWN DMA instructions of chunk k, the barrier publishes everybody's, and only then the buffer
   //      freed by chunk k-1 is refilled.
+  if constexpr (!HL) {
   if (p.nk > 0) {
     begin_chunk(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_piece(q);
+  }
   }
   // The pieces of chunk kc+1 are issued BETWEEN the MFMAs of chunk kc (one piece every PSTEP MFMAs from the start of the
   // chunk): an LDS-DMA instruction costs the issuing wave 60-180 cycles, which a burst at the top of the chunk would add
@@ -391,12 +457,165 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
       for (int q = PIN; q < NI; ++q) issue_piece(q);  // (tiles with fewer MFMAs per chunk than pieces)
     }
   };
-  {
+  if constexpr (!HL) {
     int kc = 0;
     for (; kc < p.nk - 1; ++kc) chunk(kc, std::true_type());
     for (; kc < p.nk; ++kc) chunk(kc, std::false_type());
+  } else {
+    // ================================ halo-once main loop ===================================================================
+    // K = K-groups q (a 128-byte channel chunk of one source plane; HALO_DG4: 4 planes x chunks, else the chunks of the
+    // concat sources) x HNT taps.  LDS: two halo buffers (group q in q & 1) + a ring of DRING weight tiles (tap t in t % DRING).
+    // Step (q, t): weights of step + 2 and, for t <= HNT - 2, this tap's share of the NEXT group's halo are issued between
+    // the MFMAs; at the top of every step a COUNTED wait leaves exactly the previous step's DMA instructions in flight
+    // (weights two steps ahead, halo pieces at least two steps ahead of the group that reads them), then one barrier.
+    // Nothing is branched on inside the loop: past the end the pieces are still issued, out of range (zeros into buffers
+    // nobody reads), so every wave issues the same count in every step -- what the counted waits rely on.
+    constexpr int RPT = WM / 32;  // patch rows per wave row (= TM)
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int ctot = p.C1 + p.C2;
+    // this lane's halo rows: instruction ii = wave + NW*j copies halo rows RI*ii .. (R = hyy * HWD + hxx)
+    int hpix[NJH];  // source pixel (within the image) of the lane's row of piece j for the group being FETCHED, or -1
+    auto halo_pix = [&](int pa, int pb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NJH; ++j) {
+        const int R = RI * (wave + NW * j) + ra;
+        const int hyy = R / HWD, hxx = R - hyy * HWD;
+        int v = -1;
+        if (HALO == HALO_DG4) {  // plane (pa, pb) of dz: sub-grid pixel (u, v) = dz(2u + pa, 2v + pb); rows u0 - pa + {0, 1} feed taps ty = 2r + 1 - pa
+          const int su = hy0 - pa + hyy, sv = hx0 - pb + hxx;
+          if (R < HROWS && (unsigned)su < (unsigned)p.Ho && (unsigned)sv < (unsigned)p.Wo) v = (2 * su + pa) * p.Ws + 2 * sv + pb;
+        } else {
+          const int sy = hy0 - pad_y + hyy, sx = hx0 - pad_x + hxx;
+          if (R < HROWS && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws) v = sy * p.Ws + sx;
+        }
+        hpix[j] = v;
+      }
+    };
+    int hwrow[NBW];  // byte offset of this lane's piece in weight row (n0 + RI*ii + ra), tap 0, channel 0
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) hwrow[j] = ((n0 + RI * (wave + NW * j) + ra) * p.Kw + gp * EPP) * ES;
+    struct Grp {  // K-group (wave-uniform)
+      int c0;     // first channel of the chunk in the concatenated input
+      int pa, pb;  // HALO_DG4: parity plane
+      int live;   // inside the K range
+    };
+    const int Q = p.nk;
+    auto group = [&](int q) __attribute__((always_inline)) {
+      Grp g;
+      g.live = q < Q ? 1 : 0;
+      const int qq = g.live ? q : 0;
+      const int pl = HALO == HALO_DG4 ? qq / p.cpt : 0;
+      g.c0 = (qq - pl * p.cpt) * KC;
+      g.pa = pl >> 1;
+      g.pb = pl & 1;
+      return g;
+    };
+    auto issue_halo = [&](int j, int buf, const Grp& g) __attribute__((always_inline)) {
+      const int first = g.c0 < p.C1 ? 1 : 0;
+      const int cs2 = (first ? p.C1 : p.C2) * ES;
+      const int v = (g.live && hpix[j] >= 0) ? hpix[j] * cs2 + gp * 16 : kDmaOOB;
+      rb_dma16s(first ? rsrc1 : rsrc2, lds0 + buf * HALOB + (wave + NW * j) * 1024, v, (first ? g.c0 : g.c0 - p.C1) * ES);
+    };
+    auto issue_w = [&](int j, int slot, const Grp& g, int tap) __attribute__((always_inline)) {  // tap: compile-time
+      // weight tap of (group, tap): 3x3 -> tap; phase -> tap (the parity's own 2x2 block: rsrcw starts there);
+      // DG4 -> (2r + 1 - pa) * 4 + 2s + 1 - pb
+      const int tau = HALO == HALO_DG4 ? (2 * (tap >> 1) + 1 - g.pa) * 4 + 2 * (tap & 1) + 1 - g.pb : tap;
+      rb_dma16s(rsrcw, lds0 + 2 * HALOB + slot * BSLOT + (wave + NW * j) * 1024, g.live ? hwrow[j] : kDmaOOB, (tau * ctot + g.c0) * ES);
+    };
+    // fragment addressing: A = halo rows of the lane's pixel (patch row wm*RPT + tm, column l31) shifted by the tap,
+    // swizzle key of THAT row; B as in the implicit-GEMM form
+    int rb0[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) rb0[tm] = (wm * RPT + tm) * HWD + l31;
+    const int bfl = ROWB == 128 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    int bfo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bfo[s] = (wn * WN + l31) * ROWB + (((2 * s + hi) ^ bfl) * 16);
+
+    Grp cur = group(0), nxt = group(1);
+    halo_pix(cur.pa, cur.pb);
+#pragma unroll
+    for (int j = 0; j < NJH; ++j) issue_halo(j, 0, cur);
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) issue_w(j, 0, cur, 0);
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) issue_w(j, 1 % DRING, cur, 1);
+    if (HALO == HALO_DG4) halo_pix(nxt.pa, nxt.pb);  // (the pieces issued during group q fetch group q + 1)
+    constexpr int NMMA = KS * TM * TN;
+    for (int q = 0; q < Q; ++q) {
+      const unsigned char* Hb = smem + (q & 1) * HALOB;
+      const int nbuf = (q + 1) & 1;
+      rb_for_each(
+          [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int tprev = (t + HNT - 1) % HNT;
+            // in flight after this wait: what the previous step issued (NBW weight pieces + its halo pieces)
+            // (sched_barrier: the taps are straight-line code, and without it hipcc's machine scheduler moves the next tap's
+            // first fragment reads ABOVE this wait + barrier -- reads of a weight slot whose DMA has not landed)
+            __builtin_amdgcn_sched_barrier(0);
+            rb_dma_wait_n<NBW + halo_pieces_at_tap(tprev, HNT, NJH)>();
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NHT = halo_pieces_at_tap(t, HNT, NJH);  // halo pieces that go with this tap
+            constexpr int NP = NBW + NHT;
+            constexpr int PST = NMMA / (2 * NP) >= 1 ? NMMA / (2 * NP) : 1;  // one piece every PST MFMAs, front-loaded
+            constexpr int t2 = (t + 2) % HNT;
+            auto piece = [&](int i) __attribute__((always_inline)) {  // i: compile-time after unrolling
+              if (i < NBW) {
+                issue_w(i, t2 % DRING, (t + 2 < HNT) ? cur : nxt, t2);
+              } else {
+                int seen = 0;
+#pragma unroll
+                for (int j = 0; j < NJH; ++j) {
+                  if (halo_tap_of_piece(j, HNT, NJH) == t) {
+                    if (seen == i - NBW) issue_halo(j, nbuf, nxt);
+                    ++seen;
+                  }
+                }
+              }
+            };
+            const unsigned char* Bb = smem + 2 * HALOB + (t % DRING) * BSLOT;
+            constexpr int toff = (t / HK) * HWD + (t % HK);
+            int arow[TM], akey[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+              const int R = rb0[tm] + toff;
+              arow[tm] = R * ROWB;
+              akey[tm] = ROWB == 128 ? ((R >> 1) & 7) << 4 : ((R >> 2) & 3) << 4;
+            }
+            auto rd = [&](int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const u32x4*>(Hb + arow[tm] + ((((2 * ks + hi) << 4)) ^ akey[tm]));
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(Bb + 32 * tn * ROWB + bfo[ks]);
+            };
+            u32x4 fa[2][TM], fb[2][TN];
+            rd(0, fa[0], fb[0]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              if (ks + 1 < KS) rd(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                  const int i = (ks * TM + tm) * TN + tn;  // MFMA index within the step (compile-time after unrolling)
+                  if (i % PST == 0 && i / PST < NP) piece(i / PST);
+                  mma16(acc[tn][tm], fb[ks & 1][tn], fa[ks & 1][tm], T());
+                }
+            }
+#pragma unroll
+            for (int i = (NMMA + PST - 1) / PST; i < NP; ++i) piece(i);  // (fewer MFMAs than pieces: never with these tiles)
+          },
+          std::make_integer_sequence<int, HNT>());
+      cur = nxt;
+      nxt = group(q + 2);
+      if (HALO == HALO_DG4) halo_pix(nxt.pa, nxt.pb);
+    }
+    rb_dma_wait();  // the past-the-end pieces too: they write (zeros) into the buffers the epilogue stages through
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();  // every wave is done with the pipeline buffers: the epilogue stages through them
+  if constexpr (HL) __builtin_amdgcn_sched_barrier(0);  // (no staging write may be scheduled above that barrier)
 
   // ---- epilogue: registers -> LDS [pixel][cout] fp32 -> one 16-byte piece of couts per thread, row-wise stores.
   //      TM passes of WGM*32 rows each (pass t = sub-tile tm = t of every wave) keep the staging tile at
@@ -619,6 +838,13 @@ void launch_rows(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
 }
 
 }  // namespace
+
+// halo-once forms: 8 waves as 4 x 2 over a 256-pixel patch (8 rows x 32) x BN couts, 128-byte rows
+template <int HALO, bool PHASE, int EPI>
+void launch_halo(int bn, int grid, hipStream_t s, const ConvArgsT<bf16_t>& a) {
+  if (bn == 128) conv_igemm_dma<bf16_t, 256, 128, 4, 2, 128, PHASE, EPI, HALO><<<grid, 512, 0, s>>>(a);
+  else conv_igemm_dma<bf16_t, 256, 64, 4, 2, 128, PHASE, EPI, HALO><<<grid, 512, 0, s>>>(a);
+}
 
 // RS_CONV_INSTANTIATE(name, T, PHASE, EPI)
 #define RS_CONV_DEFINE_LAUNCHER(name, T, PHASE, EPI)                                            \

@@ -115,7 +115,7 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     if PROFILE is not None:
         ev1.record()
         name = conv_tile_name(d, bf)
-        if alg_scale != 1.0 and not name.startswith("conv_thin"):  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
+        if alg_scale != 1.0 and not name.startswith(("conv_thin", "conv_halo")):  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                 conv_bytes(d, 2 if bf else 4, (residual is not None) + (relu_mask is not None)), conv_flops(d))
@@ -131,7 +131,7 @@ def conv2d_bnstats(src1, weight, src2=None, ups=0, stride=1, pad=0):
     act = src1.dtype
     lib = _lib.lib()
     out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=src1.device, dtype=act)
-    rows = lib.rs_conv2d_bnstats_rows(ctypes.byref(d))
+    rows = lib.rs_conv2d_bnstats_rows_dt(ctypes.byref(d), _dt(src1))
     if rows <= 0:
         raise ValueError("rs_conv2d_bnstats_rows: invalid arguments")
     partial = torch.empty((rows, 2, d.Cout), device=src1.device, dtype=torch.float32)
@@ -162,7 +162,7 @@ def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0,
     lib = _lib.lib()
     out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=dy.device, dtype=act)
     assert bn_y.shape == out.shape
-    rows = lib.rs_conv2d_bnstats_rows(ctypes.byref(d))
+    rows = lib.rs_conv2d_bnstats_rows_dt(ctypes.byref(d), _dt(dy))
     if rows <= 0:
         raise ValueError("rs_conv2d_bnstats_rows: invalid arguments")
     partial = torch.empty((rows, 2, d.Cout), device=dy.device, dtype=torch.float32)
@@ -272,7 +272,7 @@ def conv2d_split(src, weight, c1, stride=1, pad=0, out_hw=None, mask1=None, mask
         ev1.record()
         bf = act == BF16
         name = conv_tile_name(d, bf)
-        if alg_scale != 1.0:
+        if alg_scale != 1.0 and not name.startswith("conv_halo"):
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                 conv_bytes(d, 2 if bf else 4, ((mask1 is not None) * c1 + (mask2 is not None) * (d.Cout - c1)) / d.Cout),
@@ -492,10 +492,12 @@ def conv_tile_name(d, bf16=False, phase=False):
     base = (lib.rs_conv2d_tile_name_bf16 if bf16 else lib.rs_conv2d_tile_name)(tile.value).decode()
     if tile.value == TILES["thin"]:  # conv_thin_bf16.hip: named by the form it computes
         return "{}<{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"))
+    if tile.value == TILES["halo"]:  # halo-once forms of the kernel: form + patch pixels x N tile (`rowb` carries the N tile)
+        return "{}<{},256x{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"), rowb.value)
     return base.replace("<", "<phase," if phase else "<").replace(">", ",r{}>".format(rowb.value))
 
 
-TILES = {"128x128": 0, "128x64": 1, "128x32": 2, "64x64": 3, "256x128": 5, "256x256": 6, "thin": 7}
+TILES = {"128x128": 0, "128x64": 1, "128x32": 2, "64x64": 3, "256x128": 5, "256x256": 6, "thin": 7, "halo": 8}
 
 
 class tuning:

@@ -59,6 +59,18 @@ for STAGE in "$@"; do
     python scripts/pmc_mfma_summary.py $OUT/pmc_mfma > $OUT/pmc_mfma_per_kernel.txt 2>&1; head -30 $OUT/pmc_mfma_per_kernel.txt
     python scripts/pmc_traffic.py $OUT/pmc $OUT/pmc_traffic.json "$TAG" > $OUT/pmc_hbm_traffic.txt 2>&1; head -20 $OUT/pmc_hbm_traffic.txt
     du -sh $OUT ;;
+  halo)
+    bash scripts/halo_sweep.sh > $OUT/halo_sweep.txt 2>&1; cat $OUT/halo_sweep.txt | cut -c1-170 ;;
+  newtests)
+    # this round's new GPU tests first (a failure here should not cost the whole suite's time)
+    timeout 1500 python -m pytest tests/test_gpu_tiles.py -m gpu -q -rP -k "halo" --timeout 600 > $OUT/pytest_halo.log 2>&1; echo "halo tests exit $?"; tail -15 $OUT/pytest_halo.log | cut -c1-300
+    timeout 1200 python -m pytest tests/test_gpu_parallel.py -m gpu -q -rP -k "rccl or miou or weighted" --timeout 900 > $OUT/pytest_dp.log 2>&1; echo "dp tests exit $?"; tail -15 $OUT/pytest_dp.log | cut -c1-400 ;;
+  rccl1)
+    # the RCCL branch of the reducer inside the timed train steps, one GPU (bench.py --force-reducer), fp32 and bf16 wire
+    for W in fp32 bf16; do
+      timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --force-reducer --grad-dtype $W --no-parity --full-json $OUT/bench_rccl1_$W.json > $OUT/bench_rccl1_$W.log 2>&1; echo "exit $?"
+      tail -1 $OUT/bench_rccl1_$W.log | cut -c1-600
+    done ;;
   sweep)
     bash scripts/layer_sweep.sh > $OUT/layer_sweep.txt 2>&1; tail -n 120 $OUT/layer_sweep.txt ;;
   loader)

@@ -17,8 +17,18 @@ import re
 import sys
 from collections import defaultdict
 
+HALO_FORMS = {"1": "3x3", "2": "phase", "3": "dgrad4x4"}
+
+
 def bench_name(k):
     k = k.replace("(anonymous namespace)::", "")
+    # halo-once forms: a ninth template argument (1 = 3x3, 2 = phase, 3 = dgrad4x4); bench.py: conv_halo_bf16<form,BMxBN>
+    m = re.search(r"conv_igemm_dma<__bf16, (\d+), (\d+), \d+, \d+, \d+, (?:true|false), \d+, ([123])>", k)
+    if m:
+        return "conv_halo_bf16<{},{}x{}>".format(HALO_FORMS[m.group(3)], m.group(1), m.group(2))
+    m = re.search(r"conv_igemm_dmaIDF16bLi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb[01]ELi\d+ELi([123])EE", k)
+    if m:
+        return "conv_halo_bf16<{},{}x{}>".format(HALO_FORMS[m.group(3)], m.group(1), m.group(2))
     m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, (?:\d+|true|false))*>", k)
     if m:
         return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "float" else "bf16",

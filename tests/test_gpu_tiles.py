@@ -46,6 +46,10 @@ COVERED |= {"conv_wgrad_bf16<{}>".format(t) for t in ("256x128", "128x128", "128
 COVERED |= {"conv_wgrad_bf16<phase,{}>".format(t) for t in ("128x128", "128x64", "64x128", "64x128+64x64", "128x128+128x64")}
 
 
+# halo-once forms of the kernel (bf16): form x N tile; tests/test_gpu_tiles.py::test_halo_*
+COVERED |= {"conv_halo_bf16<{},256x{}>".format(f, bn) for f in ("3x3", "phase", "dgrad4x4") for bn in (128, 64)}
+
+
 def rnd(*shape, seed=0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
 
@@ -279,6 +283,155 @@ def test_dispatcher_reaches_the_8_wave_tile_unforced():
         x = xd[img:img + 1].float().permute(0, 3, 1, 2).cpu()
         want = F.conv2d(x, wd.float().permute(0, 3, 1, 2).cpu(), padding=1)
         close(nchw(got[img:img + 1]), want, BF, "image {}".format(img))
+
+
+# ---- halo-once forms (conv_igemm_dma_kernel.h, HALO template parameter) ------------------------------------------------------
+def _halo_name(d, phase=False):
+    from robosat_amd import ops
+
+    name = ops.conv_tile_name(d, True, phase=phase)
+    assert name in COVERED, name
+    return name
+
+
+@pytest.mark.parametrize("n,c,cout,h,w", [
+    (2, 64, 64, 8, 32),      # one patch per image, one chunk, the 64-cout N tile (layer1's class)
+    (3, 128, 128, 16, 64),   # 2 x 2 patches per image, two chunks: halo rows from the neighbouring patches, image borders
+    (2, 192, 256, 24, 32),   # three chunks (odd count: both halo buffers end the loop), two N tiles
+    (1, 64, 320, 8, 64),     # ragged last N tile
+])
+def test_halo_3x3_all_epilogues_vs_fp32_reference(n, c, cout, h, w):
+    """3x3 / stride 1 / pad 1 through the halo-once form (Bottleneck.conv2 of layer1-3 in the bf16 train step and its data
+    gradient): eval epilogue (scale / shift + residual + ReLU; ReLU mask), the train-mode statistics epilogue, the
+    data-gradient-into-BatchNorm epilogue (bits mask + the two backward reductions) -- against plain PyTorch fp32 on the same
+    bf16 operands, and against the implicit-GEMM kernel forced on the same launches."""
+    from robosat_amd import ops
+
+    x = prep(rnd(n, c, h, w, seed=61), BF)
+    wt = prep(rnd(cout, c, 3, 3, seed=62) * (2.0 / (c * 9)) ** 0.5, BF)
+    sc, sh = rnd(cout, seed=63).abs() + 0.5, rnd(cout, seed=64)
+    res, mask = prep(rnd(n, cout, h, w, seed=65), BF), prep(rnd(n, cout, h, w, seed=66), BF)
+    base = F.conv2d(x, wt, padding=1)
+    xd, wd = nhwc(x, BF), krsc(wt, BF)
+    with ops.tuning("halo"):
+        d = ops.conv_desc(xd, wd, pad=1)
+        assert _halo_name(d) == "conv_halo_bf16<3x3,256x{}>".format(128 if cout % 128 == 0 or cout > 128 else 64)
+        got = ops.conv2d(xd, wd, pad=1, scale=sc.to(DEV), shift=sh.to(DEV), residual=nhwc(res, BF), relu=True)
+        close(nchw(got), F.relu(base * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), BF, "relu")
+        gotm = ops.conv2d(xd, wd, pad=1, relu_mask=nhwc(mask, BF))
+        close(nchw(gotm), base * (mask > 0), BF, "mask")
+        plain = ops.conv2d(xd, wd, pad=1)
+        if cout % 64 == 0 and cout != 320:
+            y, partial = ops.conv2d_bnstats(xd, wd, pad=1)
+            assert partial.shape[0] == n * (h // 8) * (w // 32)  # one partial row per 8 x 32 patch
+            close(nchw(y), base, BF, "bnstats y")
+            yf = y.float()
+            s = partial.sum(0).cpu()
+            want0, want1 = yf.sum((0, 1, 2)).cpu(), (yf * yf).sum((0, 1, 2)).cpu()
+            assert float((s[0] - want0).abs().max()) <= 1e-3 * float(want0.abs().max() + 1)
+            assert float((s[1] - want1).abs().max()) <= 1e-3 * float(want1.abs().max() + 1)
+            # data gradient into a BatchNorm: g = (conv(dy) + residual) * mask bits, partial sums of g and g * xhat
+            bn_y = prep(rnd(n, cout, h, w, seed=67), BF)
+            mean, invstd = rnd(cout, seed=68) * 0.1, rnd(cout, seed=69).abs() + 0.5
+            z = nhwc(mask, BF)
+            bits = torch.zeros(z.numel() // 8, dtype=torch.uint8, device=DEV)
+            zb = (z.reshape(-1, 8) > 0).to(torch.uint8)
+            for e in range(8):
+                bits |= zb[:, e] << e
+            g, part = ops.conv2d_dgrad_bnstats(xd, wd, (h, w), nhwc(bn_y, BF), mean.to(DEV), invstd.to(DEV), pad=1,
+                                               residual=nhwc(res, BF), relu_mask_bits=bits)
+            want_g = (base + res) * (mask > 0)
+            close(nchw(g), want_g, BF, "dgrad-into-bn g")
+            gf = nchw(g)
+            xhat = (bn_y - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+            ps = part.sum(0).cpu()
+            w0, w1 = gf.sum((0, 2, 3)), (gf * xhat).sum((0, 2, 3))
+            assert float((ps[0] - w0).abs().max()) <= 2e-3 * float(w0.abs().max() + 1)
+            assert float((ps[1] - w1).abs().max()) <= 2e-3 * float(w1.abs().max() + 1)
+    with ops.tuning("128x128" if cout % 128 == 0 or cout > 128 else "128x64", 128):  # the implicit-GEMM kernel: same values up to one bf16 rounding
+        ref = ops.conv2d(xd, wd, pad=1)
+    assert float((plain.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,hs,ws", [
+    (2, 64, 0, 64, 8, 32),       # one patch, one chunk, single source, 64-cout tile (dec2's class)
+    (2, 128, 64, 128, 16, 32),   # two sources (three chunks), two patches per image: halo rows across patches + borders (dec3's class)
+    (1, 256, 64, 256, 8, 64),    # five chunks, two N tiles, two patches side by side (dec1's class)
+])
+def test_halo_phase_form_and_its_gradient_vs_autograd(n, c1, c2, cout, hs, ws):
+    """DecoderBlock (unet.py:63-73) in phase form through the halo-once kernel (one output parity per block, the 2x2 taps
+    from one source halo) and its 4x4 / stride-2 data gradient as four parity-plane 2x2 convolutions, with torch.cat's
+    backward fused into the store -- against autograd on the reference formulation and against the implicit-GEMM kernel."""
+    from robosat_amd import _lib, ops
+
+    a = prep(rnd(n, c1, hs, ws, seed=71), BF).requires_grad_(True)
+    b = prep(rnd(n, c2, hs, ws, seed=72), BF).requires_grad_(True) if c2 else None
+    src = torch.cat([a, b], 1) if c2 else a
+    wt = rnd(cout, c1 + c2, 3, 3, seed=73) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    y = F.relu(F.conv2d(F.interpolate(src, scale_factor=2, mode="nearest"), wt, padding=1))
+    gy = prep(rnd(*y.shape, seed=74), BF)
+    y.backward(gy)
+    w_krsc = krsc(wt, torch.float32)
+    ad = nhwc(a.detach(), BF)
+    bd = nhwc(b.detach(), BF) if c2 else None
+    wp = ops.pack_phase_weight(w_krsc, BF)
+    dz = gy * (y.detach() > 0)
+    dzd = nhwc(dz, BF)
+    wd = ops.pack_dgrad_phase_weight(w_krsc, BF)  # [Cin, 4, 4, Cout]: the gradient's "Cout" is c1 + c2
+    want = torch.cat([a.grad, b.grad], 1) if c2 else a.grad
+    bn_f = 128 if cout % 128 == 0 else 64
+    cg = c1 + c2
+    bn_g = 128 if (cg % 128 == 0 or (cg > 128 and -(-cg // 128) * 128 * 4 <= cg * 5)) else 64
+    with ops.tuning("halo"):
+        d = _lib.ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 1, 0)
+        assert _halo_name(d, phase=True) == "conv_halo_bf16<phase,256x{}>".format(bn_f)
+        got = ops.conv2d_phase(ad, wp, src2=bd, relu=True)
+        close(nchw(got), y.detach(), BF, "phase fwd")
+        dd = ops.conv_desc(dzd, wd, stride=2, pad=1, out_hw=(hs, ws))
+        assert _halo_name(dd) == "conv_halo_bf16<dgrad4x4,256x{}>".format(bn_g)
+        dsrc = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws), alg_scale=2.25)
+        close(nchw(dsrc), want, BF, "dgrad4x4")
+        m1 = prep(rnd(n, c1, hs, ws, seed=75), BF)
+        if c2 and c1 % bn_g == 0:
+            m2 = prep(rnd(n, c2, hs, ws, seed=76), BF)
+            d1, d2 = ops.conv2d_split(dzd, wd, c1, stride=2, pad=1, out_hw=(hs, ws), mask1=nhwc(m1, BF), mask2=nhwc(m2, BF), alg_scale=2.25)
+            close(nchw(d1), a.grad * (m1 > 0), BF, "split d1")
+            close(nchw(d2), b.grad * (m2 > 0), BF, "split d2")
+        elif not c2:
+            dm = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws), relu_mask=nhwc(m1, BF), alg_scale=2.25)
+            close(nchw(dm), a.grad * (m1 > 0), BF, "dgrad4x4 + mask")
+    with ops.tuning("128x128" if bn_f == 128 else "128x64", 128):
+        refp = ops.conv2d_phase(ad, wp, src2=bd, relu=True)
+    with ops.tuning("128x128" if bn_g == 128 else "128x64", 128):
+        refg = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws))
+    assert float((got.float() - refp.float()).abs().max()) <= 2 ** -7 * float(refp.float().abs().max())
+    assert float((dsrc.float() - refg.float()).abs().max()) <= 2 ** -7 * float(refg.float().abs().max())
+
+
+def test_halo_forms_are_what_the_bf16_train_step_runs_unforced():
+    """At the benchmark's sizes (bs 32, 512^2) the dispatcher itself takes the halo forms for the layers they can tile:
+    checked on one image-strided sample per layer against fp32 PyTorch (layer2's conv2 and dec3's DecoderBlock)."""
+    from robosat_amd import _lib, ops
+
+    g = torch.Generator(device=DEV).manual_seed(22)
+    n, c, h, w = 32, 128, 64, 64
+    xd = torch.randn(n, h, w, c, device=DEV, generator=g).to(BF)
+    wd = (torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.03).to(BF)
+    assert ops.conv_tile_name(ops.conv_desc(xd, wd, pad=1), True) == "conv_halo_bf16<3x3,256x128>"
+    got = ops.conv2d(xd, wd, pad=1)
+    for img in (0, 17, n - 1):
+        x = xd[img:img + 1].float().permute(0, 3, 1, 2).cpu()
+        close(nchw(got[img:img + 1]), F.conv2d(x, wd.float().permute(0, 3, 1, 2).cpu(), padding=1), BF, "layer2 conv2 image {}".format(img))
+    n, c1, c2, cout, hs, ws = 4, 256, 64, 128, 128, 128  # dec3's geometry, 4 images (16 384 patches-parities at bs 32; 2 048 here)
+    a = torch.randn(n, hs, ws, c1, device=DEV, generator=g).to(BF)
+    b = torch.randn(n, hs, ws, c2, device=DEV, generator=g).to(BF)
+    wt = torch.randn(cout, c1 + c2, 3, 3, generator=torch.Generator().manual_seed(23)) * 0.02
+    d = _lib.ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 1, 0)
+    assert ops.conv_tile_name(d, True, phase=True) == "conv_halo_bf16<phase,256x128>"
+    got = ops.conv2d_phase(a, ops.pack_phase_weight(krsc(wt, torch.float32), BF), src2=b, relu=True)
+    src = torch.cat([a[:1], b[:1]], 3).float().permute(0, 3, 1, 2).cpu()
+    want = F.relu(F.conv2d(F.interpolate(src, scale_factor=2, mode="nearest"), wt, padding=1))
+    close(nchw(got[:1]), want, BF, "dec3 image 0")
 
 
 def test_bench_symbols_are_covered(tmp_path):

@@ -123,7 +123,7 @@ def test_dispatcher_choices_for_the_benchmark_layers():
         assert lib.rs_conv2d_config(ctypes.byref(d), es, phase, ctypes.byref(tile), ctypes.byref(rowb)) == 0
         name = (lib.rs_conv2d_tile_name_bf16 if es == 2 else lib.rs_conv2d_tile_name)(tile.value).decode()
         if "<" not in name:
-            return "thin", rowb.value
+            return ("halo" if tile.value == 8 else "thin"), rowb.value  # (halo-once forms report their N tile in `rowb`)
         return name[name.index("<") + 1:-1], rowb.value
 
     fp32 = [  # predict bs 16, fp32 (es 4)
@@ -138,12 +138,14 @@ def test_dispatcher_choices_for_the_benchmark_layers():
     bf16 = [  # train bs 32, bf16 (es 2)
         ((32, 128, 128, 64, 0, 0, 1, 1, 0, 128, 128, 256, 2), ("128x128", 64)),      # short K: occupancy
         ((32, 32, 32, 1024, 0, 0, 1, 1, 0, 32, 32, 256, 2), ("128x128", 128)),       # nk128 = 16, 512 blocks
-        ((32, 128, 128, 64, 0, 0, 3, 1, 1, 128, 128, 64, 2), ("128x64", 128)),       # layer1 conv2
-        ((32, 32, 32, 1024, 256, 1, 3, 1, 1, 64, 64, 256, 2, 1), ("256x256", 128)),  # dec1, phase form: 8-wave tile
-        ((32, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 2, 1), ("128x128", 128)),# dec3, phase form
-        ((32, 256, 256, 128, 0, 0, 4, 2, 1, 128, 128, 320, 2), ("128x128", 128)),    # dec3 data gradient: ragged N (320)
-        ((32, 16, 16, 2048, 256, 1, 3, 1, 1, 32, 32, 256, 2, 1), ("128x128", 128)),  # dec0: too few blocks for 256x256
-        ((32, 128, 128, 64, 0, 0, 4, 2, 1, 64, 64, 768, 2), ("256x256", 128)),       # dec2 data gradient: 16 chunks, 1536 blocks
+        ((32, 128, 128, 64, 0, 0, 3, 1, 1, 128, 128, 64, 2), ("halo", 64)),          # layer1 conv2: halo-once 3x3, 64-cout N tile
+        ((32, 32, 32, 256, 0, 0, 3, 1, 1, 32, 32, 256, 2), ("halo", 128)),           # layer3 conv2: 128 patches x 2 N tiles
+        ((32, 16, 16, 512, 0, 0, 3, 1, 1, 16, 16, 512, 2), ("128x64", 128)),         # layer4 conv2: 16 px rows do not tile into 8 x 32 patches
+        ((32, 32, 32, 1024, 256, 1, 3, 1, 1, 64, 64, 256, 2, 1), ("halo", 128)),     # dec1, phase form
+        ((32, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 2, 1), ("halo", 128)),   # dec3, phase form
+        ((32, 256, 256, 128, 0, 0, 4, 2, 1, 128, 128, 320, 2), ("halo", 128)),       # dec3 data gradient: ragged N (320)
+        ((32, 16, 16, 2048, 256, 1, 3, 1, 1, 32, 32, 256, 2, 1), ("128x128", 128)),  # dec0: 16 px rows -> implicit GEMM
+        ((32, 128, 128, 64, 0, 0, 4, 2, 1, 64, 64, 768, 2), ("halo", 128)),          # dec2 data gradient: one chunk x 4 planes x 4 taps
         ((32, 512, 512, 32, 0, 0, 3, 1, 1, 512, 512, 32, 2), ("thin", 64)),          # dec5: all-taps kernel (conv_thin_bf16.hip)
         ((32, 256, 256, 128, 0, 1, 3, 1, 1, 512, 512, 32, 2, 1), ("thin", 256)),     # dec4, phase form: all-taps kernel
         ((32, 512, 512, 32, 0, 0, 4, 2, 1, 256, 256, 128, 2), ("thin", 64)),         # dec4 data gradient: all-taps kernel
@@ -178,6 +180,9 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_igemm_dma<float, 64, 64, 2, 2, 128, true, 0>(ConvArgsT<float>)": "conv_igemm_f32<phase,64x64,r128>",
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi128ELi128ELi2ELi2ELi64ELb0ELi2EEEv9ConvArgsTIT_E": "conv_igemm_bf16<128x128,r64>",
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi256ELi2ELi4ELi128ELb1ELi0EEEv9ConvArgsTIT_E": "conv_igemm_bf16<phase,256x256,r128>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi128ELi4ELi2ELi128ELb1ELi0ELi2EEEv9ConvArgsTIT_E": "conv_halo_bf16<phase,256x128>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi64ELi4ELi2ELi128ELb0ELi1ELi1EEEv9ConvArgsTIT_E": "conv_halo_bf16<3x3,256x64>",
+        ns + "conv_igemm_dma<__bf16, 256, 128, 4, 2, 128, false, 0, 3>(ConvArgsT<__bf16>)": "conv_halo_bf16<dgrad4x4,256x128>",
         ns + "conv_igemm_f32<128, 64, 2, 2, 1>((anonymous namespace)::ConvArgs)": "conv_igemm_f32<128x64,stem>",
         ns + "conv_thin_bf16<1>((anonymous namespace)::ThinConvArgs)": "conv_thin_bf16<phase>",
         ns + "conv_wgrad_thin_bf16<4, 1>((anonymous namespace)::ThinArgs)": "conv_wgrad_thin_bf16<128,ups>",

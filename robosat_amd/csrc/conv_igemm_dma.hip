@@ -261,7 +261,17 @@ int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out) {
   const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
   if ((long)d->Hs * d->Ws * cmax * 2 >= (1L << 31)) return HALO_NONE;  // 32-bit DMA offsets within one image
   const long blocks = (long)d->N * (gh / 8) * (gw / 32) * rs_cdiv(d->Cout, bn) * (phase4 ? 4 : 1);
-  if (tu.tile != THALO && blocks < tu.halo_min) return HALO_NONE;
+  if (tu.tile != THALO) {
+    // Unforced: where the A/B of profiles/r04/halo_sweep_v2.txt (bs 32, every implicit-GEMM tile against the halo form on the
+    // layers of the bf16 train step) says the halo form wins -- by the layer's GEOMETRY only:
+    //   3x3        N tile of 128 (layer2 / layer3 conv2 and their data gradients: -6 .. -12 %; the 64-cout layer1 ties / loses)
+    //   phase      Cout <= 128 (dec2, dec3: -10 .. -13 %); with Cout % 256 == 0 the 8-wave 256x256 tile is faster (dec1: +10 %)
+    //   dgrad4x4   >= 2 channel chunks per plane (dec1, dec3: -8 .. -10 %; dec2's 64 -> 768 is 16 short steps: the 256x256 tile wins)
+    if (blocks < tu.halo_min) return HALO_NONE;
+    if (mode == HALO_33 && bn != 128) return HALO_NONE;
+    if (mode == HALO_PHASE && d->Cout % 256 == 0) return HALO_NONE;
+    if (mode == HALO_DG4 && d->C1 < 128) return HALO_NONE;
+  }
   if (bn_out) *bn_out = bn;
   return mode;
 }

@@ -176,8 +176,9 @@ template <class F, int... I>
 __device__ __forceinline__ void rb_for_each(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>()), ...);
 }
-// halo pieces per wave are spread over the taps 0 .. ntap-2 of the PREVIOUS K-group: piece j goes with tap j*(ntap-1)/njh
-constexpr int halo_tap_of_piece(int j, int ntap, int njh) { return j * (ntap - 1) / njh; }
+// halo pieces per wave are spread over the taps 0 .. ntap-3 of the PREVIOUS K-group (the halo is published one step before
+// the group that reads it starts): piece j goes with tap j*(ntap-2)/njh
+constexpr int halo_tap_of_piece(int j, int ntap, int njh) { return j * (ntap - 2) / njh; }
 constexpr int halo_pieces_at_tap(int t, int ntap, int njh) {
   int n = 0;
   for (int j = 0; j < njh; ++j) n += halo_tap_of_piece(j, ntap, njh) == t ? 1 : 0;
@@ -232,17 +233,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
   constexpr int HNT = HK * HK;                     // taps per K-group
   constexpr int HWD = PWD + HK - 1, HHT = PHT + HK - 1, HROWS = HHT * HWD;  // halo: HHT x HWD source pixels
   constexpr int NJH = ((HROWS + RI - 1) / RI + NW - 1) / NW;  // halo DMA instructions per wave (every wave issues exactly NJH)
-  constexpr int HALOB = NJH * NW * 1024;           // bytes per halo buffer (two of them)
-  constexpr int DRING = HALO == HALO_33 ? 3 : 4;   // weight ring: HNT % DRING == 0, so a tap's slot is a compile-time constant
+  constexpr int HALOB = ((HROWS + RI - 1) / RI) * 1024;  // bytes per halo buffer (two of them): whole DMA instructions
+  constexpr int HSCRATCH = 2 * HALOB;              // one KiB for the zeros of the DMA instructions past the halo's last row
+  constexpr int HBOFF = 2 * HALOB + 1024;          // the weight ring
+  constexpr int DRING = 4;                         // weight ring: step g in slot g & 3 (weights are issued three steps ahead)
   constexpr int BSLOT = BN * ROWB;                 // one (tap, chunk) of weights
   constexpr int NBW = IB / NW;                     // weight DMA instructions per wave per step
-  constexpr int PIPE = HL ? 2 * HALOB + DRING * BSLOT : NBUF * BUF;
+  constexpr int PIPE = HL ? HBOFF + DRING * BSLOT : NBUF * BUF;
   constexpr int STAGE = WGM * 32 * LDO * 4;  // staging: one 32-row sub-tile per wave row at a time
   constexpr int MAINB = PIPE > STAGE ? PIPE : STAGE;
   constexpr int TABN = HL ? BM : (2 * kMaxK + 1) * BM;  // separable gather table (tap row | tap column) x tile row + output rows
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
   static_assert((IA % NW) == 0 && IB >= 1 && (BM % RI) == 0 && (BN % RI) == 0, "DMA instruction split");
-  static_assert(!HL || (sizeof(T) == 2 && NW == 8 && (IB % NW) == 0 && WM % 32 == 0 && HNT % DRING == 0 && (HALO == HALO_PHASE) == PHASE),
+  static_assert(!HL || (sizeof(T) == 2 && NW == 8 && (IB % NW) == 0 && WM % 32 == 0 && HNT >= 4 && KS % 2 == 0 && (HALO == HALO_PHASE) == PHASE),
                 "halo forms: bf16, 8 waves, whole weight DMA instructions per wave");
   static_assert(MAINB + TABN * 4 <= 160 * 1024, "LDS");
 
@@ -464,13 +467,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
   } else {
     // ================================ halo-once main loop ===================================================================
     // K = K-groups q (a 128-byte channel chunk of one source plane; HALO_DG4: 4 planes x chunks, else the chunks of the
-    // concat sources) x HNT taps.  LDS: two halo buffers (group q in q & 1) + a ring of DRING weight tiles (tap t in t % DRING).
-    // Step (q, t): weights of step + 2 and, for t <= HNT - 2, this tap's share of the NEXT group's halo are issued between
-    // the MFMAs; at the top of every step a COUNTED wait leaves exactly the previous step's DMA instructions in flight
-    // (weights two steps ahead, halo pieces at least two steps ahead of the group that reads them), then one barrier.
+    // concat sources) x HNT taps; step g = q * HNT + t.  LDS: two halo buffers (group q in q & 1) + a ring of DRING = 4
+    // weight tiles (step g in g & 3).  The wait + barrier at the top of step g publish the weights of step g + 1 (and, at a
+    // group's last tap, the next group's halo): one step EARLY, so that the first fragments of step g + 1 are read at the
+    // end of step g and its MFMAs start right behind its barrier instead of behind an LDS round trip.  During step g the
+    // weights of step g + 3 and, for t <= HNT - 3, this tap's share of the NEXT group's halo are issued between the MFMAs;
+    // the counted wait at the top of every step leaves exactly the previous step's DMA instructions in flight.
     // Nothing is branched on inside the loop: past the end the pieces are still issued, out of range (zeros into buffers
     // nobody reads), so every wave issues the same count in every step -- what the counted waits rely on.
     constexpr int RPT = WM / 32;  // patch rows per wave row (= TM)
+    constexpr int NHI = (HROWS + RI - 1) / RI;  // halo DMA instructions that carry rows; the surplus ones (ii >= NHI) land in a scratch KiB
     const int hi = lane >> 5, l31 = lane & 31;
     const int ctot = p.C1 + p.C2;
     // this lane's halo rows: instruction ii = wave + NW*j copies halo rows RI*ii .. (R = hyy * HWD + hxx)
@@ -514,13 +520,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
       const int first = g.c0 < p.C1 ? 1 : 0;
       const int cs2 = (first ? p.C1 : p.C2) * ES;
       const int v = (g.live && hpix[j] >= 0) ? hpix[j] * cs2 + gp * 16 : kDmaOOB;
-      rb_dma16s(first ? rsrc1 : rsrc2, lds0 + buf * HALOB + (wave + NW * j) * 1024, v, (first ? g.c0 : g.c0 - p.C1) * ES);
+      const int ii = wave + NW * j;  // (wave-uniform) instructions past the halo's last row write their zeros to the scratch KiB
+      rb_dma16s(first ? rsrc1 : rsrc2, lds0 + (ii < NHI ? buf * HALOB + ii * 1024 : HSCRATCH), v, (first ? g.c0 : g.c0 - p.C1) * ES);
     };
     auto issue_w = [&](int j, int slot, const Grp& g, int tap) __attribute__((always_inline)) {  // tap: compile-time
       // weight tap of (group, tap): 3x3 -> tap; phase -> tap (the parity's own 2x2 block: rsrcw starts there);
       // DG4 -> (2r + 1 - pa) * 4 + 2s + 1 - pb
       const int tau = HALO == HALO_DG4 ? (2 * (tap >> 1) + 1 - g.pa) * 4 + 2 * (tap & 1) + 1 - g.pb : tap;
-      rb_dma16s(rsrcw, lds0 + 2 * HALOB + slot * BSLOT + (wave + NW * j) * 1024, g.live ? hwrow[j] : kDmaOOB, (tau * ctot + g.c0) * ES);
+      rb_dma16s(rsrcw, lds0 + HBOFF + slot * BSLOT + (wave + NW * j) * 1024, g.live ? hwrow[j] : kDmaOOB, (tau * ctot + g.c0) * ES);
     };
     // fragment addressing: A = halo rows of the lane's pixel (patch row wm*RPT + tm, column l31) shifted by the tap,
     // swizzle key of THAT row; B as in the implicit-GEMM form
@@ -530,39 +537,55 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     const int bfl = ROWB == 128 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     int bfo[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bfo[s] = (wn * WN + l31) * ROWB + (((2 * s + hi) ^ bfl) * 16);
+    for (int s = 0; s < KS; ++s) bfo[s] = HBOFF + (wn * WN + l31) * ROWB + (((2 * s + hi) ^ bfl) * 16);
+    // fragments of k-step `ks` of the step with tap offset `toff` on halo buffer `hbuf`, weight slot `slot` (uniform)
+    auto rd = [&](int hbuf, int slot, int toff, int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int R = rb0[tm] + toff;
+        const int key = ROWB == 128 ? ((R >> 1) & 7) << 4 : ((R >> 2) & 3) << 4;
+        a[tm] = *reinterpret_cast<const u32x4*>(smem + hbuf * HALOB + R * ROWB + (((2 * ks + hi) << 4) ^ key));
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(smem + slot * BSLOT + 32 * tn * ROWB + bfo[ks]);
+    };
 
     Grp cur = group(0), nxt = group(1);
     halo_pix(cur.pa, cur.pb);
 #pragma unroll
     for (int j = 0; j < NJH; ++j) issue_halo(j, 0, cur);
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) issue_w(j, 0, cur, 0);
+    for (int d = 0; d < 3; ++d)  // weights of steps 0, 1, 2 (HNT >= 4)
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) issue_w(j, 1 % DRING, cur, 1);
+      for (int j = 0; j < NBW; ++j) issue_w(j, d, cur, d);
     if (HALO == HALO_DG4) halo_pix(nxt.pa, nxt.pb);  // (the pieces issued during group q fetch group q + 1)
     constexpr int NMMA = KS * TM * TN;
+    u32x4 fa[2][TM], fb[2][TN];
+    rb_dma_wait_n<NBW>();  // halo 0 and the weights of steps 0 and 1 have landed (step 2's may still fly)
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    rd(0, 0, 0, 0, fa[0], fb[0]);  // first fragments of step 0
     for (int q = 0; q < Q; ++q) {
-      const unsigned char* Hb = smem + (q & 1) * HALOB;
-      const int nbuf = (q + 1) & 1;
+      const int hbuf = q & 1, nbuf = (q + 1) & 1;
       rb_for_each(
           [&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
             constexpr int tprev = (t + HNT - 1) % HNT;
-            // in flight after this wait: what the previous step issued (NBW weight pieces + its halo pieces)
-            // (sched_barrier: the taps are straight-line code, and without it hipcc's machine scheduler moves the next tap's
-            // first fragment reads ABOVE this wait + barrier -- reads of a weight slot whose DMA has not landed)
+            // (sched_barrier: the taps are straight-line code, and without it hipcc's machine scheduler moves fragment reads
+            // and MFMAs across this wait + barrier)
             __builtin_amdgcn_sched_barrier(0);
+            // in flight after this wait: what the previous step issued (NBW weight pieces + its halo pieces)
             rb_dma_wait_n<NBW + halo_pieces_at_tap(tprev, HNT, NJH)>();
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NHT = halo_pieces_at_tap(t, HNT, NJH);  // halo pieces that go with this tap
             constexpr int NP = NBW + NHT;
             constexpr int PST = NMMA / (2 * NP) >= 1 ? NMMA / (2 * NP) : 1;  // one piece every PST MFMAs, front-loaded
-            constexpr int t2 = (t + 2) % HNT;
+            constexpr int t3 = (t + 3) % HNT;
+            const int gstep = q * HNT + t;  // (wave-uniform)
             auto piece = [&](int i) __attribute__((always_inline)) {  // i: compile-time after unrolling
               if (i < NBW) {
-                issue_w(i, t2 % DRING, (t + 2 < HNT) ? cur : nxt, t2);
+                issue_w(i, (gstep + 3) & (DRING - 1), (t + 3 < HNT) ? cur : nxt, t3);
               } else {
                 int seen = 0;
 #pragma unroll
@@ -574,26 +597,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
                 }
               }
             };
-            const unsigned char* Bb = smem + 2 * HALOB + (t % DRING) * BSLOT;
             constexpr int toff = (t / HK) * HWD + (t % HK);
-            int arow[TM], akey[TM];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-              const int R = rb0[tm] + toff;
-              arow[tm] = R * ROWB;
-              akey[tm] = ROWB == 128 ? ((R >> 1) & 7) << 4 : ((R >> 2) & 3) << 4;
-            }
-            auto rd = [&](int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-              for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const u32x4*>(Hb + arow[tm] + ((((2 * ks + hi) << 4)) ^ akey[tm]));
-#pragma unroll
-              for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(Bb + 32 * tn * ROWB + bfo[ks]);
-            };
-            u32x4 fa[2][TM], fb[2][TN];
-            rd(0, fa[0], fb[0]);
+            constexpr int tn1 = (t + 1) % HNT;                        // the following step: its tap offset,
+            constexpr int toff1 = (tn1 / HK) * HWD + (tn1 % HK);
+            const int hbuf1 = (t + 1 < HNT) ? hbuf : nbuf;           // ... halo buffer and weight slot
+            const int slot = gstep & (DRING - 1), slot1 = (gstep + 1) & (DRING - 1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-              if (ks + 1 < KS) rd(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+              // k-step ks + 1 of this step -- or, behind the last one, k-step 0 of the NEXT step (published by this step's barrier)
+              if (ks + 1 < KS) rd(hbuf, slot, toff, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+              else rd(hbuf1, slot1, toff1, 0, fa[0], fb[0]);
 #pragma unroll
               for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

@@ -181,10 +181,9 @@ def gpu_miou(rank, world):
     targets = torch.randint(0, c, (world * n, h, w), generator=g)
     logits = torch.randn(world * n, c, h, w, generator=g)
     onehot = torch.nn.functional.one_hot(targets, c).permute(0, 3, 1, 2).float()
-    for r in range(1, world, 2):  # odd ranks: confident, 97 % right
+    for r in range(1, world, 2):  # odd ranks: confident and right (p ~ 0.96): NLL ~ 0.04 < soft-IoU term ~ 0.07 -> the IoU branch alone
         sl = slice(r * n, (r + 1) * n)
-        flip = (torch.rand(n, 1, h, w, generator=g) < 0.03).float()
-        logits[sl] = 6.0 * (onehot[sl] * (1 - flip) + torch.roll(onehot[sl], 1, 1) * flip) + 0.1 * logits[sl]
+        logits[sl] = 4.0 * onehot[sl] + 0.1 * logits[sl]
     x_ref = logits.clone().requires_grad_(True)
     want = R.miou2d(x_ref, targets, weight=weight)
     want.backward()

@@ -410,7 +410,8 @@ def test_halo_phase_form_and_its_gradient_vs_autograd(n, c1, c2, cout, hs, ws):
 
 def test_halo_forms_are_what_the_bf16_train_step_runs_unforced():
     """At the benchmark's sizes (bs 32, 512^2) the dispatcher itself takes the halo forms for the layers they can tile:
-    checked on one image-strided sample per layer against fp32 PyTorch (layer2's conv2 and dec3's DecoderBlock)."""
+    checked on one image-strided sample per layer against fp32 PyTorch (layer2's conv2 and dec3's DecoderBlock); and the
+    layers where the implicit-GEMM tiles measured faster keep them (profiles/r04/halo_sweep_v2.txt)."""
     from robosat_amd import _lib, ops
 
     g = torch.Generator(device=DEV).manual_seed(22)

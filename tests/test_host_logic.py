@@ -138,14 +138,17 @@ def test_dispatcher_choices_for_the_benchmark_layers():
     bf16 = [  # train bs 32, bf16 (es 2)
         ((32, 128, 128, 64, 0, 0, 1, 1, 0, 128, 128, 256, 2), ("128x128", 64)),      # short K: occupancy
         ((32, 32, 32, 1024, 0, 0, 1, 1, 0, 32, 32, 256, 2), ("128x128", 128)),       # nk128 = 16, 512 blocks
-        ((32, 128, 128, 64, 0, 0, 3, 1, 1, 128, 128, 64, 2), ("halo", 64)),          # layer1 conv2: halo-once 3x3, 64-cout N tile
-        ((32, 32, 32, 256, 0, 0, 3, 1, 1, 32, 32, 256, 2), ("halo", 128)),           # layer3 conv2: 128 patches x 2 N tiles
+        ((32, 128, 128, 64, 0, 0, 3, 1, 1, 128, 128, 64, 2), ("128x64", 128)),       # layer1 conv2: the 64-cout halo form ties / loses
+        ((32, 64, 64, 128, 0, 0, 3, 1, 1, 64, 64, 128, 2), ("halo", 128)),           # layer2 conv2: halo-once 3x3 (-7 %)
+        ((32, 32, 32, 256, 0, 0, 3, 1, 1, 32, 32, 256, 2), ("halo", 128)),           # layer3 conv2: 128 patches x 2 N tiles (-12 %)
         ((32, 16, 16, 512, 0, 0, 3, 1, 1, 16, 16, 512, 2), ("128x64", 128)),         # layer4 conv2: 16 px rows do not tile into 8 x 32 patches
-        ((32, 32, 32, 1024, 256, 1, 3, 1, 1, 64, 64, 256, 2, 1), ("halo", 128)),     # dec1, phase form
-        ((32, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 2, 1), ("halo", 128)),   # dec3, phase form
-        ((32, 256, 256, 128, 0, 0, 4, 2, 1, 128, 128, 320, 2), ("halo", 128)),       # dec3 data gradient: ragged N (320)
+        ((32, 32, 32, 1024, 256, 1, 3, 1, 1, 64, 64, 256, 2, 1), ("256x256", 128)),  # dec1, phase form: 8-wave tile (halo form: +10 %)
+        ((32, 64, 64, 512, 256, 1, 3, 1, 1, 128, 128, 64, 2, 1), ("halo", 64)),      # dec2, phase form (-10 %)
+        ((32, 128, 128, 256, 64, 1, 3, 1, 1, 256, 256, 128, 2, 1), ("halo", 128)),   # dec3, phase form (-13 %)
+        ((32, 256, 256, 128, 0, 0, 4, 2, 1, 128, 128, 320, 2), ("halo", 128)),       # dec3 data gradient: ragged N (320) (-10 %)
+        ((32, 64, 64, 256, 0, 0, 4, 2, 1, 32, 32, 1280, 2), ("halo", 128)),          # dec1 data gradient (-8 %)
         ((32, 16, 16, 2048, 256, 1, 3, 1, 1, 32, 32, 256, 2, 1), ("128x128", 128)),  # dec0: 16 px rows -> implicit GEMM
-        ((32, 128, 128, 64, 0, 0, 4, 2, 1, 64, 64, 768, 2), ("halo", 128)),          # dec2 data gradient: one chunk x 4 planes x 4 taps
+        ((32, 128, 128, 64, 0, 0, 4, 2, 1, 64, 64, 768, 2), ("256x256", 128)),       # dec2 data gradient: 16 short steps, the 8-wave tile wins
         ((32, 512, 512, 32, 0, 0, 3, 1, 1, 512, 512, 32, 2), ("thin", 64)),          # dec5: all-taps kernel (conv_thin_bf16.hip)
         ((32, 256, 256, 128, 0, 1, 3, 1, 1, 512, 512, 32, 2, 1), ("thin", 256)),     # dec4, phase form: all-taps kernel
         ((32, 512, 512, 32, 0, 0, 4, 2, 1, 256, 256, 128, 2), ("thin", 64)),         # dec4 data gradient: all-taps kernel

@@ -116,6 +116,7 @@ struct Tuning {
   int min256 = 384;  // ... for launches with at least this many 256x256 blocks
   int halo = 1;      // halo-once forms allowed (bf16; RS_CONV_HALO=0: the implicit-GEMM kernel everywhere, for A/B runs)
   int halo_min = 192;  // ... for launches with at least this many blocks
+  int halo512 = -1;    // unforced launches: the 512-pixel patch -- -1 by the rule in halo_mode, 0 never, 1 wherever it can run (RS_CONV_HALO512)
 };
 Tuning& tuning() {
   static Tuning t = [] {
@@ -126,6 +127,7 @@ Tuning& tuning() {
     if (const char* e = getenv("RS_CONV_MIN256")) v.min256 = atoi(e);
     if (const char* e = getenv("RS_CONV_HALO")) v.halo = atoi(e);
     if (const char* e = getenv("RS_CONV_HALO_MIN")) v.halo_min = atoi(e);
+    if (const char* e = getenv("RS_CONV_HALO512")) v.halo512 = atoi(e);
     return v;
   }();
   return t;
@@ -237,10 +239,13 @@ int thin_mode(const rs_conv_desc* d, bool phase4, bool plain_epilogue) {
 // batch size beyond "enough blocks to fill the chip" -- : the rows of a block are an 8 x 32 patch of the grid they enumerate,
 // so that grid must tile into such patches; K-chunks are 128-byte rows.  A forced implicit-GEMM tile
 // (rs_conv2d_set_tuning) keeps the generic kernel; forcing THALO takes the halo form wherever it can run.
-int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out) {
+int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out, int* bm_out = nullptr) {
   const Tuning& tu = tuning();
   if (!tu.halo || (tu.tile != -1 && tu.tile != THALO)) return HALO_NONE;
-  if ((d->C1 % 64) != 0 || (d->C2 % 64) != 0) return HALO_NONE;
+  // patch of 512 pixels (16 x 32) with 32-channel chunks, or of 256 (8 x 32) with 64-channel chunks
+  bool big = tu.tile == THALO ? tu.rowb == 64 : tu.halo512 != 0;  // (unforced + auto: decided below, once the grid is known)
+  const bool c64 = (d->C1 % 64) == 0 && (d->C2 % 64) == 0;  // 64-channel chunks (256-pixel patch) possible
+  if ((d->C1 % 32) != 0 || (d->C2 % 32) != 0) return HALO_NONE;
   int bn;
   if (d->Cout % 128 == 0) bn = 128;
   else if (d->Cout > 128 && (long)rs_cdiv(d->Cout, 128) * 128 * 4 <= (long)d->Cout * 5) bn = 128;  // ragged last N tile (cf. pick_tile)
@@ -257,10 +262,18 @@ int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out) {
   } else {
     return HALO_NONE;
   }
-  if ((gh % 8) != 0 || (gw % 32) != 0) return HALO_NONE;
+  // unforced: the 512-pixel patch (2/3 of the DMA bytes and 3/4 of the fragment reads per MFMA) where there is at least one
+  // such patch per CU -- layer2's conv2 (-17 % against the implicit GEMM; the 256-pixel patch: -7 %), dec3 forward and data
+  // gradient (-16 %; -10 %); with fewer patches (layer3, dec1: 64) the 256-pixel patch or the 8-wave tile win
+  // (profiles/r04/halo_sweep_v3.txt)
+  if (tu.tile != THALO && tu.halo512 < 0) big = (long)d->N * (gh / 16) * (gw / 32) >= 256;
+  if (big && (bn != 128 || (gh % 16) != 0)) big = false;
+  if (!big && !c64) return HALO_NONE;
+  const int ph = big ? 16 : 8;
+  if ((gh % ph) != 0 || (gw % 32) != 0) return HALO_NONE;
   const long cmax = d->C1 > d->C2 ? d->C1 : d->C2;
   if ((long)d->Hs * d->Ws * cmax * 2 >= (1L << 31)) return HALO_NONE;  // 32-bit DMA offsets within one image
-  const long blocks = (long)d->N * (gh / 8) * (gw / 32) * rs_cdiv(d->Cout, bn) * (phase4 ? 4 : 1);
+  const long blocks = (long)d->N * (gh / ph) * (gw / 32) * rs_cdiv(d->Cout, bn) * (phase4 ? 4 : 1);
   if (tu.tile != THALO) {
     // Unforced: where the A/B of profiles/r04/halo_sweep_v2.txt (bs 32, every implicit-GEMM tile against the halo form on the
     // layers of the bf16 train step) says the halo form wins -- by the layer's GEOMETRY only:
@@ -273,6 +286,7 @@ int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out) {
     if (mode == HALO_DG4 && d->C1 < 128) return HALO_NONE;
   }
   if (bn_out) *bn_out = bn;
+  if (bm_out) *bm_out = ph * 32;
   return mode;
 }
 
@@ -362,20 +376,22 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
     if (epi == EPI_BWD && (!bn_mean || !bn_invstd)) return RS_EINVAL;
   }
   if constexpr (sizeof(T) == 2) {
-    int bn = 0;
-    const int hm = halo_mode(d, phase4, out2 ? csplit : 0, &bn);
+    int bn = 0, bm = 256;
+    const int hm = halo_mode(d, phase4, out2 ? csplit : 0, &bn, &bm);
     if (hm != HALO_NONE) {
       const int gh = hm == HALO_PHASE ? d->Hs : d->Ho, gw = hm == HALO_PHASE ? d->Ws : d->Wo;
       const int ctot = d->C1 + d->C2;
-      a.cpt = ctot / 64;
+      a.cpt = ctot / (bm == 512 ? 32 : 64);
       a.nk = a.cpt * (hm == HALO_DG4 ? 4 : 1);                             // K-groups: parity planes x channel chunks
       a.Kw = (hm == HALO_PHASE ? 4 : (hm == HALO_33 ? 9 : 16)) * ctot;      // elements per weight row
       a.tpx = gw / 32;
-      a.tpi = a.tpx * (gh / 8);
+      a.tpi = a.tpx * (gh / (bm / 32));
       a.ntiles = rs_cdiv(d->Cout, bn);
       const int grid = d->N * a.tpi * a.ntiles * (phase4 ? 4 : 1);
       hipStream_t hs = (hipStream_t)stream;
+      if (bm == 512) bn |= 0x1000;
       if (hm == HALO_33) rs_conv_launch_bf16_halo33(bn, epi, grid, hs, a);
+      else if (hm == HALO_PHASE && bn == 128 && getenv("RS_HALO_KO")) rs_conv_launch_bf16_halo_phase_ko(atoi(getenv("RS_HALO_KO")), grid, hs, a);  // (measurement only)
       else if (hm == HALO_PHASE) rs_conv_launch_bf16_halo_phase(bn, 0, grid, hs, a);
       else rs_conv_launch_bf16_halo_dg4(bn, 0, grid, hs, a);
       return RS_LAUNCH_RESULT();
@@ -420,10 +436,10 @@ extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* 
     return 0;
   }
   if (es == 2) {  // halo-once forms: reported as THALO with the N tile in `rowb` (the K-chunk rows are always 128 bytes)
-    int bn = 0;
-    if (halo_mode(d, phase4 != 0, 0, &bn) != HALO_NONE) {
+    int bn = 0, bm = 256;
+    if (halo_mode(d, phase4 != 0, 0, &bn, &bm) != HALO_NONE) {
       if (tile) *tile = THALO;
-      if (rowb) *rowb = bn;
+      if (rowb) *rowb = bn | (bm == 512 ? 0x1000 : 0);  // (N tile; + 0x1000: the 512-pixel patch)
       return 0;
     }
   }
@@ -566,7 +582,8 @@ extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
 
 extern "C" long rs_conv2d_bnstats_rows_dt(const rs_conv_desc* d, int dtype) {
   if (!valid(d) || (dtype != RS_F32 && dtype != RS_BF16)) return RS_EINVAL;
-  if (dtype == RS_BF16 && halo_mode(d, false, 0, nullptr) != HALO_NONE) return (long)d->N * (d->Ho / 8) * (d->Wo / 32);  // one row per patch
+  int bn = 0, bm = 256;
+  if (dtype == RS_BF16 && halo_mode(d, false, 0, &bn, &bm) != HALO_NONE) return (long)d->N * (d->Ho / (bm / 32)) * (d->Wo / 32);  // one row per patch
   return rs_conv2d_bnstats_rows(d);
 }
 

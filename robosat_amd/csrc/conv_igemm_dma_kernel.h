@@ -73,6 +73,7 @@ RS_CONV_LAUNCHER(rs_conv_launch_bf16_phase_eval, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo33, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_phase, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_dg4, bf16_t);
+__attribute__((visibility("hidden"))) void rs_conv_launch_bf16_halo_phase_ko(int ko, int grid, hipStream_t s, const ConvArgsT<bf16_t>& a);
 
 #ifdef RS_CONV_INSTANTIATE  // ---- kernel + launcher body: only in the instantiating translation units --------------------
 namespace {
@@ -206,7 +207,9 @@ constexpr int conv_waves_per_simd(int nw, int bm, int bn, int rowb, int es, int 
 //   EPI_EVAL  : scale/shift, residual, ReLU, ReLU mask, two-destination store (predict, and every plain data gradient)
 //   EPI_STATS : raw output + per-tile BatchNorm partial sums (sum y, sum y^2): the train-mode forward
 //   EPI_BWD   : residual, ReLU mask, + partial sums (sum g, sum g * xhat) against bn_y: data gradient into a BatchNorm
-template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int EPI, int HALO = HALO_NONE>
+// KO (measurement builds only, conv_halo_ko.hip; results are WRONG for KO != 0): knock-outs of the halo main loop that say
+// where its time goes -- 1: no waits / barriers, 2: no DMA, 3: no fragment reads (one set reused), 4: no MFMAs.
+template <typename T, int BM, int BN, int WGM, int WGN, int ROWB, bool PHASE, int EPI, int HALO = HALO_NONE, int KO = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, BN, ROWB, (int)sizeof(T), EPI, HALO)) void conv_igemm_dma(
     const ConvArgsT<T> p) {
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
@@ -567,6 +570,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     rd(0, 0, 0, 0, fa[0], fb[0]);  // first fragments of step 0
     for (int q = 0; q < Q; ++q) {
       const int hbuf = q & 1, nbuf = (q + 1) & 1;
+      // (opaque to the optimiser on purpose: the HNT x TM fragment row addresses are loop-invariant per lane, and hipcc would
+      // hoist all of them out of the group loop -- up to 72 registers -- and spill; recomputed per tap they are a few VALU)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(rb0[tm]));
       rb_for_each(
           [&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
@@ -575,8 +582,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
             // and MFMAs across this wait + barrier)
             __builtin_amdgcn_sched_barrier(0);
             // in flight after this wait: what the previous step issued (NBW weight pieces + its halo pieces)
-            rb_dma_wait_n<NBW + halo_pieces_at_tap(tprev, HNT, NJH)>();
-            __syncthreads();
+            if constexpr (KO != 1) {
+              rb_dma_wait_n<NBW + halo_pieces_at_tap(tprev, HNT, NJH)>();
+              __syncthreads();
+            }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NHT = halo_pieces_at_tap(t, HNT, NJH);  // halo pieces that go with this tap
             constexpr int NP = NBW + NHT;
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
             constexpr int t3 = (t + 3) % HNT;
             const int gstep = q * HNT + t;  // (wave-uniform)
             auto piece = [&](int i) __attribute__((always_inline)) {  // i: compile-time after unrolling
+              if constexpr (KO == 2) return;
               if (i < NBW) {
                 issue_w(i, (gstep + 3) & (DRING - 1), (t + 3 < HNT) ? cur : nxt, t3);
               } else {
@@ -605,15 +615,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
               // k-step ks + 1 of this step -- or, behind the last one, k-step 0 of the NEXT step (published by this step's barrier)
-              if (ks + 1 < KS) rd(hbuf, slot, toff, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-              else rd(hbuf1, slot1, toff1, 0, fa[0], fb[0]);
+              if constexpr (KO != 3) {
+                if (ks + 1 < KS) rd(hbuf, slot, toff, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                else rd(hbuf1, slot1, toff1, 0, fa[0], fb[0]);
+              }
 #pragma unroll
               for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                   const int i = (ks * TM + tm) * TN + tn;  // MFMA index within the step (compile-time after unrolling)
                   if (i % PST == 0 && i / PST < NP) piece(i / PST);
-                  mma16(acc[tn][tm], fb[ks & 1][tn], fa[ks & 1][tm], T());
+                  if constexpr (KO == 4) {
+                    asm volatile("" ::"v"(fb[ks & 1][tn]), "v"(fa[ks & 1][tm]));  // (the fragments stay live: the reads are not dead code)
+                  } else if constexpr (KO == 3) {
+                    mma16(acc[tn][tm], fb[0][tn], fa[0][tm], T());
+                  } else {
+                    mma16(acc[tn][tm], fb[ks & 1][tn], fa[ks & 1][tm], T());
+                  }
                 }
             }
 #pragma unroll
@@ -852,10 +870,13 @@ void launch_rows(int tile, int grid, hipStream_t s, const ConvArgsT<T>& a) {
 
 }  // namespace
 
-// halo-once forms: 8 waves as 4 x 2 over a 256-pixel patch (8 rows x 32) x BN couts, 128-byte rows
+// halo-once forms: 8 waves as 4 x 2 over a 256-pixel patch (8 rows x 32) x BN couts with 128-byte rows (64-channel
+// chunks), or -- `bn` = 128 | 0x1000 -- over a 512-pixel patch (16 rows x 32) x 128 couts with 64-byte rows (32-channel
+// chunks): wave tiles of 128 x 64, 2/3 of the weight DMA bytes and 3/4 of the fragment reads per MFMA
 template <int HALO, bool PHASE, int EPI>
 void launch_halo(int bn, int grid, hipStream_t s, const ConvArgsT<bf16_t>& a) {
-  if (bn == 128) conv_igemm_dma<bf16_t, 256, 128, 4, 2, 128, PHASE, EPI, HALO><<<grid, 512, 0, s>>>(a);
+  if (bn == (128 | 0x1000)) conv_igemm_dma<bf16_t, 512, 128, 4, 2, 64, PHASE, EPI, HALO><<<grid, 512, 0, s>>>(a);
+  else if (bn == 128) conv_igemm_dma<bf16_t, 256, 128, 4, 2, 128, PHASE, EPI, HALO><<<grid, 512, 0, s>>>(a);
   else conv_igemm_dma<bf16_t, 256, 64, 4, 2, 128, PHASE, EPI, HALO><<<grid, 512, 0, s>>>(a);
 }
 

@@ -493,7 +493,8 @@ def conv_tile_name(d, bf16=False, phase=False):
     if tile.value == TILES["thin"]:  # conv_thin_bf16.hip: named by the form it computes
         return "{}<{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"))
     if tile.value == TILES["halo"]:  # halo-once forms of the kernel: form + patch pixels x N tile (`rowb` carries the N tile)
-        return "{}<{},256x{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"), rowb.value)
+        return "{}<{},{}x{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"),
+                                     512 if rowb.value & 0x1000 else 256, rowb.value & 0xFFF)
     return base.replace("<", "<phase," if phase else "<").replace(">", ",r{}>".format(rowb.value))
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the halo-once forms against the implicit-GEMM tiles on the layers of the bf16 train step they can run
 # (scripts/bench_layer.py; "auto" = what the dispatcher picks, "halo/0" = the halo form forced).
-V="auto halo/0 128x128/128 128x64/128 256x128/128 256x256/128"
+V="auto halo/0 halo/64 128x128/128 256x128/128 256x256/128"
 echo "## bf16 bs 32: Bottleneck.conv2 forward with BN statistics (layer1..3)"
 timeout 600 python scripts/bench_layer.py --variants "$V" \
   bf16:stats:32,64,128,128,64,3,1,1 bf16:stats:32,128,64,64,128,3,1,1 bf16:stats:32,256,32,32,256,3,1,1

@@ -48,6 +48,7 @@ COVERED |= {"conv_wgrad_bf16<phase,{}>".format(t) for t in ("128x128", "128x64",
 
 # halo-once forms of the kernel (bf16): form x N tile; tests/test_gpu_tiles.py::test_halo_*
 COVERED |= {"conv_halo_bf16<{},256x{}>".format(f, bn) for f in ("3x3", "phase", "dgrad4x4") for bn in (128, 64)}
+COVERED |= {"conv_halo_bf16<{},512x128>".format(f) for f in ("3x3", "phase", "dgrad4x4")}  # 16 x 32 patches, 32-channel chunks
 
 
 def rnd(*shape, seed=0):
@@ -406,6 +407,69 @@ def test_halo_phase_form_and_its_gradient_vs_autograd(n, c1, c2, cout, hs, ws):
         refg = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws))
     assert float((got.float() - refp.float()).abs().max()) <= 2 ** -7 * float(refp.float().abs().max())
     assert float((dsrc.float() - refg.float()).abs().max()) <= 2 ** -7 * float(refg.float().abs().max())
+
+
+@pytest.mark.parametrize("n,c,cout,h,w", [
+    (2, 96, 128, 16, 32),    # one 16 x 32 patch per image, three 32-channel chunks (96 is no multiple of 64: only this form can run it)
+    (2, 128, 256, 32, 64),   # 2 x 2 patches, four chunks, two N tiles
+])
+def test_halo512_3x3_epilogues_vs_fp32_reference(n, c, cout, h, w):
+    """The 512-pixel-patch variant (16 x 32 pixels, 32-channel chunks, wave tiles of 128 x 64) of the 3x3 halo form: eval
+    epilogue, train-mode statistics, against plain PyTorch fp32 on the same bf16 operands."""
+    from robosat_amd import ops
+
+    x = prep(rnd(n, c, h, w, seed=81), BF)
+    wt = prep(rnd(cout, c, 3, 3, seed=82) * (2.0 / (c * 9)) ** 0.5, BF)
+    res, mask = prep(rnd(n, cout, h, w, seed=85), BF), prep(rnd(n, cout, h, w, seed=86), BF)
+    base = F.conv2d(x, wt, padding=1)
+    xd, wd = nhwc(x, BF), krsc(wt, BF)
+    with ops.tuning("halo", 64):
+        assert _halo_name(ops.conv_desc(xd, wd, pad=1)) == "conv_halo_bf16<3x3,512x128>"
+        got = ops.conv2d(xd, wd, pad=1, residual=nhwc(res, BF), relu=True)
+        close(nchw(got), F.relu(base + res), BF, "relu")
+        gotm = ops.conv2d(xd, wd, pad=1, relu_mask=nhwc(mask, BF))
+        close(nchw(gotm), base * (mask > 0), BF, "mask")
+        y, partial = ops.conv2d_bnstats(xd, wd, pad=1)
+        assert partial.shape[0] == n * (h // 16) * (w // 32)
+        close(nchw(y), base, BF, "bnstats y")
+        yf = y.float()
+        s = partial.sum(0).cpu()
+        want0, want1 = yf.sum((0, 1, 2)).cpu(), (yf * yf).sum((0, 1, 2)).cpu()
+        assert float((s[0] - want0).abs().max()) <= 1e-3 * float(want0.abs().max() + 1)
+        assert float((s[1] - want1).abs().max()) <= 1e-3 * float(want1.abs().max() + 1)
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,hs,ws", [
+    (2, 128, 64, 128, 16, 32),   # dec3's class: two sources (4 + 2 chunks of 32 channels), one patch per image
+    (1, 64, 0, 128, 32, 64),     # single source, 2 x 2 patches
+])
+def test_halo512_phase_form_and_its_gradient_vs_autograd(n, c1, c2, cout, hs, ws):
+    """DecoderBlock phase form and its 4x4 / stride-2 data gradient on the 512-pixel-patch variant, against autograd."""
+    from robosat_amd import _lib, ops
+
+    a = prep(rnd(n, c1, hs, ws, seed=91), BF).requires_grad_(True)
+    b = prep(rnd(n, c2, hs, ws, seed=92), BF).requires_grad_(True) if c2 else None
+    src = torch.cat([a, b], 1) if c2 else a
+    wt = rnd(cout, c1 + c2, 3, 3, seed=93) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    y = F.relu(F.conv2d(F.interpolate(src, scale_factor=2, mode="nearest"), wt, padding=1))
+    gy = prep(rnd(*y.shape, seed=94), BF)
+    y.backward(gy)
+    w_krsc = krsc(wt, torch.float32)
+    ad = nhwc(a.detach(), BF)
+    bd = nhwc(b.detach(), BF) if c2 else None
+    dzd = nhwc(gy * (y.detach() > 0), BF)
+    wd = ops.pack_dgrad_phase_weight(w_krsc, BF)
+    want = torch.cat([a.grad, b.grad], 1) if c2 else a.grad
+    with ops.tuning("halo", 64):
+        d = _lib.ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 1, 0)
+        assert _halo_name(d, phase=True) == "conv_halo_bf16<phase,512x128>"
+        got = ops.conv2d_phase(ad, ops.pack_phase_weight(w_krsc, BF), src2=bd, relu=True)
+        close(nchw(got), y.detach(), BF, "phase fwd")
+        cg = c1 + c2
+        if cg % 128 == 0 or (cg > 128 and -(-cg // 128) * 128 * 4 <= cg * 5):
+            assert _halo_name(ops.conv_desc(dzd, wd, stride=2, pad=1, out_hw=(hs, ws))) == "conv_halo_bf16<dgrad4x4,512x128>"
+        dsrc = ops.conv2d(dzd, wd, stride=2, pad=1, out_hw=(hs, ws), alg_scale=2.25)
+        close(nchw(dsrc), want, BF, "dgrad4x4")
 
 
 def test_halo_forms_are_what_the_bf16_train_step_runs_unforced():

@@ -286,41 +286,6 @@ int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float e
                          float* running_var, long long* num_batches_tracked, void* workspace, rs_stream_t stream);
 /* (workspace: 64 * 2 * C doubles, optional -- enables the parallel first-level reduction when rows > 256) */
 
-/* The same two steps -- convolution with partial statistics, then the finalize -- in ONE launch: the block of the convolution
- * that arrives last (per slice of 64 partial rows, then per N tile) sums the rows in row order and writes what
- * rs_bn_finalize_stats writes (mode 0: mean / invstd / scale / shift / running statistics of torch.nn.BatchNorm2d in train
- * mode, unet.py:127-130 via torchvision's Bottleneck), or what the first half of rs_bn_bwd_from_partials_dt writes (mode 1:
- * dgamma, dbeta and the three coefficient rows coef[3][C] that rs_bn_bwd_apply_dt turns into dy).  ~100 dependent 8 us
- * launches per training step disappear from the critical path.  `workspace`: rs_bn_fin_workspace_bytes(rows, C) bytes;
- * `counters`: rs_bn_fin_counter_words() 32-bit words that are ZERO when the launch starts -- every launch leaves them at
- * zero, so one zero-initialised buffer per stream serves every launch on that stream. */
-typedef struct rs_bn_fin {
-  int mode;
-  long M;                                 /* elements per channel (N * Ho * Wo) */
-  float eps, momentum;                    /* mode 0 */
-  const float* gamma;                     /* both modes */
-  const float* beta;                      /* mode 0 */
-  const float* invstd_in;                 /* mode 1: the layer's forward invstd */
-  float *mean, *invstd, *scale, *shift;   /* mode 0 outputs [C] */
-  float *running_mean, *running_var;      /* mode 0, optional, updated in place */
-  long long* num_batches_tracked;         /* mode 0, optional, += 1 */
-  float *dgamma, *dbeta, *coef;           /* mode 1 outputs: [C], [C], [3][C] */
-  void* workspace;
-  unsigned int* counters;
-} rs_bn_fin;
-long rs_bn_fin_workspace_bytes(long rows, int C);
-long rs_bn_fin_counter_words(void);
-int rs_conv2d_fwd_bnstats_fin_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2, const void* weight,
-                                 void* out, float* stats_partial, const rs_bn_fin* fin, rs_stream_t stream);
-/* relu_mask (a tensor shaped like out) or relu_mask_bits (one bit per element), or neither */
-int rs_conv2d_dgrad_bnstats_fin_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight, const void* residual,
-                                   const void* relu_mask, const unsigned char* relu_mask_bits, const void* bn_y,
-                                   const float* bn_mean, const float* bn_invstd, void* out, float* stats_partial,
-                                   const rs_bn_fin* fin, rs_stream_t stream);
-/* dy = coef[0][c] * g - coef[1][c] - coef[2][c] * (y - mean[c]): the streaming pass of BatchNorm's backward */
-int rs_bn_bwd_apply_dt(const void* g, const void* y, const float* mean, const float* coef, void* dy, int dtype, long M, int C,
-                       rs_stream_t stream);
-
 /* Phase form of DecoderBlock (unet.py:73: conv3x3(pad 1) over interpolate(nearest, x2)): each output parity (oy&1, ox&1)
  * sees a 2x2 convolution on the SOURCE grid whose taps are sums of the 3x3 taps that fall on the same source pixel, so
  * the layer is four 2x2 convolutions with 4/9 of the multiply-adds and no duplicated gathers -- same result up to fp32

@@ -32,20 +32,6 @@ class ConvDesc(ctypes.Structure):
 
 P = c_void_p  # device pointers and the stream travel as void*
 
-
-class BnFin(ctypes.Structure):
-    """``rs_bn_fin`` (include/robosat_hip.h): the BatchNorm finalize fused into the convolution that produced the partial rows."""
-
-    _fields_ = [
-        ("mode", c_int32), ("M", ctypes.c_long), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
-        ("gamma", c_void_p), ("beta", c_void_p), ("invstd_in", c_void_p),
-        ("mean", c_void_p), ("invstd", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
-        ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
-        ("dgamma", c_void_p), ("dbeta", c_void_p), ("coef", c_void_p),
-        ("workspace", c_void_p), ("counters", c_void_p),
-    ]
-
-
 # name -> (restype, argtypes); must list every symbol declared in include/robosat_hip.h
 SIGNATURES = {
     "rs_abi_version": (c_int, []),
@@ -106,11 +92,6 @@ SIGNATURES = {
     "rs_upsample2x_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_conv2d_bnstats_rows": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_bnstats_rows_dt": (c_long, [POINTER(ConvDesc), c_int]),
-    "rs_bn_fin_workspace_bytes": (c_long, [c_long, c_int]),
-    "rs_bn_fin_counter_words": (c_long, []),
-    "rs_conv2d_fwd_bnstats_fin_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, POINTER(BnFin), P]),
-    "rs_conv2d_dgrad_bnstats_fin_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P, POINTER(BnFin), P]),
-    "rs_bn_bwd_apply_dt": (c_int, [P, P, P, P, P, c_int, c_long, c_int, P]),
     "rs_conv2d_fwd_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P]),
     "rs_bn_finalize_stats": (c_int, [P, c_long, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rs_pack_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -176,16 +176,6 @@ def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
     """conv -> train-mode BatchNorm (-> + residual -> ReLU) with the statistics fused into the convolution: returns
     (y, z, (mean, invstd), ReLU mask bits of z or None)."""
 
-    if ops.fused_finalize():  # the statistics are finalized by the convolution's own last-arriving blocks: one launch less
-        y, (mean, invstd, scale, shift) = ops.conv2d_bn_train(
-            src, w, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-            bn.num_batches_tracked, stride=stride, pad=pad)
-        bn._folded = None
-        if relu and ops.bn_bits_ok(y.shape[-1]):
-            z, bits = ops.bn_apply(y, scale, shift, residual=residual, relu=relu, want_bits=True)
-        else:
-            z, bits = ops.bn_apply(y, scale, shift, residual=residual, relu=relu), None
-        return y, z, (mean, invstd), bits
     y, partial = ops.conv2d_bnstats(src, w, stride=stride, pad=pad)
     z, st, bits = _bn_train(bn, y, residual=residual, relu=relu, partial=partial, want_bits=True)
     return y, z, st, bits
@@ -343,28 +333,14 @@ def _backward(net, tape, dlogits, arena):
     skip_grad = {id(r.layer2[0]): g_enc1, id(r.layer3[0]): g_enc2, id(r.layer4[0]): g_enc3}
     layer_heads = {id(r.layer1[0]), id(r.layer2[0]), id(r.layer3[0]), id(r.layer4[0])}
 
-    fused = ops.fused_finalize()
-
-    def dgrad_into_bn(dy, conv, out_hw, y, st, z, bits, residual=None, bn=None):
+    def dgrad_into_bn(dy, conv, out_hw, y, st, z, bits, residual=None):
         """Gradient at the OUTPUT of a BatchNorm+ReLU (z) from the convolution that consumed z, with the ReLU mask (z's sign:
         its bit form when the forward wrote one) and BatchNorm's two backward reductions done in the convolution's
-        epilogue: returns (g, partial) -- or, with the finalize fused into the launch as well (``bn`` given), (g, coef): the
-        layer's dgamma / dbeta are then already in the arena and only the streaming pass is left."""
+        epilogue: returns (g, partial)."""
         wd = conv.dgrad_weight(dy.dtype)
-        if fused and bn is not None:
-            g, coef, _, _ = ops.conv2d_dgrad_bn(dy, wd, out_hw, y, st[0], st[1], bn.weight.detach(), ups=2 if conv.stride == 2 else 0,
-                                                pad=conv.k - 1 - conv.padding, residual=residual,
-                                                relu_mask=z if bits is None else None, relu_mask_bits=bits, **bn_grads(bn))
-            return g, coef
         return ops.conv2d_dgrad_bnstats(dy, wd, out_hw, y, st[0], st[1], ups=2 if conv.stride == 2 else 0,
                                         pad=conv.k - 1 - conv.padding, residual=residual,
                                         relu_mask=z if bits is None else None, relu_mask_bits=bits)
-
-    def bn_bwd_after(g, y, st, bn, p):
-        """dy of a BatchNorm whose gradient g came out of ``dgrad_into_bn`` with p = its partial rows or (fused) coefficients."""
-        if fused:
-            return ops.bn_bwd_apply(g, y, st[0], p)
-        return ops.bn_bwd_from_partials(g, y, st[0], st[1], bn.weight.detach(), p, **bn_grads(bn))[0]
 
     g_partial = None  # partial sums riding with g when a fused dgrad produced it
     blocks = tape.blocks
@@ -376,22 +352,23 @@ def _backward(net, tape, dlogits, arena):
             dy3, _, _, gm = ops.bn_bwd(g, rec["z3"], rec["y3"], rec["st3"][0], rec["st3"][1], blk.bn3.weight.detach(),
                                        want_masked=True, **bn_grads(blk.bn3))
         else:  # g is already masked (it IS the residual-branch gradient) and its reductions are done
-            dy3 = bn_bwd_after(g, rec["y3"], rec["st3"], blk.bn3, g_partial)
+            dy3, _, _ = ops.bn_bwd_from_partials(g, rec["y3"], rec["st3"][0], rec["st3"][1], blk.bn3.weight.detach(), g_partial,
+                                                 **bn_grads(blk.bn3))
             gm = g
         del g
         w3 = arena.conv(blk.conv3)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy3, rec["z2"], 1, 1, out=w3), dy3, rec["z2"])
-        g2, p2 = dgrad_into_bn(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]), rec["y2"], rec["st2"], rec["z2"], rec["b2"],
-                               bn=blk.bn2)
+        g2, p2 = dgrad_into_bn(dy3, blk.conv3, (rec["z2"].shape[1], rec["z2"].shape[2]), rec["y2"], rec["st2"], rec["z2"], rec["b2"])
         del dy3
-        dy2 = bn_bwd_after(g2, rec["y2"], rec["st2"], blk.bn2, p2)
+        dy2, _, _ = ops.bn_bwd_from_partials(g2, rec["y2"], rec["st2"][0], rec["st2"][1], blk.bn2.weight.detach(), p2,
+                                             **bn_grads(blk.bn2))
         del g2
         w2 = arena.conv(blk.conv2)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=w2), dy2, rec["z1"])
-        g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"], rec["b1"],
-                               bn=blk.bn1)
+        g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"], rec["b1"])
         del dy2
-        dy1 = bn_bwd_after(g1, rec["y1"], rec["st1"], blk.bn1, p1)
+        dy1, _, _ = ops.bn_bwd_from_partials(g1, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), p1,
+                                             **bn_grads(blk.bn1))
         del g1
         w1 = arena.conv(blk.conv1)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy1, h, 1, 1, out=w1), dy1, h)
@@ -408,8 +385,7 @@ def _backward(net, tape, dlogits, arena):
             res = gm
         if bi > 0:  # h is the previous bottleneck's z3 = relu(bn3(y3) + identity): fuse its mask + reductions
             prev = blocks[bi - 1]
-            g, g_partial = dgrad_into_bn(dy1, blk.conv1, hw_in, prev["y3"], prev["st3"], prev["z3"], prev["b3"], residual=res,
-                                         bn=prev["blk"].bn3)
+            g, g_partial = dgrad_into_bn(dy1, blk.conv1, hw_in, prev["y3"], prev["st3"], prev["z3"], prev["b3"], residual=res)
         else:  # h is the stem's pooled output
             g, g_partial = _dgrad(dy1, blk.conv1, hw_in, residual=res), None
         del dy1, res, gm

@@ -647,21 +647,6 @@ extern "C" int rs_bn_bwd_from_partials_dt(const void* g, const void* y, const fl
   return RS_LAUNCH_RESULT();
 }
 
-extern "C" int rs_bn_bwd_apply_dt(const void* g, const void* y, const float* mean, const float* coef, void* dy, int dtype, long M,
-                                  int C, rs_stream_t stream) {
-  if (!g || !y || !mean || !coef || !dy || M <= 0 || C <= 0 || (C & 3)) return RS_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == RS_F32)
-    bn_bwd_apply_launch<float>(reinterpret_cast<const float*>(g), nullptr, reinterpret_cast<const float*>(y), mean, coef,
-                               reinterpret_cast<float*>(dy), nullptr, M, C, s);
-  else if (dtype == RS_BF16)
-    bn_bwd_apply_launch<bf16_t>(reinterpret_cast<const bf16_t*>(g), nullptr, reinterpret_cast<const bf16_t*>(y), mean, coef,
-                                reinterpret_cast<bf16_t*>(dy), nullptr, M, C, s);
-  else
-    return RS_EINVAL;
-  return RS_LAUNCH_RESULT();
-}
-
 extern "C" int rs_bn_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
                          const float* gamma, float* dy, float* dmasked, float* dgamma, float* dbeta, long M, int C,
                          void* workspace, rs_stream_t stream) {

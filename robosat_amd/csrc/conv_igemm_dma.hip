@@ -109,8 +109,6 @@ const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 32, 128};
 // Dispatcher overrides (rs_conv2d_set_tuning): process-global, for the parity tests (which must reach every tile with
 // small problems) and for A/B measurements.  -1 / 0 = the measured heuristics below.  Initialised from the environment
 // (RS_CONV_TILE, RS_CONV_ROWB, RS_CONV_BIG) so that a whole benchmark run can be steered from outside.
-constexpr long kBnFinCounterWords = 4096;  // >= 64 slices x 32 N tiles + 32 (Cout <= 2048 on 64-wide tiles)
-
 struct Tuning {
   int tile = -1;  // forced tile index, honoured whenever the launch can run it
   int rowb = 0;   // forced K-chunk row bytes: 64 | 128
@@ -297,14 +295,8 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
              float* stats = nullptr, const void* bn_y = nullptr, const float* bn_mean = nullptr,
              const float* bn_invstd = nullptr, bool phase4 = false, void* out2 = nullptr, const void* mask2 = nullptr,
-             int csplit = 0, const unsigned char* mask_bits = nullptr, const rs_bn_fin* fin = nullptr) {
+             int csplit = 0, const unsigned char* mask_bits = nullptr) {
   if (!valid(d) || !src1 || !weight || !out) return RS_EINVAL;
-  if (fin && (!stats || !fin->workspace || !fin->counters || fin->M <= 0 || !fin->gamma)) return RS_EINVAL;
-  if (fin && fin->mode == 0 && (!fin->beta || !fin->mean || !fin->invstd || !fin->scale || !fin->shift ||
-                                (fin->running_mean == nullptr) != (fin->running_var == nullptr)))
-    return RS_EINVAL;
-  if (fin && fin->mode == 1 && (!fin->invstd_in || !fin->dgamma || !fin->dbeta || !fin->coef)) return RS_EINVAL;
-  if (fin && fin->mode != 0 && fin->mode != 1) return RS_EINVAL;
   if (mask_bits && (relu_mask || !bn_y || (d->Cout & 7))) return RS_EINVAL;  // (bits: data gradients into a BatchNorm only)
   if (out2 && (csplit <= 0 || csplit >= d->Cout || residual || stats)) return RS_EINVAL;
   if (phase4 && (!phase_ok(d) || stats)) return RS_EINVAL;
@@ -373,39 +365,6 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   a.Kw = a.nk * kc;
   a.relu = d->relu;
   a.tpx = a.tpi = 0;
-  a.fin = ConvBnFin{};
-  // the fused BatchNorm finalize, once the launch's partial rows and N tiles are known
-  auto set_fin = [&](long rows, int ntiles) {
-    if (!fin) return true;
-    int rps = (int)((rows + 63) / 64);
-    if (rps < 64) rps = 64;
-    const int nslices = (int)((rows + rps - 1) / rps);
-    if ((long)nslices * ntiles + ntiles > kBnFinCounterWords) return false;
-    a.fin.on = 1;
-    a.fin.mode = fin->mode;
-    a.fin.rows = (int)rows;
-    a.fin.rps = rps;
-    a.fin.nslices = nslices;
-    a.fin.M = fin->M;
-    a.fin.eps = fin->eps;
-    a.fin.momentum = fin->momentum;
-    a.fin.gamma = fin->gamma;
-    a.fin.beta = fin->beta;
-    a.fin.invstd_in = fin->invstd_in;
-    a.fin.mean = fin->mean;
-    a.fin.invstd = fin->invstd;
-    a.fin.scale = fin->scale;
-    a.fin.shift = fin->shift;
-    a.fin.running_mean = fin->running_mean;
-    a.fin.running_var = fin->running_var;
-    a.fin.num_batches_tracked = fin->num_batches_tracked;
-    a.fin.dgamma = fin->dgamma;
-    a.fin.dbeta = fin->dbeta;
-    a.fin.coef = fin->coef;
-    a.fin.slices = reinterpret_cast<double*>(fin->workspace);
-    a.fin.counters = fin->counters;
-    return true;
-  };
 
   // epilogue kind: forward with fused BatchNorm statistics takes no other epilogue input; the data gradient into a
   // BatchNorm takes residual / mask but no scale / shift / ReLU
@@ -429,7 +388,6 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
       a.tpi = a.tpx * (gh / (bm / 32));
       a.ntiles = rs_cdiv(d->Cout, bn);
       const int grid = d->N * a.tpi * a.ntiles * (phase4 ? 4 : 1);
-      if (!set_fin((long)d->N * a.tpi, a.ntiles)) return RS_EINVAL;
       hipStream_t hs = (hipStream_t)stream;
       if (bm == 512) bn |= 0x1000;
       if (hm == HALO_33) rs_conv_launch_bf16_halo33(bn, epi, grid, hs, a);
@@ -444,7 +402,6 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
   a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
-  if (!set_fin(rs_cdiv(M, kTileBM[tile]), a.ntiles)) return RS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   launch(kc == kc128 ? 128 : 64, phase4, epi, tile, grid, s, a);
   return RS_LAUNCH_RESULT();
@@ -663,41 +620,6 @@ extern "C" int rs_conv2d_fwd_bnstats_dt(const rs_conv_desc* d, int dtype, const 
   if (!stats_partial) return RS_EINVAL;
   if (dtype == RS_F32) return conv_fwd<float>(d, src1, src2, weight, nullptr, nullptr, nullptr, nullptr, out, stream, stats_partial);
   if (dtype == RS_BF16) return conv_fwd<bf16_t>(d, src1, src2, weight, nullptr, nullptr, nullptr, nullptr, out, stream, stats_partial);
-  return RS_EINVAL;
-}
-
-extern "C" long rs_bn_fin_workspace_bytes(long rows, int C) {
-  if (rows <= 0 || C <= 0) return RS_EINVAL;
-  return 64L * 2 * C * (long)sizeof(double);  // <= 64 slice rows
-}
-
-extern "C" long rs_bn_fin_counter_words(void) { return kBnFinCounterWords; }
-
-extern "C" int rs_conv2d_fwd_bnstats_fin_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2,
-                                            const void* weight, void* out, float* stats_partial, const rs_bn_fin* fin,
-                                            rs_stream_t stream) {
-  if (!stats_partial || !fin || fin->mode != 0) return RS_EINVAL;
-  if (dtype == RS_F32)
-    return conv_fwd<float>(d, src1, src2, weight, nullptr, nullptr, nullptr, nullptr, out, stream, stats_partial, nullptr, nullptr,
-                           nullptr, false, nullptr, nullptr, 0, nullptr, fin);
-  if (dtype == RS_BF16)
-    return conv_fwd<bf16_t>(d, src1, src2, weight, nullptr, nullptr, nullptr, nullptr, out, stream, stats_partial, nullptr, nullptr,
-                            nullptr, false, nullptr, nullptr, 0, nullptr, fin);
-  return RS_EINVAL;
-}
-
-extern "C" int rs_conv2d_dgrad_bnstats_fin_dt(const rs_conv_desc* d, int dtype, const void* dy, const void* weight,
-                                              const void* residual, const void* relu_mask, const unsigned char* relu_mask_bits,
-                                              const void* bn_y, const float* bn_mean, const float* bn_invstd, void* out,
-                                              float* stats_partial, const rs_bn_fin* fin, rs_stream_t stream) {
-  if (!stats_partial || !bn_y || !bn_mean || !bn_invstd || !fin || fin->mode != 1 || (d && d->C2 != 0) || (relu_mask && relu_mask_bits))
-    return RS_EINVAL;
-  if (dtype == RS_F32)
-    return conv_fwd<float>(d, dy, nullptr, weight, nullptr, nullptr, residual, relu_mask, out, stream, stats_partial, bn_y, bn_mean,
-                           bn_invstd, false, nullptr, nullptr, 0, relu_mask_bits, fin);
-  if (dtype == RS_BF16)
-    return conv_fwd<bf16_t>(d, dy, nullptr, weight, nullptr, nullptr, residual, relu_mask, out, stream, stats_partial, bn_y, bn_mean,
-                            bn_invstd, false, nullptr, nullptr, 0, relu_mask_bits, fin);
   return RS_EINVAL;
 }
 

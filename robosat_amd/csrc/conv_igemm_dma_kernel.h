@@ -25,25 +25,6 @@ enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T2
 // phase form = four 2x2 convolutions, one per parity plane of dz, accumulated into the same output patch (16 taps).
 enum { HALO_NONE = 0, HALO_33 = 1, HALO_PHASE = 2, HALO_DG4 = 3 };
 
-// BatchNorm finalize fused into the convolution that produced the partial rows (EPI_STATS / EPI_BWD launches): the block that
-// arrives LAST at its slice's counter sums the slice's rows, the block that completes the last slice of an N tile sums the
-// slice rows and writes the statistics (forward) / the backward coefficients of the tile's channels -- what
-// rs_bn_finalize_stats / the first half of rs_bn_bwd_from_partials_dt did in a launch of their own (include/robosat_hip.h:
-// rs_bn_fin).  Sums run in row order whoever computes them: deterministic.
-struct ConvBnFin {
-  int on;    // 0: the launch only writes the partial rows
-  int mode;  // 0 forward statistics, 1 backward coefficients
-  int rows, rps, nslices;  // partial rows (M tiles), rows per slice, slices
-  long M;    // elements per channel
-  float eps, momentum;
-  const float *gamma, *beta, *invstd_in;  // (mode 1: gamma and the layer's invstd)
-  float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
-  long long* num_batches_tracked;
-  float *dgamma, *dbeta, *coef;
-  double* slices;          // [nslices][2][Cout]
-  unsigned int* counters;  // [nslices * ntiles + ntiles], zero between launches (every launch leaves them at zero)
-};
-
 template <typename T>
 struct ConvArgsT {
   const T* src1;
@@ -74,7 +55,6 @@ struct ConvArgsT {
   int kh, kw, stride, pad, Ho, Wo, Cout;
   int M, cpt, nk, Kw, relu, ntiles, ntaps, phase4;
   int tpx, tpi;  // HALO forms: patches per row of the grid the rows enumerate / per image (nk = K-groups: planes x chunks)
-  ConvBnFin fin;
 };
 
 
@@ -221,92 +201,6 @@ constexpr int conv_waves_per_simd(int nw, int bm, int bn, int rowb, int es, int 
   // fp32 epilogue operands per row (not a benchmarked path: no spills matter more than its occupancy)
   const int cap = nw == 8 ? (bm * bn >= 256 * 256 ? 1 : 2) : ((es == 4 && epi == 2 && bm * bn >= 128 * 128) ? 2 : 4);
   return w < 1 ? 1 : (w > cap ? cap : w);
-}
-
-// The fused BatchNorm finalize (ConvBnFin): called by every block of an EPI_STATS / EPI_BWD launch after it has written its
-// partial row with write-through (sc1) stores.  Publishing across XCDs follows the platform guide's in-launch split-K
-// recipe: sc1 stores -> every wave waits for its stores -> block barrier -> ONE relaxed device-scope arrival per block;
-// the last arriver reads with sc1 loads (which bypass its XCD's non-coherent lines).  `flag` = two ints of the block's one
-// LDS array (a second __shared__ object would make hipcc drain the DMA pipeline of the main loop).
-template <int BN, int NT>
-__device__ __forceinline__ void conv_bn_finalize(const ConvBnFin& f, float* stats, int Cout, int ntiles, int mt, int nt, int n0,
-                                                 int tid, int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int slice = mt / f.rps;
-  const int row0 = slice * f.rps;
-  const int nrows = (f.rows - row0) < f.rps ? (f.rows - row0) : f.rps;
-  if (tid == 0) {
-    unsigned int* ctr = f.counters + slice * ntiles + nt;
-    const unsigned int before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = before == (unsigned int)(nrows - 1);
-    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all arrivals of this launch have happened)
-    flag[0] = last;
-  }
-  __syncthreads();
-  if (!flag[0]) return;
-  // ---- last block of the slice: column (k, c) of the slice's rows, in row order, fp64
-  for (int v = tid; v < 2 * BN; v += NT) {
-    const int k = v / BN, c = v - k * BN;
-    if (n0 + c >= Cout) continue;
-    const float* col = stats + ((long)row0 * 2 + k) * Cout + n0 + c;
-    double s = 0;
-    int r = 0;
-    for (; r + 8 <= nrows; r += 8) {  // 8 loads in flight per thread
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = __hip_atomic_load(col + (long)(r + u) * 2 * Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (double)x[u];
-    }
-    for (; r < nrows; ++r) s += (double)__hip_atomic_load(col + (long)r * 2 * Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(f.slices + ((long)slice * 2 + k) * Cout + n0 + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    unsigned int* ctr = f.counters + f.nslices * ntiles + nt;
-    const unsigned int before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = before == (unsigned int)(f.nslices - 1);
-    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[1] = last;
-  }
-  __syncthreads();
-  if (!flag[1]) return;
-  // ---- the block that completed the N tile's last slice: its channels' statistics / coefficients
-  if (f.mode == 0 && nt == 0 && tid == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
-  for (int c = tid; c < BN; c += NT) {
-    const int ch = n0 + c;
-    if (ch >= Cout) continue;
-    double s0 = 0, s1 = 0;
-    for (int sl = 0; sl < f.nslices; ++sl) {
-      s0 += __hip_atomic_load(f.slices + ((long)sl * 2) * Cout + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s1 += __hip_atomic_load(f.slices + ((long)sl * 2 + 1) * Cout + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (f.mode == 0) {  // (bn.hip: bn_stats_finalize_body)
-      const double mu = s0 / (double)f.M;
-      double var = s1 / (double)f.M - mu * mu;
-      if (var < 0) var = 0;
-      const float is = (float)(1.0 / sqrt(var + (double)f.eps));
-      f.mean[ch] = (float)mu;
-      f.invstd[ch] = is;
-      const float sc = f.gamma[ch] * is;
-      f.scale[ch] = sc;
-      f.shift[ch] = f.beta[ch] - (float)mu * sc;
-      if (f.running_mean) {
-        const double unbiased = f.M > 1 ? var * ((double)f.M / (double)(f.M - 1)) : var;
-        f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * (float)mu;
-        f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unbiased;
-      }
-    } else {  // (bn.hip: bn_bwd_finalize_body)
-      f.dbeta[ch] = (float)s0;
-      f.dgamma[ch] = (float)s1;
-      const double k1 = (double)f.gamma[ch] * (double)f.invstd_in[ch];
-      f.coef[ch] = (float)k1;
-      f.coef[Cout + ch] = (float)(k1 * s0 / (double)f.M);
-      f.coef[2 * Cout + ch] = (float)(k1 * (double)f.invstd_in[ch] * s1 / (double)f.M);
-    }
-  }
 }
 
 // EPI selects the epilogue a launch needs, so that each instantiation carries only its own registers and loads:
@@ -951,15 +845,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
       float a = 0.f;
 #pragma unroll 4
       for (int l = 0; l < RPI; ++l) a += r[l * BN + c];
-      if (n0 + c < p.Cout) {
-        float* dst = p.stats + ((long)mt * 2 + (tid < BN ? 0 : 1)) * p.Cout + n0 + c;
-        if (p.fin.on) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another XCD's block below
-        else *dst = a;
-      }
-    }
-    if (p.fin.on) {  // (launch-uniform)
-      __syncthreads();  // r0 / r1 have been read: the first two ints of the array become the finalize's flags
-      conv_bn_finalize<BN, NT>(p.fin, p.stats, p.Cout, p.ntiles, mt, nt, n0, tid, reinterpret_cast<int*>(smem));
+      if (n0 + c < p.Cout) p.stats[((long)mt * 2 + (tid < BN ? 0 : 1)) * p.Cout + n0 + c] = a;
     }
   }
 }

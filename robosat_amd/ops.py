@@ -191,129 +191,6 @@ def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0,
     return out, partial
 
 
-_FIN_COUNTERS = {}
-
-
-def _fin_counters(device):
-    """The zero-initialised counter words of the fused BatchNorm finalize, one buffer per (device, stream): every launch
-    leaves them at zero, launches on one stream run one after the other (``rs_bn_fin.counters``)."""
-
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    buf = _FIN_COUNTERS.get(key)
-    if buf is None:
-        buf = torch.zeros(int(_lib.lib().rs_bn_fin_counter_words()), device=device, dtype=torch.int32)
-        _FIN_COUNTERS[key] = buf
-    return buf
-
-
-def fused_finalize():
-    """Whether conv -> BatchNorm pairs finalize their statistics inside the convolution launch (default) or in a launch of
-    their own (ROBOSAT_BN_FUSED_FINALIZE=0: A/B measurements and the tests that compare the two)."""
-
-    import os
-
-    return os.environ.get("ROBOSAT_BN_FUSED_FINALIZE", "1") != "0"
-
-
-def conv2d_bn_train(src1, weight, gamma, beta, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None,
-                    src2=None, ups=0, stride=1, pad=0):
-    """``conv2d_bnstats`` + ``bn_finalize_stats`` in ONE launch (``rs_conv2d_fwd_bnstats_fin_dt``): the convolution's
-    last-arriving blocks reduce the partial rows and write the statistics.  Returns (y, (mean, invstd, scale, shift))."""
-
-    d = conv_desc(src1, weight, src2, ups, stride, pad, False, 0, None)
-    act = src1.dtype
-    lib = _lib.lib()
-    dev = src1.device
-    out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=dev, dtype=act)
-    rows = lib.rs_conv2d_bnstats_rows_dt(ctypes.byref(d), _dt(src1))
-    if rows <= 0:
-        raise ValueError("rs_conv2d_bnstats_rows: invalid arguments")
-    c = d.Cout
-    partial = torch.empty((rows, 2, c), device=dev, dtype=torch.float32)
-    mean, invstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
-    fin = _lib.BnFin()
-    fin.mode, fin.M, fin.eps, fin.momentum = 0, d.N * d.Ho * d.Wo, eps, momentum
-    fin.gamma, fin.beta = _dev(gamma, "gamma").value, _dev(beta, "beta").value
-    fin.mean, fin.invstd, fin.scale, fin.shift = (_dev(t, "stat").value for t in (mean, invstd, scale, shift))
-    fin.running_mean = None if running_mean is None else _dev(running_mean, "running_mean").value
-    fin.running_var = None if running_var is None else _dev(running_var, "running_var").value
-    fin.num_batches_tracked = None if num_batches_tracked is None else _dev(num_batches_tracked, "num_batches_tracked", torch.int64).value
-    fin.workspace = _workspace(lib.rs_bn_fin_workspace_bytes(rows, c), dev).value
-    fin.counters = _dev(_fin_counters(dev), "counters", torch.int32).value
-    if PROFILE is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    rc = lib.rs_conv2d_fwd_bnstats_fin_dt(ctypes.byref(d), _dt(src1), _dev(src1, "src1", act), _dev(src2, "src2", act),
-                                          _dev(weight, "weight", act), _dev(out, "out", act), _dev(partial, "partial"),
-                                          ctypes.byref(fin), _stream())
-    check(rc, "rs_conv2d_fwd_bnstats_fin_dt")
-    if PROFILE is not None:
-        ev1.record()
-        bf = act == BF16
-        _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                conv_bytes(d, 2 if bf else 4))
-    return out, (mean, invstd, scale, shift)
-
-
-def conv2d_dgrad_bn(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, gamma, ups=0, pad=0, residual=None, relu_mask=None,
-                    relu_mask_bits=None, dgamma=None, dbeta=None):
-    """``conv2d_dgrad_bnstats`` + the finalize half of ``bn_bwd_from_partials`` in ONE launch
-    (``rs_conv2d_dgrad_bnstats_fin_dt``).  Returns (g, coef [3, C], dgamma, dbeta); ``bn_bwd_apply(g, y, mean, coef)`` is the
-    streaming pass that is left."""
-
-    d = conv_desc(dy, wd, None, ups, 1, pad, False, 0, out_hw)
-    act = dy.dtype
-    lib = _lib.lib()
-    dev = dy.device
-    out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=dev, dtype=act)
-    assert bn_y.shape == out.shape
-    rows = lib.rs_conv2d_bnstats_rows_dt(ctypes.byref(d), _dt(dy))
-    if rows <= 0:
-        raise ValueError("rs_conv2d_bnstats_rows: invalid arguments")
-    c = d.Cout
-    partial = torch.empty((rows, 2, c), device=dev, dtype=torch.float32)
-    coef = torch.empty((3, c), device=dev, dtype=torch.float32)
-    if dgamma is None:
-        dgamma = torch.empty(c, device=dev, dtype=torch.float32)
-    if dbeta is None:
-        dbeta = torch.empty(c, device=dev, dtype=torch.float32)
-    if relu_mask_bits is not None:
-        assert relu_mask is None and relu_mask_bits.numel() * 8 == out.numel(), "one mask bit per output element"
-    fin = _lib.BnFin()
-    fin.mode, fin.M = 1, d.N * d.Ho * d.Wo
-    fin.gamma, fin.invstd_in = _dev(gamma, "gamma").value, _dev(bn_invstd, "bn_invstd").value
-    fin.dgamma, fin.dbeta, fin.coef = _dev(dgamma, "dgamma").value, _dev(dbeta, "dbeta").value, _dev(coef, "coef").value
-    fin.workspace = _workspace(lib.rs_bn_fin_workspace_bytes(rows, c), dev).value
-    fin.counters = _dev(_fin_counters(dev), "counters", torch.int32).value
-    if PROFILE is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    rc = lib.rs_conv2d_dgrad_bnstats_fin_dt(
-        ctypes.byref(d), _dt(dy), _dev(dy, "dy", act), _dev(wd, "weight", act), _dev(residual, "residual", act),
-        _dev(relu_mask, "relu_mask", act), _dev(relu_mask_bits, "relu_mask_bits", torch.uint8), _dev(bn_y, "bn_y", act),
-        _dev(bn_mean, "bn_mean"), _dev(bn_invstd, "bn_invstd"), _dev(out, "out", act), _dev(partial, "partial"), ctypes.byref(fin),
-        _stream())
-    check(rc, "rs_conv2d_dgrad_bnstats_fin_dt")
-    if PROFILE is not None:
-        ev1.record()
-        bf = act == BF16
-        _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
-                conv_bytes(d, 2 if bf else 4, 1 + (residual is not None) + (relu_mask is not None))
-                + (out.numel() // 8 if relu_mask_bits is not None else 0))
-    return out, coef, dgamma, dbeta
-
-
-def bn_bwd_apply(g, y, mean, coef):
-    """dy = coef[0] * g - coef[1] - coef[2] * (y - mean): the streaming pass of BatchNorm's backward (``rs_bn_bwd_apply_dt``)."""
-
-    c = y.shape[-1]
-    dy = torch.empty_like(y)
-    t = y.dtype
-    check(_lib.lib().rs_bn_bwd_apply_dt(_dev(g, "g", t), _dev(y, "y", t), _dev(mean, "mean"), _dev(coef, "coef"), _dev(dy, "dy", t),
-                                        _dt(y), y.numel() // c, c, _stream()), "rs_bn_bwd_apply_dt")
-    return dy
-
-
 def bn_bwd_from_partials(g, y, mean, invstd, gamma, partial, dgamma=None, dbeta=None):
     """BatchNorm backward from ``conv2d_dgrad_bnstats``'s partial sums: returns (dy, dgamma, dbeta); ``g`` is already
     masked by the ReLU, so it is also the gradient of a residual branch."""

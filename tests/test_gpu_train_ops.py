@@ -371,66 +371,3 @@ def test_relu_mask_as_bits(case, dtype):
     assert float((g1 == 0).float().mean()) > 0.2  # the mask did something
     with pytest.raises(Exception):
         ops.bn_apply(y[..., :24].contiguous(), scale[:24], shift[:24], relu=True, want_bits=True)  # 24 does not divide 2048
-
-
-# ---- BatchNorm finalize fused into the producing convolution (rs_conv2d_fwd_bnstats_fin_dt / rs_conv2d_dgrad_bnstats_fin_dt) ----
-@pytest.mark.parametrize("dtype,n,c,cout,h,w,k", [
-    (torch.float32, 2, 64, 256, 40, 36, 1),     # 23 partial rows (one slice), two N tiles, M tail
-    (torch.bfloat16, 8, 64, 64, 96, 96, 1),     # 576 rows of 128 pixels: 9 slices, the 64-wide tile
-    (torch.bfloat16, 4, 128, 320, 48, 64, 3),   # ragged last N tile, 3x3
-    (torch.bfloat16, 40, 128, 128, 32, 32, 3),  # the halo form (160 patches, 3 slices) on layer2's class
-    (torch.float32, 3, 32, 96, 17, 19, 3),      # odd sizes, Cout = 96 on 32-wide tiles
-])
-def test_fused_bn_finalize_equals_the_separate_launch(dtype, n, c, cout, h, w, k):
-    """conv + train-mode BatchNorm statistics finalized by the convolution's own last-arriving blocks == the two-launch
-    form (partial rows, then rs_bn_finalize_stats), to fp64-summation-order noise; running statistics and the batch counter
-    move the same way; the launch is deterministic (50 launches, every word equal) and leaves its counters at zero.  Same
-    for the backward pair (data gradient into a BatchNorm + coefficients)."""
-    from robosat_amd import ops
-
-    g = torch.Generator().manual_seed(5)
-    bf = dtype == torch.bfloat16
-    x = torch.randn(n, h, w, c, generator=g).to(DEV).to(dtype)
-    wt = (torch.randn(cout, k, k, c, generator=g) * (2.0 / (c * k * k)) ** 0.5).to(DEV).to(dtype)
-    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
-    pad = k // 2
-    rm0, rv0 = torch.randn(cout, generator=g).to(DEV), (torch.rand(cout, generator=g) + 0.5).to(DEV)
-
-    def run(fused):
-        rm, rv, nbt = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
-        if fused:
-            y, st = ops.conv2d_bn_train(x, wt, gamma, beta, 1e-5, 0.1, rm, rv, nbt, pad=pad)
-        else:
-            y, partial = ops.conv2d_bnstats(x, wt, pad=pad)
-            st = ops.bn_finalize_stats(partial, y.numel() // cout, gamma, beta, 1e-5, 0.1, rm, rv, nbt)
-        return y, st, rm, rv, nbt
-
-    y0, st0, rm_a, rv_a, nbt_a = run(False)
-    y1, st1, rm_b, rv_b, nbt_b = run(True)
-    assert torch.equal(y0, y1)
-    for a, b, what in list(zip(st0, st1, ("mean", "invstd", "scale", "shift"))) + [(rm_a, rm_b, "running_mean"), (rv_a, rv_b, "running_var")]:
-        err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
-        assert err <= 2e-6, (what, err)
-    assert int(nbt_a) == int(nbt_b) == 1
-    first = [t.clone() for t in st1]
-    for _ in range(50):  # deterministic, and no stale word whichever block finalizes
-        _, st, _, _, _ = run(True)
-        for a, b in zip(first, st):
-            assert torch.equal(a, b)
-    assert int(ops._fin_counters(x.device).abs().sum()) == 0  # every launch leaves its counters at zero
-
-    # backward pair: dy -> conv (same weights as a stand-in data-gradient filter) -> g masked, sums of g and g * xhat, coefficients
-    bn_y = torch.randn(n, h, w, cout, generator=g).to(DEV).to(dtype)
-    mask = torch.randn(n, h, w, cout, generator=g).to(DEV).to(dtype)
-    mean, invstd = st0[0], st0[1]
-    g0, part = ops.conv2d_dgrad_bnstats(x, wt, (h, w), bn_y, mean, invstd, pad=pad, relu_mask=mask)
-    dy0, dg0, db0 = ops.bn_bwd_from_partials(g0, bn_y, mean, invstd, gamma, part)
-    g1, coef, dg1, db1 = ops.conv2d_dgrad_bn(x, wt, (h, w), bn_y, mean, invstd, gamma, pad=pad, relu_mask=mask)
-    dy1 = ops.bn_bwd_apply(g1, bn_y, mean, coef)
-    assert torch.equal(g0, g1)
-    for a, b, what in ((dg0, dg1, "dgamma"), (db0, db1, "dbeta")):
-        err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
-        assert err <= 2e-6, (what, err)
-    scale = float(dy0.float().abs().max())
-    assert float((dy0.float() - dy1.float()).abs().max()) <= (1e-2 if bf else 1e-5) * scale
-    assert int(ops._fin_counters(x.device).abs().sum()) == 0

@@ -24,6 +24,11 @@
 //            ds_read_b32: 4x the LDS instructions, 89 TF on dec3 against 134 TF for the forward kernel.)
 //   split-P: partial tiles go to a workspace [split][Cout][K] and are summed by a second (streaming) kernel:
 //            deterministic, no atomics.
+//   PHASE  : DecoderBlock (3x3 / pad 1 behind the nearest-x2 upsample, robosat/unet.py:63-73).  Instead of nine taps over
+//            the UPSAMPLED pixels the block reduces one of 16 (output parity, source offset) combinations over the SOURCE
+//            pixels, G[(py,px),(r,s)][co][ci] = sum_{n,a,b} dz[n][2a+py][2b+px][co] * src[n][a-(1-py)+r][b-(1-px)+s][ci]
+//            -- 16/36 of the multiply-adds -- and combine_phase_wgrad_f32_kernel adds the four G's that make up each
+//            filter tap (the fp32 twin of conv_wgrad_bf16.hip's phase form; round 4).
 #include "common.h"
 
 namespace {
@@ -36,7 +41,7 @@ struct WgradArgs {
   int N, Hs, Ws, C1, C2, Hv, Wv, ups;
   int kw, stride, pad, Ho, Wo, Cout;
   int M, K, tiles_co, tiles_ci, tiles_k, chunks_per_split;
-  rs_fastdiv div_howo, div_wo;
+  rs_fastdiv div_howo, div_wo;  // PHASE: of the source grid (Hs*Ws, Ws): the rows m enumerate source pixels
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -50,8 +55,11 @@ __device__ __forceinline__ f32x4 wg_buffer_load4(__amdgpu_buffer_rsrc_t r, int b
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
-template <int BMo, int BNo, int WGM, int WGN, int STEM>
+// FORM: 0 plain, 1 the packed 7x7 stem, 2 phase form of DecoderBlock
+template <int BMo, int BNo, int WGM, int WGN, int FORM>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs p) {
+  constexpr int STEM = FORM == 1 ? 1 : 0;
+  constexpr bool PHASE = FORM == 2;
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -74,8 +82,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   const int tk = bid % p.tiles_k;
   const int split = bid / p.tiles_k;
   const int tap = tk / p.tiles_ci, tci = tk - tap * p.tiles_ci;
-  const int ky = STEM ? tap : tap / p.kw;
-  const int kx = STEM ? 0 : tap - ky * p.kw;
+  const int ky = STEM ? tap : (PHASE ? ((tap >> 1) & 1) : tap / p.kw);  // PHASE: tap = 4*(2*py+px) + 2*r + s
+  const int kx = STEM ? 0 : (PHASE ? (tap & 1) : tap - ky * p.kw);
+  const int py = (tap >> 3) & 1, px = (tap >> 2) & 1;
   const int co0 = tco * BMo;
   const int ci0 = tci * BNo;  // STEM: 0
 
@@ -92,13 +101,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
   const int total_chunks = (p.M + 31) >> 5;
   int chunk1 = chunk0 + p.chunks_per_split;
   if (chunk1 > total_chunks) chunk1 = total_chunks;
-  const int HoWo = p.Ho * p.Wo;
+  const int HoWo = PHASE ? p.Hs * p.Ws : p.Ho * p.Wo;  // pixels per image of the grid the rows enumerate
+  const int Wrow = PHASE ? p.Ws : p.Wo;
 
   // 32-bit byte offsets relative to this split's first pixel (dy) / first image (input); validated on the host
   const int m_first = chunk0 << 5;
   const int n_first = (int)rs_div((unsigned)m_first, p.div_howo);
   const long img = (long)p.Hs * p.Ws * Cs;
-  const __amdgpu_buffer_rsrc_t rsrc_dy = wg_make_rsrc(p.dy + (long)m_first * p.Cout, ((long)p.M - m_first) * p.Cout * 4);
+  const long dyimg = (long)p.Ho * p.Wo * p.Cout;
+  const __amdgpu_buffer_rsrc_t rsrc_dy = PHASE ? wg_make_rsrc(p.dy + n_first * dyimg, (long)(p.N - n_first) * dyimg * 4)
+                                               : wg_make_rsrc(p.dy + (long)m_first * p.Cout, ((long)p.M - m_first) * p.Cout * 4);
   const __amdgpu_buffer_rsrc_t rsrc_x = wg_make_rsrc(src + n_first * img, (long)(p.N - n_first) * img * 4);
   const int ush = p.ups ? 1 : 0;
   const int upar = p.ups == 2 ? 1 : 0;
@@ -112,7 +124,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
 
   auto load_a = [&](int e) __attribute__((always_inline)) {
     const int m = (lchunk << 5) + a_pg * 4 + e;
-    const int off = (doA && m < p.M) ? ((m - m_first) * p.Cout + co0 + a_c4 * 4) * 4 : -1;
+    int off = (doA && m < p.M) ? ((m - m_first) * p.Cout + co0 + a_c4 * 4) * 4 : -1;
+    if (PHASE) {  // row m = source pixel (n, a, b): dz pixel (2a + py, 2b + px) of the same image
+      const int n = (int)rs_div((unsigned)m, p.div_howo);
+      const int rem = m - n * HoWo;
+      const int a = (int)rs_div((unsigned)rem, p.div_wo);
+      const int b = rem - a * Wrow;
+      const int pix = ((n - n_first) * p.Ho + 2 * a + py) * p.Wo + 2 * b + px;
+      off = (doA && m < p.M) ? (pix * p.Cout + co0 + a_c4 * 4) * 4 : -1;
+    }
     ra[e] = wg_buffer_load4(rsrc_dy, off);
   };
   auto load_b = [&](int e) __attribute__((always_inline)) {
@@ -120,12 +140,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_f32(const WgradArgs
     const int n = (int)rs_div((unsigned)m, p.div_howo);
     const int rem = m - n * HoWo;
     const int oy = (int)rs_div((unsigned)rem, p.div_wo);
-    const int ox = rem - oy * p.Wo;
-    const int iy = oy * p.stride - p.pad + ky;
-    const int ix = ox * p.stride - p.pad + (STEM ? b_c4 : kx);
-    bool ok = doB && (m < p.M) && ((unsigned)iy < (unsigned)p.Hv) && ((unsigned)ix < (unsigned)p.Wv);
-    ok = ok && (((iy | ix) & upar) == 0);
-    const int pix = ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
+    const int ox = rem - oy * Wrow;
+    const int iy = PHASE ? oy - (1 - py) + ky : oy * p.stride - p.pad + ky;
+    const int ix = PHASE ? ox - (1 - px) + kx : ox * p.stride - p.pad + (STEM ? b_c4 : kx);
+    bool ok = doB && (m < p.M) && ((unsigned)iy < (unsigned)(PHASE ? p.Hs : p.Hv)) && ((unsigned)ix < (unsigned)(PHASE ? p.Ws : p.Wv));
+    ok = ok && (PHASE || (((iy | ix) & upar) == 0));
+    const int pix = PHASE ? ((n - n_first) * p.Hs + iy) * p.Ws + ix : ((n - n_first) * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
     const int off = ok ? (pix * Cs + (STEM ? 0 : cs + b_c4 * 4)) * 4 : -1;
     rb[e] = wg_buffer_load4(rsrc_x, off);
   };
@@ -269,10 +289,35 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
   }
 }
 
+// G [Cout][16][Cin] (phase form, tap index 4*(2*py+px) + 2*r + s) -> dW [Cout][3][3][Cin]: the (py, r) pairs whose tap
+// set contains ky are ky 0 -> (0,0),(1,0); 1 -> (0,1),(1,0); 2 -> (0,1),(1,1) (same in x)
+__global__ void combine_phase_wgrad_f32_kernel(const float* __restrict__ g, float* __restrict__ dw, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  long t = i / Cin;
+  const int kx = (int)(t % 3), ky = (int)((t / 3) % 3);
+  const long co = t / 9;
+  const int ya[2][2] = {{0, ky == 0 ? 0 : 1}, {1, ky == 2 ? 1 : 0}};
+  const int xa[2][2] = {{0, kx == 0 ? 0 : 1}, {1, kx == 2 ? 1 : 0}};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc += g[(co * 16 + 4 * (2 * ya[a][0] + xa[b][0]) + 2 * ya[a][1] + xa[b][1]) * Cin + ci];
+  dw[i] = acc;
+}
+
 struct Plan {
   int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split;
   long K;
+  bool phase;
 };
+
+bool phase_ok(const rs_conv_desc* d) {
+  return !d->stem && d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs &&
+         d->Wo == 2 * d->Ws && getenv("RS_WGRAD_F32_PHASE") == nullptr;  // (RS_WGRAD_F32_PHASE=0: the direct form, for A/B runs)
+}
 
 enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32, VSTEM };
 
@@ -294,7 +339,8 @@ int largest_tile(int c) { return (c % 128 == 0) ? 128 : (c % 64 == 0) ? 64 : 32;
 
 Plan plan(const rs_conv_desc* d) {
   Plan pl;
-  const long M = (long)d->N * d->Ho * d->Wo;
+  pl.phase = phase_ok(d);
+  const long M = pl.phase ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo;
   if (d->stem) {
     pl.bmo = 64;
     pl.bno = 32;
@@ -314,7 +360,7 @@ Plan plan(const rs_conv_desc* d) {
     pl.variant = pl.bmo == 128 ? (pl.bno == 128 ? V128x128 : V128x64)
                  : pl.bmo == 64 ? (pl.bno == 128 ? V64x128 : V64x64)
                                 : (pl.bno == 128 ? V32x128 : V32x32);
-    pl.taps = d->kh * d->kw;
+    pl.taps = pl.phase ? 16 : d->kh * d->kw;
     pl.tiles_ci = (d->C1 + d->C2) / pl.bno;
     pl.K = (long)pl.taps * (d->C1 + d->C2);
   }
@@ -330,11 +376,11 @@ Plan plan(const rs_conv_desc* d) {
   // touches (+1 for the prefetch past its end); shrink the splits until both fit
   const long cmax = d->stem ? 4 : (d->C1 > d->C2 ? d->C1 : d->C2);
   const long img_bytes = (long)d->Hs * d->Ws * cmax * 4;
-  const long howo = (long)d->Ho * d->Wo;
+  const long howo = pl.phase ? (long)d->Hs * d->Ws : (long)d->Ho * d->Wo;
   for (;;) {
     pl.chunks_per_split = (int)((chunks + s - 1) / s);
     const long px = ((long)pl.chunks_per_split + 1) * 32;
-    const long span_dy = px * d->Cout * 4;
+    const long span_dy = pl.phase ? (px / howo + 2) * (long)d->Ho * d->Wo * d->Cout * 4 : px * d->Cout * 4;
     const long span_x = (px / howo + 2) * img_bytes;
     if ((span_dy < (1L << 31) && span_x < (1L << 31)) || pl.chunks_per_split == 1) break;
     s *= 2;
@@ -349,7 +395,7 @@ extern "C" long rs_conv2d_wgrad_workspace_bytes(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
   const Plan pl = plan(d);
   const long n = (long)d->Cout * pl.K;
-  return (pl.splits * n + rs_reduce_scratch_floats(n, pl.splits)) * (long)sizeof(float);
+  return (pl.splits * n + rs_reduce_scratch_floats(n, pl.splits) + (pl.phase ? n : 0)) * (long)sizeof(float);  // (+ G for the combine)
 }
 
 extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const float* src1, const float* src2, float* dw,
@@ -368,8 +414,8 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
   a.C1 = d->C1;
   a.C2 = d->C2;
   a.ups = d->ups;
-  a.div_howo = rs_make_fastdiv((unsigned)(d->Ho * d->Wo));
-  a.div_wo = rs_make_fastdiv((unsigned)d->Wo);
+  a.div_howo = rs_make_fastdiv((unsigned)(pl.phase ? d->Hs * d->Ws : d->Ho * d->Wo));
+  a.div_wo = rs_make_fastdiv((unsigned)(pl.phase ? d->Ws : d->Wo));
   a.Hv = d->ups == 0 ? d->Hs : (d->ups == 1 ? 2 * d->Hs : 2 * d->Hs - 1);
   a.Wv = d->ups == 0 ? d->Ws : (d->ups == 1 ? 2 * d->Ws : 2 * d->Ws - 1);
   a.kw = d->kw;
@@ -378,7 +424,7 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
   a.Ho = d->Ho;
   a.Wo = d->Wo;
   a.Cout = d->Cout;
-  a.M = (int)((long)d->N * d->Ho * d->Wo);
+  a.M = (int)(pl.phase ? (long)d->N * d->Hs * d->Ws : (long)d->N * d->Ho * d->Wo);
   a.K = (int)pl.K;
   a.tiles_co = pl.tiles_co;
   a.tiles_ci = pl.tiles_ci;
@@ -386,6 +432,27 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
   a.chunks_per_split = pl.chunks_per_split;
   const int grid = pl.tiles_co * pl.tiles_k * pl.splits;
   hipStream_t s = (hipStream_t)stream;
+  if (pl.phase) {
+    switch (pl.variant) {
+      case V128x128: conv_wgrad_f32<128, 128, 2, 2, 2><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_f32<128, 64, 2, 2, 2><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_f32<64, 128, 2, 2, 2><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_f32<64, 64, 2, 2, 2><<<grid, 256, 0, s>>>(a); break;
+      case V32x128: conv_wgrad_f32<32, 128, 1, 4, 2><<<grid, 256, 0, s>>>(a); break;
+      case V32x32: conv_wgrad_f32<32, 32, 1, 1, 2><<<grid, 64, 0, s>>>(a); break;
+      default: return RS_EINVAL;
+    }
+    const int rc = RS_LAUNCH_RESULT();
+    if (rc) return rc;
+    const long n = (long)d->Cout * pl.K;  // Cout x 16 x Cin
+    float* scratch = a.out + (long)pl.splits * n;
+    float* gbuf = scratch + rs_reduce_scratch_floats(n, pl.splits);
+    const int rc2 = rs_reduce_splits(a.out, gbuf, n, pl.splits, scratch, stream);
+    if (rc2) return rc2;
+    const long total = (long)d->Cout * 9 * (d->C1 + d->C2);
+    combine_phase_wgrad_f32_kernel<<<rs_cdiv(total, 256), 256, 0, s>>>(gbuf, dw, d->C1 + d->C2, total);
+    return RS_LAUNCH_RESULT();
+  }
   switch (pl.variant) {
     case V128x128: conv_wgrad_f32<128, 128, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
     case V128x64: conv_wgrad_f32<128, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;

@@ -804,6 +804,10 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         es = 2 if bf else 4
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
         form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d)) if bf else 0
+        if not bf and not stem and ups == 1 and (kh, kw, stride, pad) == (3, 3, 1, 1):
+            import os
+
+            form = 2 if os.environ.get("RS_WGRAD_F32_PHASE") is None else 0  # conv_wgrad.hip: the fp32 phase form (16 / 36 of the MACs)
         name = wgrad_kernel_name(d, form) if bf else "conv_wgrad_f32"
         _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes,
                 conv_flops(d) * (4.0 / 9.0 if form == 2 else 1.0))

@@ -91,6 +91,34 @@ def test_decoder_block_backward(c1, c2, cout):
     close(nchw(d1b), a.grad + 1.0, what="accumulate")
 
 
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [(3, 64, 32, 64, 9, 13), (1, 128, 0, 128, 33, 20), (5, 32, 0, 32, 16, 16)])
+def test_decoder_wgrad_fp32_phase_form_vs_autograd_and_direct_form(n, c1, c2, cout, h, w):
+    """The fp32 weight gradient of DecoderBlock in phase form (16 parity / offset reductions over the SOURCE pixels + a
+    combine: 16/36 of the multiply-adds, conv_wgrad.hip) against autograd on the reference formulation (unet.py:63-73) and
+    against the direct form (nine taps over the upsampled pixels) on the same launch: odd sizes, splits that straddle images,
+    two sources."""
+    from robosat_amd import ops
+
+    a = rnd(n, c1, h, w, seed=41).requires_grad_(True)
+    b = rnd(n, c2, h, w, seed=42).requires_grad_(True) if c2 else None
+    wt = (rnd(cout, c1 + c2, 3, 3, seed=43) * 0.05).requires_grad_(True)
+    cat = torch.cat([a, b], 1) if c2 else a
+    y = F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1)
+    gy = rnd(*y.shape, seed=44)
+    y.backward(gy)
+    args = (nhwc(gy), nhwc(a.detach()), 3, 3)
+    kw = dict(src2=nhwc(b.detach()) if c2 else None, ups=1, pad=1)
+    dw = ops.conv2d_wgrad(*args, **kw)
+    close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="phase-form wgrad")
+    os.environ["RS_WGRAD_F32_PHASE"] = "0"
+    try:
+        direct = ops.conv2d_wgrad(*args, **kw)
+    finally:
+        del os.environ["RS_WGRAD_F32_PHASE"]
+    close(direct.permute(0, 3, 1, 2).cpu(), wt.grad, what="direct-form wgrad")
+    assert float((dw - direct).abs().max()) <= 1e-4 * float(direct.abs().max())
+
+
 def test_stem_wgrad():
     from robosat_amd import ops
 

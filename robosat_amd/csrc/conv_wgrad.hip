@@ -368,7 +368,7 @@ Plan plan(const rs_conv_desc* d) {
   pl.tiles_k = pl.taps * pl.tiles_ci;
   const long tiles = (long)pl.tiles_co * pl.tiles_k;
   const long chunks = (M + 31) / 32;
-  long s = (1024 + tiles - 1) / tiles;       // aim at >= 1024 blocks ...
+  long s = (1024 + tiles - 1) / tiles;       // aim at >= 1024 blocks (512 measured 3 % slower on the fp32 step, 2048 the same) ...
   const long smax = (chunks + 7) / 8;        // ... of at least 8 chunks (256 pixels) each
   if (s > smax) s = smax;
   if (s < 1) s = 1;

@@ -482,7 +482,7 @@ def test_halo_forms_are_what_the_bf16_train_step_runs_unforced():
     n, c, h, w = 32, 128, 64, 64
     xd = torch.randn(n, h, w, c, device=DEV, generator=g).to(BF)
     wd = (torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.03).to(BF)
-    assert ops.conv_tile_name(ops.conv_desc(xd, wd, pad=1), True) == "conv_halo_bf16<3x3,256x128>"
+    assert ops.conv_tile_name(ops.conv_desc(xd, wd, pad=1), True) == "conv_halo_bf16<3x3,512x128>"  # (256 patches of 16 x 32: one per CU)
     got = ops.conv2d(xd, wd, pad=1)
     for img in (0, 17, n - 1):
         x = xd[img:img + 1].float().permute(0, 3, 1, 2).cpu()
@@ -492,7 +492,7 @@ def test_halo_forms_are_what_the_bf16_train_step_runs_unforced():
     b = torch.randn(n, hs, ws, c2, device=DEV, generator=g).to(BF)
     wt = torch.randn(cout, c1 + c2, 3, 3, generator=torch.Generator().manual_seed(23)) * 0.02
     d = _lib.ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 1, 0)
-    assert ops.conv_tile_name(d, True, phase=True) == "conv_halo_bf16<phase,256x128>"
+    assert ops.conv_tile_name(d, True, phase=True) == "conv_halo_bf16<phase,256x128>"  # (4 images: 128 patches of 16 x 32 < 256 -> the 8 x 32 patch)
     got = ops.conv2d_phase(a, ops.pack_phase_weight(krsc(wt, torch.float32), BF), src2=b, relu=True)
     src = torch.cat([a[:1], b[:1]], 3).float().permute(0, 3, 1, 2).cpu()
     want = F.relu(F.conv2d(F.interpolate(src, scale_factor=2, mode="nearest"), wt, padding=1))

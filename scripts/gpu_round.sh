@@ -12,6 +12,12 @@ TAG=$1; shift
 export TMPDIR=/tmp
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 B="python $REPO/bench.py --no-cpu-baseline --no-extra-legs --no-miou"
+# A box whose GPU faults on the first transfer (seen once in round 4: "Memory access fault by GPU node" in every process,
+# rocprofv3 then sat in each of its 10-minute timeouts: 55 GPU-minutes gone) must cost seconds, not the visit: one tiny
+# device round trip first, and every later command under a timeout sized to its normal duration.
+if ! timeout 90 python -c "import torch; x = torch.arange(1 << 20, device='cuda:0', dtype=torch.float32); assert float((x * 2).sum().cpu()) == float((1 << 20) * ((1 << 20) - 1))" > $OUT/sanity.log 2>&1; then
+  echo "=== sanity check of the GPU FAILED -- leaving the box"; tail -3 $OUT/sanity.log; exit 3
+fi
 for STAGE in "$@"; do
   echo "=== stage $STAGE ($(date +%T))"
   case $STAGE in
@@ -22,9 +28,9 @@ for STAGE in "$@"; do
   smoke)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   bench)
-    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers-json $OUT/layers_predict.json --full-json $OUT/bench_default_full.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
+    timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --layers-json $OUT/layers_predict.json --full-json $OUT/bench_default_full.json > $OUT/bench_default.log 2>&1; echo "bench exit $?"
     tail -1 $OUT/bench_default.log > $OUT/bench_default.json; python scripts/bench_brief.py $OUT/bench_default.json
-    timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --layers-json $OUT/layers_train.json --full-json $OUT/bench_train_full.json > $OUT/bench_train.log 2>&1; echo "train bench exit $?"
+    timeout 240 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --layers-json $OUT/layers_train.json --full-json $OUT/bench_train_full.json > $OUT/bench_train.log 2>&1; echo "train bench exit $?"
     tail -1 $OUT/bench_train.log > $OUT/bench_train_bf16_bs32.json; cut -c1-500 $OUT/bench_train_bf16_bs32.json ;;
   smi)
     # does a concurrent SMU poller (what the driver runs beside its bench: one sample every 5 s) move the train leg?  Same
@@ -35,9 +41,9 @@ for STAGE in "$@"; do
     tail -1 $OUT/bench_with_smi.log > $OUT/bench_with_smi.json; python scripts/bench_brief.py $OUT/bench_with_smi.json ;;
   trace)
     cd /tmp
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_predict -o p -- $B --no-train-leg --steps 5 --warmup 2 > $OUT/trace_predict.log 2>&1; echo "exit $?"
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o p -- $B --phase train --dtype bf16 --batch 32 --steps 5 --warmup 2 > $OUT/trace_train.log 2>&1; echo "exit $?"
-    ROBOSAT_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train_serial -o p -- $B --phase train --dtype bf16 --batch 32 --steps 5 --warmup 2 > $OUT/trace_train_serial.log 2>&1; echo "exit $?"
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_predict -o p -- $B --no-train-leg --steps 5 --warmup 2 > $OUT/trace_predict.log 2>&1; echo "exit $?"
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o p -- $B --phase train --dtype bf16 --batch 32 --steps 5 --warmup 2 > $OUT/trace_train.log 2>&1; echo "exit $?"
+    ROBOSAT_WGRAD_STREAM=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train_serial -o p -- $B --phase train --dtype bf16 --batch 32 --steps 5 --warmup 2 > $OUT/trace_train_serial.log 2>&1; echo "exit $?"
     cd $REPO
     for T in predict train train_serial; do
       F=$(find $OUT/trace_$T -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/${T}_kernel_stats.csv
@@ -48,11 +54,11 @@ for STAGE in "$@"; do
     C1="SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
     P="$B --no-train-leg --no-parity --steps 1 --warmup 1"
     T="$B --phase train --dtype bf16 --batch 32 --no-parity --steps 1 --warmup 1"
-    timeout 600 rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/pmc_mfma/predict -o p -- $P > $OUT/pmc_mfma_predict.log 2>&1; echo "exit $?"
-    ROBOSAT_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/pmc_mfma/trainbf16 -o p -- $T > $OUT/pmc_mfma_train.log 2>&1; echo "exit $?"
+    timeout 200 rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/pmc_mfma/predict -o p -- $P > $OUT/pmc_mfma_predict.log 2>&1; echo "exit $?"
+    ROBOSAT_WGRAD_STREAM=0 timeout 200 rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/pmc_mfma/trainbf16 -o p -- $T > $OUT/pmc_mfma_train.log 2>&1; echo "exit $?"
     for CTR in FETCH_SIZE WRITE_SIZE; do
-      timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc/predict_pmc_$CTR -o p -- $P > $OUT/pmc_${CTR}_predict.log 2>&1; echo "exit $?"
-      ROBOSAT_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc/trainbf16_pmc_$CTR -o p -- $T > $OUT/pmc_${CTR}_train.log 2>&1; echo "exit $?"
+      timeout 200 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc/predict_pmc_$CTR -o p -- $P > $OUT/pmc_${CTR}_predict.log 2>&1; echo "exit $?"
+      ROBOSAT_WGRAD_STREAM=0 timeout 200 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc/trainbf16_pmc_$CTR -o p -- $T > $OUT/pmc_${CTR}_train.log 2>&1; echo "exit $?"
     done
     cd $REPO
     find $OUT/pmc $OUT/pmc_mfma -name "*kernel_trace.csv" -size +8M -delete
@@ -68,7 +74,7 @@ for STAGE in "$@"; do
   rccl1)
     # the RCCL branch of the reducer inside the timed train steps, one GPU (bench.py --force-reducer), fp32 and bf16 wire
     for W in fp32 bf16; do
-      timeout 600 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --force-reducer --grad-dtype $W --no-parity --full-json $OUT/bench_rccl1_$W.json > $OUT/bench_rccl1_$W.log 2>&1; echo "exit $?"
+      timeout 200 $B --phase train --dtype bf16 --batch 32 --steps 10 --warmup 3 --force-reducer --grad-dtype $W --no-parity --full-json $OUT/bench_rccl1_$W.json > $OUT/bench_rccl1_$W.log 2>&1; echo "exit $?"
       tail -1 $OUT/bench_rccl1_$W.log | cut -c1-600
     done ;;
   sweep)

@@ -6,6 +6,11 @@ SRC=gpurun_out/$TAG; DST=profiles/$ROUND; mkdir -p $DST
 cp $SRC/bench_default.json $DST/bench_default.json
 cp $SRC/bench_default.json $DST/bench_driver_command.json   # (the `bench` stage runs the driver's command: --gpus 1 --steps 20 --warmup 5)
 cp $SRC/bench_train_bf16_bs32.json $DST/ 2>/dev/null
+# the full records behind the compact stdout lines (per-kernel tables, every step time, counter provenance)
+cp $SRC/bench_default_full.json $DST/bench_default_full.json 2>/dev/null
+cp $SRC/bench_train_full.json $DST/bench_train_bf16_bs32_full.json 2>/dev/null
+# the RCCL branch of the gradient reducer inside the timed steps, one GPU (bench.py --force-reducer)
+for W in fp32 bf16; do [ -f $SRC/bench_rccl1_$W.log ] && tail -1 $SRC/bench_rccl1_$W.log > $DST/bench_rccl1_world1_$W.json; done
 cp $SRC/layers_predict.json $SRC/layers_train.json $DST/ 2>/dev/null
 cp $SRC/predict_kernel_stats.csv $DST/predict_fp32_bs16_512_kernel_stats.csv 2>/dev/null
 cp $SRC/train_kernel_stats.csv $DST/train_bf16_bs32_512_kernel_stats.csv 2>/dev/null

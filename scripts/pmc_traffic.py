@@ -23,10 +23,10 @@ HALO_FORMS = {"1": "3x3", "2": "phase", "3": "dgrad4x4"}
 def bench_name(k):
     k = k.replace("(anonymous namespace)::", "")
     # halo-once forms: a ninth template argument (1 = 3x3, 2 = phase, 3 = dgrad4x4); bench.py: conv_halo_bf16<form,BMxBN>
-    m = re.search(r"conv_igemm_dma<__bf16, (\d+), (\d+), \d+, \d+, \d+, (?:true|false), \d+, ([123])>", k)
+    m = re.search(r"conv_igemm_dma<__bf16, (\d+), (\d+), \d+, \d+, \d+, (?:true|false), \d+, ([123])(?:, \d+)*>", k)
     if m:
         return "conv_halo_bf16<{},{}x{}>".format(HALO_FORMS[m.group(3)], m.group(1), m.group(2))
-    m = re.search(r"conv_igemm_dmaIDF16bLi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb[01]ELi\d+ELi([123])EE", k)
+    m = re.search(r"conv_igemm_dmaIDF16bLi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb[01]ELi\d+ELi([123])E(?:Li\d+E)*E", k)
     if m:
         return "conv_halo_bf16<{},{}x{}>".format(HALO_FORMS[m.group(3)], m.group(1), m.group(2))
     m = re.search(r"conv_igemm_dma<(float|__bf16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, (?:\d+|true|false))*>", k)

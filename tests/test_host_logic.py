@@ -185,7 +185,12 @@ def test_profiler_symbols_map_to_the_bench_names():
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi256ELi2ELi4ELi128ELb1ELi0EEEv9ConvArgsTIT_E": "conv_igemm_bf16<phase,256x256,r128>",
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi128ELi4ELi2ELi128ELb1ELi0ELi2EEEv9ConvArgsTIT_E": "conv_halo_bf16<phase,256x128>",
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi256ELi64ELi4ELi2ELi128ELb0ELi1ELi1EEEv9ConvArgsTIT_E": "conv_halo_bf16<3x3,256x64>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi512ELi128ELi4ELi2ELi64ELb1ELi0ELi2ELi0EEEv9ConvArgsTIT_E": "conv_halo_bf16<phase,512x128>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi512ELi128ELi4ELi2ELi64ELb0ELi0ELi3ELi0EEEv9ConvArgsTIT_E": "conv_halo_bf16<dgrad4x4,512x128>",
+        "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi128ELi128ELi2ELi2ELi64ELb0ELi2ELi0ELi0EEEv9ConvArgsTIT_E": "conv_igemm_bf16<128x128,r64>",
         ns + "conv_igemm_dma<__bf16, 256, 128, 4, 2, 128, false, 0, 3>(ConvArgsT<__bf16>)": "conv_halo_bf16<dgrad4x4,256x128>",
+        ns + "conv_igemm_dma<__bf16, 256, 128, 4, 2, 128, false, 0, 3, 0>(ConvArgsT<__bf16>)": "conv_halo_bf16<dgrad4x4,256x128>",
+        ns + "conv_igemm_dma<float, 128, 128, 2, 2, 64, false, 0, 0, 0>(ConvArgsT<float>)": "conv_igemm_f32<128x128,r64>",
         ns + "conv_igemm_f32<128, 64, 2, 2, 1>((anonymous namespace)::ConvArgs)": "conv_igemm_f32<128x64,stem>",
         ns + "conv_thin_bf16<1>((anonymous namespace)::ThinConvArgs)": "conv_thin_bf16<phase>",
         ns + "conv_wgrad_thin_bf16<4, 1>((anonymous namespace)::ThinArgs)": "conv_wgrad_thin_bf16<128,ups>",

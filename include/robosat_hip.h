@@ -214,7 +214,11 @@ int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* 
  * tile (index as above; honoured for every launch that tile can run, -1 = the measured heuristics) and the K-chunk row
  * size (64 | 128; 0 = heuristics).  rs_conv2d_config reports what a launch will then use, so a test can assert that the
  * symbol it means to cover is the one that ran.  The reference has no counterpart: cuDNN's autotuner
- * (torch.backends.cudnn.benchmark, tools/train.py:72-73) is its equivalent of the heuristics this overrides. */
+ * (torch.backends.cudnn.benchmark, tools/train.py:72-73) is its equivalent of the heuristics this overrides.
+ * Tile 8 = the bf16 HALO-ONCE forms (3x3 / stride 1 / pad 1; DecoderBlock phase form; its 4x4 / stride-2 data gradient):
+ * the block's rows are a 2-D patch of the output grid (8 x 32 pixels; rowb = 64: 16 x 32 pixels with 32-channel chunks),
+ * its source halo is copied to LDS once per channel chunk and every filter tap reads it at a row offset.  rs_conv2d_config
+ * reports them as tile 8 with the N tile (128 | 64, + 0x1000 for the 512-pixel patch) in *rowb. */
 int rs_conv2d_set_tuning(int tile, int rowb);
 const char* rs_conv2d_tile_name_bf16(int tile);
 

@@ -33,7 +33,21 @@ def cpu_logic(rank, world):
     red.reduce_async(flat[0:400])
     red.reduce_async(flat[400:1000])
     red.wait()
+    # the global-batch branch of mIoULoss2d (robosat_amd.losses._global_batch_miou) on hand-made per-rank statistics: rank 0 has
+    # the larger NLL, rank 1 the larger soft-IoU term; the global batch takes the NLL branch with the global denominator
+    from robosat_amd import losses
+
+    nc = 2 * 3  # (N * C gradient coefficients per half: unused here)
+    miou_r, num_r, sw_r = (0.8, 14.0, 10.0) if rank == 0 else (0.07, 0.4, 11.0)
+    stats = torch.zeros(5 + 2 * nc)
+    stats[0], stats[1], stats[2] = max(miou_r, num_r / sw_r), sw_r, float(num_r / sw_r > miou_r)
+    stats[-2], stats[-1] = miou_r, num_r
+    local_branch = float(stats[2])
+    got = losses._global_batch_miou(stats[0].clone(), stats, True)
+    off = losses._global_batch_miou(stats[0].clone(), stats.clone(), False)
     return {"before": before, "sums": [float(s) for s in sums], "running_var": net[1].running_var.tolist(),
+            "miou_dp": {"loss": float(got), "branch": float(stats[2]), "den": float(stats[1]), "local_branch": local_branch,
+                        "untouched_without_opt_in": float(off)},
             "flat_ok": bool(torch.allclose(flat, torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1)) / world)),
             "loss": parallel.average_scalars([float(rank)], torch.device("cpu"))[0],
             "counts": parallel.sum_counts(torch.tensor([1, 2, 3, 4 + rank])).tolist(),

@@ -35,6 +35,15 @@ def test_launcher_reducer_broadcast_and_sharding_world2(tmp_path):
         assert r["counts"] == [2, 4, 6, 9]
         assert r["sums"][0] == r["sums"][1]  # after broadcast_module both replicas hold rank 0's parameters + buffers
         assert r["running_var"] == [2.0] * 4  # rank 0's running_var (x2), also on rank 1 (which had x3)
+    # mIoULoss2d under data parallelism: ONE branch decision over the global batch (losses.py:72-83 under DataParallel).
+    # rank 0: miou 0.8 < nll 1.4; rank 1: miou 0.07 > nll 0.036 -> alone they differ; global: nll (14.4 / 21) > miou 0.435
+    for rank, r in enumerate(res):
+        m = r["miou_dp"]
+        assert m["branch"] == 1.0 and abs(m["den"] - 10.5) < 1e-6, m            # NLL branch everywhere, D = mean_r sum w
+        assert abs(m["loss"] - ((14.0, 0.4)[rank] / 10.5)) < 1e-6, m            # num_r / D: the ranks' mean is 14.4 / 21
+        assert m["local_branch"] == (1.0, 0.0)[rank]                              # (the shards alone choose differently)
+        assert abs(m["untouched_without_opt_in"] - (1.4, 0.07)[rank]) < 1e-6, m  # no collective, no change without the opt-in
+    assert abs((res[0]["miou_dp"]["loss"] + res[1]["miou_dp"]["loss"]) / 2 - 14.4 / 21.0) < 1e-6
     assert res[0]["before"] != res[1]["before"]  # ... and they really started different
     # 10 samples, 2 per rank, 2 ranks -> 2 global batches of 4 (drop_last), split contiguously like DataParallel
     assert res[0]["shards"] == [[0, 1], [4, 5]] and res[1]["shards"] == [[2, 3], [6, 7]]

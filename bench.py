@@ -318,6 +318,8 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
             from robosat_amd import parallel
 
             parallel.broadcast_module(net)  # (the replicas are seeded identically; this is what `rs train` does)
+            if dist and hasattr(crit, "global_batch"):
+                crit.global_batch = True  # batch-level loss terms over the GLOBAL batch, as rs train sets it (losses.py)
             # bucketed RCCL all-reduce overlapped with the backward kernels (--force-reducer: over a group of one rank too)
             net.grad_reducer = GradReducer(wire_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32,
                                            force=force_reducer)

@@ -68,21 +68,10 @@ __device__ __forceinline__ int w33_swz(int row) { return (row ^ (row >> 1)) & 3;
 // HEAD: 0 = the layer alone; 1 / 2 / 3 = + self.final and logits-or-softmax / quantised probabilities / argmax (one
 // instantiation per output kind: each carries only its own epilogue code -- the kernel's instructions are fetched cold on
 // every launch, which a single-tile `rs serve` request pays for in full)
-// WPC = cout groups per WAVE.  1: eight waves, wave (tg, cg) owns 16 tiles x 16 couts -- both cout groups of a tile group
-//      repeat the same input transform, and the two waves of a SIMD do theirs at the same time (they leave the chunk's
-//      barrier together), so the matrix pipe idles for both.  2: FOUR waves, one per SIMD, wave tg owns 16 tiles x all 32
-//      couts of the block: one transform per 128 MFMAs instead of per 64, 32 accumulators (the wave has the SIMD's whole
-//      register file), and self.final needs no exchange between waves.
-// VAR (bits): 1 = the next chunk's LDS-DMA pieces all go out right behind the chunk's barrier, BEFORE the input transform
-//      (a whole period to land), instead of spread over the chunk's MFMAs; 2 = measurement only, results WRONG: no wait for
-//      the DMA at all (what the kernel takes when no piece is ever late).
-template <int TG, int CG, int HEAD = 0, int WPC = 1, int VAR = 0>
-__global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void conv_wino33_f32_kernel(const Wino33Args p) {
-  constexpr int NW = TG * CG / WPC;
-  // (TG x CG = 4 x 1: a four-wave block of 64 tiles x 16 couts, 76 KB of LDS -- TWO independent blocks per CU, each SIMD
-  //  holding one wave of either: their chunk barriers are not in step, so one block's reads and transform run under the
-  //  other's MFMAs)
-  static_assert(NW == 8 || (NW == 4 && WPC == 2 && CG == 2) || (NW == 4 && WPC == 1 && CG == 1), "8 waves, or 4");
+template <int TG, int CG, int HEAD = 0>
+__global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Args p) {
+  constexpr int NW = TG * CG;
+  static_assert(NW == 8, "8 waves");
   static_assert(!HEAD || (TG == 4 && CG == 2), "the fused head: one 8x8 patch of tiles x all 32 couts per block");
   constexpr int BMT = 16 * TG, BN = 16 * CG;
   constexpr int SB = BMT / (kPB * kPB);
@@ -105,7 +94,7 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tg = wave % TG, cg = WPC == 1 ? wave / TG : 0;  // (WPC = 2: the wave's FIRST cout group; the second is cg + 1)
+  const int tg = wave % TG, cg = wave / TG;
   const int per_img = p.BBY * p.BBX;
   const int nk = p.Cin / KC;
   const int ntiles = ((p.nsub + SB - 1) / SB) * p.ncb;
@@ -201,7 +190,6 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
       }
   }
   const int addrB = AROWS_PAD * 64 + (16 * cg + l15) * 64 + ((pc ^ w33_swz(l15)) & 3) * 16;  // + xi * BN * 64 (BN, 16 cg: multiples of 8)
-  constexpr int kCgB = 16 * 64;  // LDS bytes from a cout group's filter rows to the next group's
 
   if constexpr (HEAD) {
     for (int f = threadIdx.x; f < HEADW; f += 64 * NW) {
@@ -222,7 +210,7 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
   long hpix = -1;
   int hbuf = 0;
   auto finish_head = [&]() __attribute__((always_inline)) {
-    if constexpr (HEAD != 0 && WPC == 1) {
+    if constexpr (HEAD) {
       if (cg == 0) {
         const float* xrow = xch + hbuf * XCH + (16 * tg + l15) * XROW + pc * kHeadMaxC;
         const f32x4 o0 = *reinterpret_cast<const f32x4*>(xrow), o1 = *reinterpret_cast<const f32x4*>(xrow + 4);
@@ -236,27 +224,18 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
   };
 
   int g = 0;
-  f32x4 V[16];
   for (int seq = 0; seq < nitems; ++seq) {
-    f32x4 acc[WPC][16];
+    f32x4 acc[16];
 #pragma unroll
-    for (int w = 0; w < WPC; ++w)
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[w][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 16; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kc = 0; kc < nk; ++kc, ++g) {
-      if constexpr (!(VAR & 2)) rb_dma_wait();
+      rb_dma_wait();
       __syncthreads();
-      if (HEAD && WPC == 1 && kc == 0 && seq > 0) finish_head();  // (behind this barrier the other cout group's partial logits are in LDS)
+      if (HEAD && kc == 0 && seq > 0) finish_head();  // (behind this barrier the other cout group's partial logits are in LDS)
       const unsigned char* L = smem + (g & 1) * STAGE;
-      if constexpr (VAR & 1) {  // (stage (g + 1) & 1 was last read before this barrier)
-        fetch_chunk([&](auto issue) __attribute__((always_inline)) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j) issue(j);
-        }, !(g + 1 < total));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (!(VAR & 4) || g == 0) {  // (VAR & 4, measurement only, results WRONG: the patch is read and transformed once per launch)
+      f32x4 V[16];
+      {
         // (the transform on 2-float halves: hipcc turns those into v_pk_add_f32 -- two lanes' worth of fp32 adds per
         //  instruction -- where the 4-float form came out as scalar v_sub_f32)
         f32x2 Pl[4][4], Ph[4][4];
@@ -291,31 +270,26 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
         }
       }
       const bool more = g + 1 < total;
-      constexpr int NMMA = 64 * WPC, PSTEP = NMMA / NI >= 1 ? NMMA / NI : 1;
-      f32x4 Bq[WPC][16];
-#pragma unroll
-      for (int w = 0; w < WPC; ++w) Bq[w][0] = *reinterpret_cast<const f32x4*>(L + addrB + w * kCgB);
+      constexpr int NMMA = 64, PSTEP = NMMA / NI >= 1 ? NMMA / NI : 1;
+      f32x4 Bq[16];
+      Bq[0] = *reinterpret_cast<const f32x4*>(L + addrB);
       __builtin_amdgcn_sched_barrier(0);
       auto mfmas = [&](auto issue) __attribute__((always_inline)) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
           if (x + 1 < 16) {
-#pragma unroll
-            for (int w = 0; w < WPC; ++w) Bq[w][x + 1] = *reinterpret_cast<const f32x4*>(L + addrB + w * kCgB + (x + 1) * BN * 64);
-            __builtin_amdgcn_sched_barrier(0);  // (keep the reads in front of the MFMAs below)
+            Bq[x + 1] = *reinterpret_cast<const f32x4*>(L + addrB + (x + 1) * BN * 64);
+            __builtin_amdgcn_sched_barrier(0);  // (keep the read in front of the MFMAs below)
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int w = 0; w < WPC; ++w) {
-              const int q = (x * 4 + k) * WPC + w;
-              if (q % PSTEP == 0 && q / PSTEP < NI) issue(q / PSTEP);
-              acc[w][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bq[w][x][k], V[x][k], acc[w][x], 0, 0, 0);
-            }
+          for (int k = 0; k < 4; ++k) {
+            const int q = x * 4 + k;
+            if (q % PSTEP == 0 && q / PSTEP < NI) issue(q / PSTEP);
+            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bq[x][k], V[x][k], acc[x], 0, 0, 0);
+          }
         }
       };
-      if constexpr (VAR & 1) mfmas([](int) __attribute__((always_inline)) {});
-      else fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); }, !more);
+      fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); }, !more);
       if (kc == 0 && seq + 1 < nitems) build_table(seq + 1);
     }
 
@@ -327,77 +301,42 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
     const int n = sub / per_img, r2 = sub - n * per_img;
     const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
     const int a0 = 2 * (bby * kPB + tty), b0 = 2 * (bbx * kPB + ttx);
-    const int co = nblk * BN + 16 * cg + 4 * pc;  // (+ 16 w for the wave's cout group w)
-    f32x4 Y[WPC][2][2];
+    const int co = nblk * BN + 16 * cg + 4 * pc;
+    f32x4 Y[2][2];
     if (live || HEAD) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + co);
+      f32x4 R[2][4];  // rows transformed: R[u][b] = sum_a A^T[u][a] M[a][b]
 #pragma unroll
-      for (int w = 0; w < WPC; ++w) {
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + co + 16 * w);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + co + 16 * w);
-        f32x4 R[2][4];  // rows transformed: R[u][b] = sum_a A^T[u][a] M[a][b]
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          R[0][b] = (acc[w][0 * 4 + b] + acc[w][1 * 4 + b]) + acc[w][2 * 4 + b];
-          R[1][b] = (acc[w][1 * 4 + b] - acc[w][2 * 4 + b]) - acc[w][3 * 4 + b];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            f32x4 y = v == 0 ? (R[u][0] + R[u][1]) + R[u][2] : (R[u][1] - R[u][2]) - R[u][3];
-            y = y * sc + sh;
-            if (p.relu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-            }
-            Y[w][u][v] = y;
-          }
+      for (int b = 0; b < 4; ++b) {
+        R[0][b] = (acc[0 * 4 + b] + acc[1 * 4 + b]) + acc[2 * 4 + b];
+        R[1][b] = (acc[1 * 4 + b] - acc[2 * 4 + b]) - acc[3 * 4 + b];
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          f32x4 y = v == 0 ? (R[u][0] + R[u][1]) + R[u][2] : (R[u][1] - R[u][2]) - R[u][3];
+          y = y * sc + sh;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+          }
+          Y[u][v] = y;
+        }
     }
     if constexpr (!HEAD) {
       if (live) {
 #pragma unroll
-        for (int w = 0; w < WPC; ++w)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-              const int a = a0 + u, b = b0 + v;
-              if (a >= p.H || b >= p.W) continue;
-              *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co + 16 * w) = Y[w][u][v];
-            }
-      }
-    } else if constexpr (WPC == 2) {
-      // ---- self.final with all 32 channels of the block in this wave: per cout group the lane's 4 couts -> the group's 16
-      //      (lanes l15 + 16 pc), then (group 0 + group 1) + bias -- the association of the eight-wave form, bit for bit --
-      //      and one pixel per lane (pixel pc of tile l15).
-      float lg[kHeadMaxC];
-#pragma unroll
-      for (int c = 0; c < kHeadMaxC; ++c) {
-        float mine[2] = {0.f, 0.f};
-        if (c < p.hC) {
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(hws + c * 32 + 16 * w + 4 * pc);
-            float part[4];
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-              const f32x4 y = Y[w][px >> 1][px & 1];
-              float v = fmaf(y[3], wv[3], fmaf(y[2], wv[2], fmaf(y[1], wv[1], y[0] * wv[0])));
-              v += __shfl_xor(v, 16);
-              v += __shfl_xor(v, 32);
-              part[px] = v;
-            }
-            mine[w] = pc == 0 ? part[0] : (pc == 1 ? part[1] : (pc == 2 ? part[2] : part[3]));
+          for (int v = 0; v < 2; ++v) {
+            const int a = a0 + u, b = b0 + v;
+            if (a >= p.H || b >= p.W) continue;
+            *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = Y[u][v];
           }
-        }
-        lg[c] = (mine[0] + mine[1]) + hws[kHeadMaxC * 32 + c];
       }
-      const int a = a0 + (pc >> 1), b = b0 + (pc & 1);
-      if (live && a < p.H && b < p.W)
-        rs_final_epilogue_rt(lg, p.hC, (long)(n * p.H + a) * p.W + b, (long)p.H * p.W, HEAD == 1 ? (p.hmode & 1) : HEAD, p.hanchors, p.hq,
-                             p.hout, p.W, p.hov);
     } else {
       // ---- self.final on the block's 32 channels: this lane's 4 couts -> the wave's 16 (lanes l15 + 16 pc) -> both cout
       //      groups (waves tg and tg + TG, through LDS) + bias; then one pixel per lane of the cg = 0 waves (pixel pc of tile
@@ -409,7 +348,7 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
           const f32x4 wv = *reinterpret_cast<const f32x4*>(hws + c * 32 + 16 * cg + 4 * pc);
 #pragma unroll
           for (int px = 0; px < 4; ++px) {
-            const f32x4 y = Y[0][px >> 1][px & 1];
+            const f32x4 y = Y[px >> 1][px & 1];
             float v = fmaf(y[3], wv[3], fmaf(y[2], wv[2], fmaf(y[1], wv[1], y[0] * wv[0])));
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
@@ -438,7 +377,7 @@ __global__ __launch_bounds__(64 * TG * CG / WPC, (TG * CG == 4 ? 2 : 1)) void co
       hpix = (live && a < p.H && b < p.W) ? (long)(n * p.H + a) * p.W + b : -1;
     }
   }
-  if constexpr (HEAD != 0 && WPC == 1) {
+  if constexpr (HEAD) {
     __syncthreads();
     if (nitems > 0) finish_head();
   }
@@ -480,22 +419,6 @@ int w33_cus() {
     return cus;
   }();
   return n;
-}
-
-// Cout groups per wave of the 32-cout blocks (the kernel's WPC): 2 unless RS_WINO33_WPC=1 asks for the eight-wave form.
-int w33_wpc() {
-  static const int v = [] {
-    const char* e = getenv("RS_WINO33_WPC");
-    return (e && e[0] == '2') ? 2 : 1;
-  }();
-  return v;
-}
-int w33_var() {
-  static const int v = [] {
-    const char* e = getenv("RS_WINO33_VAR");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
 }
 
 // 0: cannot run; 1: can and should; (there is no "can but should not": the form needs >= 8 tiles per image side to run at all)
@@ -569,16 +492,7 @@ extern "C" int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, con
   if (items >= (1L << 31)) return RS_EINVAL;
   const int grid = (int)(items < w33_cus() ? items : w33_cus());
   hipStream_t s = (hipStream_t)stream;
-  if (cgn == 2 && w33_wpc() == 2) conv_wino33_f32_kernel<4, 2, 0, 2><<<grid, 256, 0, s>>>(a);
-  else if (cgn == 2 && w33_var() == 1) conv_wino33_f32_kernel<4, 2, 0, 1, 1><<<grid, 512, 0, s>>>(a);
-  else if (cgn == 2 && w33_var() == 2) conv_wino33_f32_kernel<4, 2, 0, 1, 2><<<grid, 512, 0, s>>>(a);
-  else if (cgn == 2 && w33_var() == 6) conv_wino33_f32_kernel<4, 2, 0, 1, 6><<<grid, 512, 0, s>>>(a);
-  else if (cgn == 2 && w33_var() == 4) {
-    a.ncb = d->Cout / 16;
-    const long it4 = (long)a.nsub * a.ncb;
-    conv_wino33_f32_kernel<4, 1><<<(int)(it4 < 2 * w33_cus() ? it4 : 2 * w33_cus()), 256, 0, s>>>(a);
-  }
-  else if (cgn == 2) conv_wino33_f32_kernel<4, 2><<<grid, 512, 0, s>>>(a);
+  if (cgn == 2) conv_wino33_f32_kernel<4, 2><<<grid, 512, 0, s>>>(a);
   else conv_wino33_f32_kernel<8, 1><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }
@@ -622,15 +536,7 @@ extern "C" int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src
   if (items >= (1L << 31)) return RS_EINVAL;
   const int grid = (int)(items < w33_cus() ? items : w33_cus());
   hipStream_t s = (hipStream_t)stream;
-  if (w33_wpc() == 2) {
-    if (mode <= 1) conv_wino33_f32_kernel<4, 2, 1, 2><<<grid, 256, 0, s>>>(a);
-    else if (mode == 2) conv_wino33_f32_kernel<4, 2, 2, 2><<<grid, 256, 0, s>>>(a);
-    else conv_wino33_f32_kernel<4, 2, 3, 2><<<grid, 256, 0, s>>>(a);
-  } else if (w33_var() & 1) {
-    if (mode <= 1) conv_wino33_f32_kernel<4, 2, 1, 1, 1><<<grid, 512, 0, s>>>(a);
-    else if (mode == 2) conv_wino33_f32_kernel<4, 2, 2, 1, 1><<<grid, 512, 0, s>>>(a);
-    else conv_wino33_f32_kernel<4, 2, 3, 1, 1><<<grid, 512, 0, s>>>(a);
-  } else if (mode <= 1) conv_wino33_f32_kernel<4, 2, 1><<<grid, 512, 0, s>>>(a);
+  if (mode <= 1) conv_wino33_f32_kernel<4, 2, 1><<<grid, 512, 0, s>>>(a);
   else if (mode == 2) conv_wino33_f32_kernel<4, 2, 2><<<grid, 512, 0, s>>>(a);
   else conv_wino33_f32_kernel<4, 2, 3><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();

@@ -89,8 +89,7 @@ __device__ __forceinline__ int wino_swz(int row) { return (row ^ (row >> 1)) & 3
 
 // TG tile groups (16 tiles each) x CG cout groups (32 couts each) = 8 waves per block
 // NM = MFMA tiles of 16 couts per wave (a wave owns 16 tiles x 16*NM couts)
-// VAR 1: the next chunk's LDS-DMA pieces all go out right behind the chunk's barrier, before the input transform
-template <int PB, int TG, int CG, int NM = 2, int VAR = 0>
+template <int PB, int TG, int CG, int NM = 2>
 __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p) {
   using G = WinoGeom<PB>;
   constexpr int NW = TG * CG;
@@ -245,7 +244,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
   const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
 
   int g = 0;
-  f32x4 V[9];
   for (int seq = 0; seq < nitems; ++seq) {
     f32x4 acc[9][NM];
 #pragma unroll
@@ -254,23 +252,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       for (int m = 0; m < NM; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kc = 0; kc < nk; ++kc, ++g) {
-      if constexpr (!(VAR & 2)) rb_dma_wait();  // (VAR & 2 / VAR & 4: measurement only, results WRONG -- no wait for the DMA / the patch read and transformed once per launch)
+      rb_dma_wait();
       __syncthreads();  // chunk g is in stage g & 1; stage (g + 1) & 1 is free again
       const unsigned char* L = smem + (g & 1) * STAGE;
-      if constexpr (VAR & 1) {
-        fetch_chunk([&](auto issue) __attribute__((always_inline)) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j) issue(j);
-        }, !(g + 1 < total));
-        __builtin_amdgcn_sched_barrier(0);
-      }
       f32x4 P[3][3];
-      if (!(VAR & 4) || g == 0) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) P[r][c] = *reinterpret_cast<const f32x4*>(L + addrA[r][c]);
-      }
+        for (int c = 0; c < 3; ++c) P[r][c] = *reinterpret_cast<const f32x4*>(L + addrA[r][c]);
       const bool more = g + 1 < total;
       // LDS-DMA pieces of the NEXT chunk, spread evenly over this chunk's MFMAs: the CU's DMA path moves ~23 B/clk and this
       // kernel needs ~12 B/clk of it (55 KB per 4608 MFMA cycles); issued in a burst the pieces queue up and hold the issuing
@@ -284,7 +273,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       __builtin_amdgcn_sched_barrier(0);
       // V = B^T d B: along x, then along y ([d0 - d1, d1, d2 - d1] each way), on 2-float halves with v_pk_add_f32 (two fp32
       // subtractions per instruction; written as 4-float vector code hipcc emits scalar v_sub_f32: measured -4 % on the 3x3 form)
-      if (!(VAR & 4) || g == 0) {
+      f32x4 V[9];
+      {
         f32x2 Tl[3][3], Th[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -325,8 +315,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
             }
         }
       };
-      if constexpr (VAR & 1) mfmas([](int) __attribute__((always_inline)) {});
-      else fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); }, !more);
+      fetch_chunk([&](auto issue) __attribute__((always_inline)) { mfmas(issue); }, !more);
 
       if (kc == 0 && seq + 1 < nitems) build_table(seq + 1);  // (its buffer held item seq - 1's table: the fetch side left it a whole item ago)
     }
@@ -483,17 +472,7 @@ extern "C" int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1
   // persistent: one block per CU (its LDS stages fill the CU), items dealt round-robin
   const int grid = (int)(items < wino_cus() ? items : wino_cus());
   hipStream_t s = (hipStream_t)stream;
-  static const int var = [] {
-    const char* e = getenv("RS_WINO_VAR");
-    return e ? atoi(e) : 0;
-  }();
-  if (pl.wide && var == 1) conv_wino_f32_kernel<8, 8, 1, 4, 1><<<grid, 512, 0, s>>>(a);
-  else if (pl.wide && var == 2) conv_wino_f32_kernel<8, 8, 1, 4, 2><<<grid, 512, 0, s>>>(a);
-  else if (pl.wide && var == 4) conv_wino_f32_kernel<8, 8, 1, 4, 4><<<grid, 512, 0, s>>>(a);
-  else if (pl.wide && var == 6) conv_wino_f32_kernel<8, 8, 1, 4, 6><<<grid, 512, 0, s>>>(a);
-  else if (pl.pb == 8 && pl.wgn == 2 && var == 1) conv_wino_f32_kernel<8, 4, 2, 2, 1><<<grid, 512, 0, s>>>(a);
-  else if (pl.pb == 8 && var == 1) conv_wino_f32_kernel<8, 8, 1, 2, 1><<<grid, 512, 0, s>>>(a);
-  else if (pl.wide) conv_wino_f32_kernel<8, 8, 1, 4><<<grid, 512, 0, s>>>(a);  // 128 tiles x 64 couts
+  if (pl.wide) conv_wino_f32_kernel<8, 8, 1, 4><<<grid, 512, 0, s>>>(a);  // 128 tiles x 64 couts
   else if (pl.pb == 8 && pl.wgn == 2) conv_wino_f32_kernel<8, 4, 2><<<grid, 512, 0, s>>>(a);
   else if (pl.pb == 8) conv_wino_f32_kernel<8, 8, 1><<<grid, 512, 0, s>>>(a);
   else if (pl.wgn == 2) conv_wino_f32_kernel<4, 4, 2><<<grid, 512, 0, s>>>(a);

@@ -42,9 +42,8 @@ def bench_name(k):
     m = re.search(r"conv_wino_f32_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?>", k)
     if m:
         return "conv_wino_f32<phase,p{},{}x{}>".format(m.group(1), 16 * int(m.group(2)), 16 * int(m.group(4) or 2) * int(m.group(3)))
-    m = re.search(r"conv_wino33_f32_kernel<(\d+), (\d+)(?:, (true|false|\d+))?(?:, \d+)?>", k)
-    if m:  # (third parameter: 0 / absent = the layer alone, 1..3 = + self.final with one of its three output kinds; fourth:
-        #    cout groups per wave -- the same block tile either way)
+    m = re.search(r"conv_wino33_f32_kernel<(\d+), (\d+)(?:, (true|false|\d+))?>", k)
+    if m:  # (third parameter: 0 / absent = the layer alone, 1..3 = + self.final with one of its three output kinds)
         head = m.group(3) not in (None, "false", "0")
         return "conv_wino_f32<3x3{},p8,{}x{}>".format("+final" if head else "", 16 * int(m.group(1)), 16 * int(m.group(2)))
     m = re.search(r"conv_thin_bf16<(\d)>", k)

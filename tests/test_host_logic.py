@@ -179,9 +179,6 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_wino33_f32_kernel<4, 2, 0>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3,p8,64x32>",
         ns + "conv_wino33_f32_kernel<4, 2, 1>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
         ns + "conv_wino33_f32_kernel<4, 2, 3>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
-        ns + "conv_wino33_f32_kernel<4, 2, 0, 2>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3,p8,64x32>",
-        ns + "conv_wino33_f32_kernel<4, 2, 2, 2>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
-        ns + "conv_wino33_f32_kernel<8, 1, 0, 1>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3,p8,128x16>",
         ns + "conv_igemm_dma<float, 128, 128, 2, 2, 64, false, 0>(ConvArgsT<float>)": "conv_igemm_f32<128x128,r64>",
         ns + "conv_igemm_dma<float, 64, 64, 2, 2, 128, true, 0>(ConvArgsT<float>)": "conv_igemm_f32<phase,64x64,r128>",
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi128ELi128ELi2ELi2ELi64ELb0ELi2EEEv9ConvArgsTIT_E": "conv_igemm_bf16<128x128,r64>",

@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of variants of the two fp32 Winograd kernels on the predict pass (env knobs of conv_wino33_f32.hip / conv_wino_f32.hip):
+# (The knobs RS_WINO33_WPC / RS_WINO33_VAR / RS_WINO_VAR exist only in commit 0489e6e, which the next commit reverts: check that
+#  commit out to repeat the measurement; results are in profiles/r04/wino_variants_r04.txt.)
 # parity tests of the kernels under the variant first, then the predict bench with each setting.
 OUT=gpurun_out/${1:-wpc}; mkdir -p $OUT
 timeout 60 python -c "import torch; x = torch.arange(1 << 20, device='cuda:0', dtype=torch.float32); assert float((x * 2).sum().cpu()) == float((1 << 20) * ((1 << 20) - 1))" || { echo "GPU sanity failed"; exit 3; }

@@ -1,6 +1,7 @@
 // MEASUREMENT BUILD of the HALO_PHASE kernel with parts knocked out (KO template parameter of conv_igemm_dma_kernel.h):
-// selected by the environment variable RS_HALO_KO = 1..4 in the dispatcher, never by a product path -- the results of a
-// knocked-out launch are wrong by construction.  scripts/halo_knockout.sh times them on dec3's shape.
+// NOT part of the default library: `make KO=1` compiles this file and the dispatcher's RS_HALO_KO = 1..4 branch
+// (-DRS_HALO_KO_BUILD) -- the results of a knocked-out launch are wrong by construction.  scripts/halo_knockout.sh builds
+// that way, times them on dec3's shape and restores the default build.
 #define RS_CONV_INSTANTIATE
 #include "conv_igemm_dma_kernel.h"
 

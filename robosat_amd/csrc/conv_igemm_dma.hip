@@ -391,7 +391,9 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
       hipStream_t hs = (hipStream_t)stream;
       if (bm == 512) bn |= 0x1000;
       if (hm == HALO_33) rs_conv_launch_bf16_halo33(bn, epi, grid, hs, a);
-      else if (hm == HALO_PHASE && bn == 128 && getenv("RS_HALO_KO")) rs_conv_launch_bf16_halo_phase_ko(atoi(getenv("RS_HALO_KO")), grid, hs, a);  // (measurement only)
+#ifdef RS_HALO_KO_BUILD  // (`make KO=1`: the knock-out instantiations of conv_halo_ko.hip, measurement only -- not in the default library)
+      else if (hm == HALO_PHASE && bn == 128 && getenv("RS_HALO_KO")) rs_conv_launch_bf16_halo_phase_ko(atoi(getenv("RS_HALO_KO")), grid, hs, a);
+#endif
       else if (hm == HALO_PHASE) rs_conv_launch_bf16_halo_phase(bn, 0, grid, hs, a);
       else rs_conv_launch_bf16_halo_dg4(bn, 0, grid, hs, a);
       return RS_LAUNCH_RESULT();

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Does the HIP queue priority of the two streams of the train step (main: forward / dgrad / BatchNorm chain, side: weight
+# (ROBOSAT_MAIN_PRIORITY / ROBOSAT_SIDE_PRIORITY were two-line measurement knobs in bench.py / autograd._side_stream -- torch.cuda.Stream(priority=...) --
+#  not kept: the result, "no effect", is in profiles/r04/halo_variants.txt.)
 # gradients) move the bf16 train step?  ROBOSAT_MAIN_PRIORITY (bench.py) / ROBOSAT_SIDE_PRIORITY (autograd._side_stream).
 OUT=gpurun_out/${1:-prio}; mkdir -p $OUT
 timeout 60 python -c "import torch; x = torch.arange(1 << 20, device='cuda:0', dtype=torch.float32); assert float((x * 2).sum().cpu()) == float((1 << 20) * ((1 << 20) - 1)); print(torch.cuda.Stream.priority_range())" || { echo "GPU sanity failed"; exit 3; }

@@ -72,3 +72,37 @@ def test_ranks_for_batch_follows_dataparallel_scatter():
     assert ranks_for_batch(12, 8) == 6
     assert ranks_for_batch(7, 4) == 1
     assert ranks_for_batch(16, 1) == 1
+
+
+def test_sharding_properties_for_every_world_size():
+    """For 1..8 ranks: the ranks' shares of a global batch, concatenated in rank order, ARE the reference's batch (what
+    DataParallel's scatter along dim 0 gives, tools/train.py:69), with the reference's drop_last; ``rs predict``'s
+    sequential batches are dealt so that every tile is predicted exactly once and ``len()`` tells each rank's count."""
+
+    import random
+
+    from robosat_amd.parallel import shard_indices
+    from robosat_amd.tools.predict import RankBatchSampler
+
+    rng = random.Random(7)
+    for world in range(1, 9):
+        for n, per_rank in ((0, 2), (5, 1), (64, 4), (67, 2), (100, 3)):
+            order = list(range(n))
+            rng.shuffle(order)
+            shards = [shard_indices(n, per_rank, r, world, epoch_order=order) for r in range(world)]
+            gb = per_rank * world
+            assert all(len(s) == n // gb for s in shards)  # drop_last on the GLOBAL batch, the same step count on every rank
+            for b in range(n // gb):
+                assert sum((shards[r][b] for r in range(world)), []) == order[b * gb:(b + 1) * gb]
+            # validation order: no permutation given = range(n)
+            assert shard_indices(n, per_rank, 0, world)[:1] == ([list(range(per_rank))] if n >= gb else [])
+        for n, bs in ((0, 3), (1, 3), (10, 3), (4096, 16), (4097, 16)):
+            per_rank = [list(RankBatchSampler(n, bs, r, world)) for r in range(world)]
+            assert [len(RankBatchSampler(n, bs, r, world)) for r in range(world)] == [len(p) for p in per_rank]
+            seen = sorted(i for p in per_rank for batch in p for i in batch)
+            assert seen == list(range(n))  # every tile once
+            # batch b of the reference's sequential loader goes to rank b % world, whole
+            for r, p in enumerate(per_rank):
+                for k, batch in enumerate(p):
+                    b = k * world + r
+                    assert batch == list(range(b * bs, min((b + 1) * bs, n)))

@@ -259,3 +259,32 @@ def test_resize_treats_an_alpha_plane_as_a_data_band():
     assert np.array_equal(np.asarray(Resize((32, 32), Image.BILINEAR)(opaque)), np.asarray(opaque.resize((32, 32), Image.BILINEAR)))
     # same size: a copy, whatever the mode
     assert np.array_equal(np.asarray(Resize((48, 48), Image.BILINEAR)(img)), np.asarray(img))
+
+
+def test_history_plot_is_the_references_picture(tmp_path):
+    """``history-*.png`` (robosat/utils.py:8-25, written by tools/train.py:146-148): drawn here without pyplot state, the
+    same pixels as the reference's function where the reference is present (this container), a valid PNG anywhere."""
+
+    import collections
+    import importlib.util
+
+    import numpy as np
+    from PIL import Image
+
+    from robosat_amd.utils import plot
+
+    history = collections.OrderedDict([("train loss", [0.9, 0.7, 0.5]), ("train miou", [0.1, 0.3, 0.5]),
+                                       ("val loss", [1.0, 0.8, 0.75]), ("val miou", [0.2, 0.4, 0.45])])
+    mine = str(tmp_path / "mine.png")
+    plot(mine, history)
+    got = np.asarray(Image.open(mine).convert("RGB"))
+    assert got.shape == (480, 640, 3) and got.min() < 128  # something was drawn
+    plot(str(tmp_path / "empty.png"), {})  # first epoch of a run that has no entries yet: no exception
+    ref_src = "/root/reference/robosat/utils.py"
+    if os.path.exists(ref_src):
+        spec = importlib.util.spec_from_file_location("reference_utils", ref_src)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        theirs = str(tmp_path / "theirs.png")
+        ref.plot(theirs, history)
+        assert np.array_equal(got, np.asarray(Image.open(theirs).convert("RGB")))

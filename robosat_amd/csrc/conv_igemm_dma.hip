@@ -375,6 +375,12 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
     if (epi == EPI_STATS && (residual || relu_mask)) return RS_EINVAL;
     if (epi == EPI_BWD && (!bn_mean || !bn_invstd)) return RS_EINVAL;
   }
+  if constexpr (sizeof(T) == 4) {
+    // measurement candidate (conv1x1_ew_f32.hip): the epilogue of an fp32 1x1 launch on its own waves; never taken unless asked for
+    const char* ew = getenv("RS_CONV1X1_EW");
+    if (ew && ew[0] == '1' && epi == EPI_EVAL && !phase4 && !relu_mask && !out2 && !mask_bits && rs_conv1x1_ew_f32_ok(d))
+      return rs_conv1x1_ew_f32_launch(a, (hipStream_t)stream);
+  }
   if constexpr (sizeof(T) == 2) {
     int bn = 0, bm = 256;
     const int hm = halo_mode(d, phase4, out2 ? csplit : 0, &bn, &bm);

@@ -74,6 +74,9 @@ RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo33, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_phase, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_dg4, bf16_t);
 __attribute__((visibility("hidden"))) void rs_conv_launch_bf16_halo_phase_ko(int ko, int grid, hipStream_t s, const ConvArgsT<bf16_t>& a);
+// conv1x1_ew_f32.hip: fp32 1x1 / stride-1 launches with the epilogue on its own waves (measurement candidate, RS_CONV1X1_EW=1)
+__attribute__((visibility("hidden"))) int rs_conv1x1_ew_f32_ok(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) int rs_conv1x1_ew_f32_launch(const ConvArgsT<float>& a, hipStream_t s);
 
 #ifdef RS_CONV_INSTANTIATE  // ---- kernel + launcher body: only in the instantiating translation units --------------------
 namespace {

@@ -720,3 +720,29 @@ def test_winograd_3x3_declines_what_it_cannot_run():
     assert not ops.wino33_ok(torch.zeros(4, 32, 32, 16, device=DEV), 64)        # one chunk only
     assert not ops.wino33_ok(torch.zeros(4, 32, 32, 64, device=DEV, dtype=BF), 64)
     assert ops.wino33_ok(torch.zeros(1, 16, 16, 64, device=DEV), 64) and ops.wino33_ok(torch.zeros(16, 16, 16, 64, device=DEV), 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [(2, 16, 16, 64, 256, True), (3, 17, 13, 32, 64, False), (2, 32, 32, 512, 128, True)])
+def test_epilogue_wave_1x1_kernel_is_bit_identical_to_the_generic_one(n, h, w, cin, cout, res, monkeypatch):
+    """conv1x1_ew_f32 (RS_CONV1X1_EW=1, a measurement candidate: main loop and epilogue of an fp32 1x1 launch on separate
+    waves of a persistent block) computes the generic kernel's K order and epilogue arithmetic: the same bits, ragged last
+    pixel tile included (reference: Bottleneck conv1 / conv3 with the folded eval-mode BatchNorm, unet.py:94,122-130)."""
+    from robosat_amd import ops
+
+    x = rnd(n, cin, h, w, seed=91)
+    wt = rnd(cout, cin, 1, 1, seed=92) * (1.0 / cin) ** 0.5
+    sc, sh = (torch.rand(cout) + 0.5).to(DEV), (rnd(cout, seed=93) * 0.1).to(DEV)
+    r = nhwc(rnd(n, cout, h, w, seed=94), torch.float32) if res else None
+    s, wk = nhwc(x, torch.float32), krsc(wt, torch.float32)
+    monkeypatch.delenv("RS_CONV1X1_EW", raising=False)
+    generic = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
+    monkeypatch.setenv("RS_CONV1X1_EW", "1")
+    ew = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("RS_CONV1X1_EW", raising=False)
+    assert torch.equal(ew, generic)
+    ref = F.conv2d(x, wt) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.cpu().permute(0, 3, 1, 2)
+    assert float((ew.cpu().permute(0, 3, 1, 2) - F.relu(ref)).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))

@@ -220,6 +220,13 @@ int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* 
  * its source halo is copied to LDS once per channel chunk and every filter tap reads it at a row offset.  rs_conv2d_config
  * reports them as tile 8 with the N tile (128 | 64, + 0x1000 for the 512-pixel patch) in *rowb. */
 int rs_conv2d_set_tuning(int tile, int rowb);
+/* The library's measurement / A-B switches by name (process-global; robosat_amd/csrc/knobs.hip lists them with the environment
+ * variable that seeds each ONCE, at the first use: "conv1x1_ew" <- RS_CONV1X1_EW, "conv_halo" <- RS_CONV_HALO,
+ * "wgrad_f32_phase" <- RS_WGRAD_F32_PHASE, ...).  No dispatcher reads the environment per launch: a workspace query and the
+ * launch it sizes always see the same settings.  rs_set_knob returns 0, or RS_EINVAL for an unknown name; rs_get_knob writes
+ * the current value.  No reference counterpart (torch.backends.cudnn.* flags are the closest). */
+int rs_set_knob(const char* name, int value);
+int rs_get_knob(const char* name, int* value);
 const char* rs_conv2d_tile_name_bf16(int tile);
 
 /* rs_conv2d_wgrad with bf16 dy / sources; dw is fp32 KRSC (the optimizer's master gradient). */

@@ -72,6 +72,8 @@ SIGNATURES = {
     "rs_conv2d_tile_bf16": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_config": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "rs_conv2d_set_tuning": (c_int, [c_int, c_int]),
+    "rs_set_knob": (c_int, [c_char_p, c_int]),
+    "rs_get_knob": (c_int, [c_char_p, POINTER(c_int)]),
     "rs_conv2d_tile_name_bf16": (c_char_p, [c_int]),
     "rs_conv2d_wgrad_bf16_workspace_bytes": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_wgrad_bf16_form": (c_int, [POINTER(ConvDesc)]),

@@ -109,19 +109,21 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ y
       }
     }
   }
+  // (component-major: red[component][thread] -- consecutive threads write consecutive 8-byte words; the thread-major layout
+  // of rounds 1-4 put all 64 lanes of a store on the same two banks: 76 % of this kernel's LDS cycles were conflicts)
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    red[tid * 2 * V + e] = s0[e];
-    red[tid * 2 * V + V + e] = s1[e];
+    red[e * 256 + tid] = s0[e];
+    red[(V + e) * 256 + tid] = s1[e];
   }
   __syncthreads();
   if (active && rl == 0) {
     for (int g = 1; g < rpb; ++g) {
-      const double* o = red + (g * qb + ql) * 2 * V;
+      const double* o = red + g * qb + ql;
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        s0[e] += o[e];
-        s1[e] += o[V + e];
+        s0[e] += o[e * 256];
+        s1[e] += o[(V + e) * 256];
       }
     }
     double* p0 = part + ((long)blockIdx.y * 2) * C + q * V;

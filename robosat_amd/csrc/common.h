@@ -152,6 +152,27 @@ __host__ __device__ __forceinline__ unsigned int rs_div(unsigned int n, const rs
 #endif
 }
 
+// knobs.hip (library-internal): the measurement / A-B switches of every dispatcher, seeded from the environment once and
+// changed afterwards only through rs_set_knob() -- no dispatcher calls getenv().  Unset = the measured rules.
+struct RsKnobs {
+  int conv_tile = -1;          // RS_CONV_TILE: forced implicit-GEMM tile index (rs_conv2d_set_tuning), -1 = heuristics
+  int conv_rowb = 0;           // RS_CONV_ROWB: forced K-chunk row bytes (64 | 128), 0 = heuristics
+  int conv_big = 1;            // RS_CONV_BIG: the 8-wave 256x256 tile allowed (bf16, no fused statistics)
+  int conv_min256 = 384;       // RS_CONV_MIN256: ... for launches with at least this many 256x256 blocks
+  int conv_halo = 1;           // RS_CONV_HALO: halo-once forms allowed (bf16)
+  int conv_halo_min = 192;     // RS_CONV_HALO_MIN: ... for launches with at least this many blocks
+  int conv_halo512 = -1;       // RS_CONV_HALO512: the 512-pixel patch: -1 by rule, 0 never, 1 wherever it can run
+  int conv1x1_ew = -1;         // RS_CONV1X1_EW: conv1x1_ew_f32 -- -1 by rule (K <= 64), 0 never, 1 wherever it can run
+  int conv1x1_ew_bf16 = 0;     // RS_CONV1X1_EW_BF16: conv1x1_ew_bf16 (train-mode 1x1 forward) -- 0 never, 1 wherever it can run
+  int halo_ko = 0;             // RS_HALO_KO: knock-out variant of the halo kernel (`make KO=1` builds only)
+  int wgrad_f32_phase = 1;     // RS_WGRAD_F32_PHASE: fp32 DecoderBlock weight gradient in phase form (0: direct form)
+  int wgrad_f32_dma = -1;      // RS_WGRAD_F32_DMA: fp32 weight gradient by LDS-DMA (conv_wgrad_f32_dma.hip): -1 by rule, 0 never, 1 wherever it can run
+  int wgrad_blocks = 256;      // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches
+  int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
+  int wino_wide = 1;           // ROBOSAT_WINO_WIDE: the 128 x 64 block of the fp32 Winograd DecoderBlock kernel
+};
+__attribute__((visibility("hidden"))) RsKnobs& rs_knobs();
+
 // conv_wgrad_thin_bf16.hip (library-internal): all-taps-per-block weight gradient of the Cout = 32 3x3 layers.
 // plan: 1 if `d` qualifies (+ grid size and number of fp32 partial slices [32][9*Cin] it writes); launch: the kernel.
 __attribute__((visibility("hidden"))) int rs_wgrad_thin_plan(const rs_conv_desc* d, int* blocks, int* slices);

@@ -297,8 +297,12 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM, T256x128, NTILES };
-const char* const kTileNames[NTILES] = {"conv_igemm_f32<128x128>", "conv_igemm_f32<128x64>", "conv_igemm_f32<128x32>",
-                                        "conv_igemm_f32<64x64>", "conv_igemm_f32<128x64,stem>", "conv_igemm_f32<256x128>"};
+// (report names by tile index; 6..8 are bf16-only kernels of conv_igemm_dma.hip's table, 9 = conv1x1_ew_f32.hip: the fp32 1x1
+// kernel with the epilogue on its own waves)
+constexpr int kNamedTiles = 10;
+const char* const kTileNames[kNamedTiles] = {"conv_igemm_f32<128x128>", "conv_igemm_f32<128x64>", "conv_igemm_f32<128x32>",
+                                             "conv_igemm_f32<64x64>", "conv_igemm_f32<128x64,stem>", "conv_igemm_f32<256x128>",
+                                             "", "", "", "conv1x1_ew_f32<128x64>"};
 const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256};
 const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128};
 
@@ -337,7 +341,7 @@ extern "C" int rs_conv2d_tile(const rs_conv_desc* d) {
   return d->stem ? (int)TSTEM : rs_conv_dma_tile(d);  // same index order as kTileNames
 }
 
-extern "C" const char* rs_conv2d_tile_name(int tile) { return (tile >= 0 && tile < NTILES) ? kTileNames[tile] : ""; }
+extern "C" const char* rs_conv2d_tile_name(int tile) { return (tile >= 0 && tile < kNamedTiles) ? kTileNames[tile] : ""; }
 
 extern "C" int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const float* src2, const float* weight,
                              const float* scale, const float* shift, const float* residual, const float* relu_mask,

@@ -102,35 +102,19 @@ extern "C" int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int to
 
 const char* const kTileNamesBf16[NTILES] = {"conv_igemm_bf16<128x128>", "conv_igemm_bf16<128x64>", "conv_igemm_bf16<128x32>",
                                             "conv_igemm_bf16<64x64>", "", "conv_igemm_bf16<256x128>",
-                                            "conv_igemm_bf16<256x256>", "conv_thin_bf16", "conv_halo_bf16"};
-const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 128, 256};
-const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 32, 128};
+                                            "conv_igemm_bf16<256x256>", "conv_thin_bf16", "conv_halo_bf16", "conv1x1_ew_bf16<128x128>"};
+const int kTileBM[NTILES] = {128, 128, 128, 64, 128, 256, 256, 128, 256, 128};
+const int kTileBN[NTILES] = {128, 64, 32, 64, 64, 128, 256, 32, 128, 64};
 
-// Dispatcher overrides (rs_conv2d_set_tuning): process-global, for the parity tests (which must reach every tile with
-// small problems) and for A/B measurements.  -1 / 0 = the measured heuristics below.  Initialised from the environment
-// (RS_CONV_TILE, RS_CONV_ROWB, RS_CONV_BIG) so that a whole benchmark run can be steered from outside.
+// Dispatcher overrides: the process-global knob table of knobs.hip (rs_set_knob / rs_conv2d_set_tuning; seeded from the
+// environment ONCE -- RS_CONV_TILE, RS_CONV_ROWB, RS_CONV_BIG, ... -- so that a whole benchmark run can be steered from
+// outside), for the parity tests (which must reach every tile with small problems) and for A/B measurements.
 struct Tuning {
-  int tile = -1;  // forced tile index, honoured whenever the launch can run it
-  int rowb = 0;   // forced K-chunk row bytes: 64 | 128
-  int big = 1;    // 8-wave 256x256 tile allowed (bf16, no fused statistics)
-  int min256 = 384;  // ... for launches with at least this many 256x256 blocks
-  int halo = 1;      // halo-once forms allowed (bf16; RS_CONV_HALO=0: the implicit-GEMM kernel everywhere, for A/B runs)
-  int halo_min = 192;  // ... for launches with at least this many blocks
-  int halo512 = -1;    // unforced launches: the 512-pixel patch -- -1 by the rule in halo_mode, 0 never, 1 wherever it can run (RS_CONV_HALO512)
+  int tile, rowb, big, min256, halo, halo_min, halo512;
 };
-Tuning& tuning() {
-  static Tuning t = [] {
-    Tuning v;
-    if (const char* e = getenv("RS_CONV_TILE")) v.tile = atoi(e);
-    if (const char* e = getenv("RS_CONV_ROWB")) v.rowb = atoi(e);
-    if (const char* e = getenv("RS_CONV_BIG")) v.big = atoi(e);
-    if (const char* e = getenv("RS_CONV_MIN256")) v.min256 = atoi(e);
-    if (const char* e = getenv("RS_CONV_HALO")) v.halo = atoi(e);
-    if (const char* e = getenv("RS_CONV_HALO_MIN")) v.halo_min = atoi(e);
-    if (const char* e = getenv("RS_CONV_HALO512")) v.halo512 = atoi(e);
-    return v;
-  }();
-  return t;
+Tuning tuning() {
+  const RsKnobs& k = rs_knobs();
+  return {k.conv_tile, k.conv_rowb, k.conv_big, k.conv_min256, k.conv_halo, k.conv_halo_min, k.conv_halo512};
 }
 
 bool valid(const rs_conv_desc* d) {
@@ -150,11 +134,11 @@ bool phase_ok(const rs_conv_desc* d) {
 int pick_tile(const rs_conv_desc* d, bool phase4 = false, int es = 4, bool stats = false) {
   const long M = phase4 ? (long)d->N * d->Hs * d->Ws * 4 : (long)d->N * d->Ho * d->Wo;  // (x4: the phases share the grid)
   const long want = 512;  // >= 2 blocks per CU
-  const Tuning& tu = tuning();
+  const Tuning tu = tuning();
   const int ft = tu.tile;
   // a forced tile must be able to run the launch: N tiles whole (or the ragged 128-wide form below), 8 waves only in bf16
   // without fused statistics (the statistics' block reduction is laid out for 256 threads)
-  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && ft != TTHIN && ft != THALO && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
+  if (ft >= 0 && ft < NTILES && ft != TSTEM_RESERVED && ft != TTHIN && ft != THALO && ft != TEW && (d->Cout % kTileBN[ft] == 0 || (ft == T128x128 && d->Cout > 128)) &&
       (ft != T256x256 || (es == 2 && !stats)))
     return ft;
   // 8-wave 256x256 tile (bf16, no fused statistics; one block per CU): half the LDS-DMA bytes per MFMA of the 128x128 tile,
@@ -239,8 +223,10 @@ int thin_mode(const rs_conv_desc* d, bool phase4, bool plain_epilogue) {
 // batch size beyond "enough blocks to fill the chip" -- : the rows of a block are an 8 x 32 patch of the grid they enumerate,
 // so that grid must tile into such patches; K-chunks are 128-byte rows.  A forced implicit-GEMM tile
 // (rs_conv2d_set_tuning) keeps the generic kernel; forcing THALO takes the halo form wherever it can run.
-int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out, int* bm_out = nullptr) {
-  const Tuning& tu = tuning();
+// `epi`: the launch's epilogue kind -- only the 3x3 form carries the statistics / into-BatchNorm epilogues (HALO_PHASE and
+// HALO_DG4 are instantiated for EPI_EVAL alone: a launch with fused statistics keeps the implicit-GEMM kernel there).
+int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int epi, int* bn_out, int* bm_out = nullptr) {
+  const Tuning tu = tuning();
   if (!tu.halo || (tu.tile != -1 && tu.tile != THALO)) return HALO_NONE;
   // patch of 512 pixels (16 x 32) with 32-channel chunks, or of 256 (8 x 32) with 64-channel chunks
   bool big = tu.tile == THALO ? tu.rowb == 64 : tu.halo512 != 0;  // (unforced + auto: decided below, once the grid is known)
@@ -262,6 +248,7 @@ int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out, int* 
   } else {
     return HALO_NONE;
   }
+  if (mode != HALO_33 && epi != EPI_EVAL) return HALO_NONE;
   // unforced: the 512-pixel patch (2/3 of the DMA bytes and 3/4 of the fragment reads per MFMA) where there is at least one
   // such patch per CU -- layer2's conv2 (-17 % against the implicit GEMM; the 256-pixel patch: -7 %), dec3 forward and data
   // gradient (-16 %; -10 %); with fewer patches (layer3, dec1: 64) the 256-pixel patch or the 8-wave tile win
@@ -288,6 +275,14 @@ int halo_mode(const rs_conv_desc* d, bool phase4, int csplit, int* bn_out, int* 
   if (bn_out) *bn_out = bn;
   if (bm_out) *bm_out = ph * 32;
   return mode;
+}
+
+// fp32 1x1 launches that take conv1x1_ew_f32.hip (main loop and epilogue on separate waves of a persistent block; bit-identical
+// to the generic kernel).  By rule (knob -1) where it was measured to win: K <= 64 -- layer1's HBM-bound launches, x 1.12-1.15
+// (profiles/r04/ew_1x1.txt) -- geometry only, never the batch size.  A forced implicit-GEMM tile keeps the generic kernel.
+bool ew_f32_mode(const rs_conv_desc* d, bool phase4, bool plain) {
+  const int ew = rs_knobs().conv1x1_ew;
+  return ew != 0 && tuning().tile < 0 && !phase4 && plain && rs_conv1x1_ew_f32_ok(d) && (ew > 0 || d->C1 <= 64);
 }
 
 template <typename T>
@@ -376,14 +371,11 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
     if (epi == EPI_BWD && (!bn_mean || !bn_invstd)) return RS_EINVAL;
   }
   if constexpr (sizeof(T) == 4) {
-    // measurement candidate (conv1x1_ew_f32.hip): the epilogue of an fp32 1x1 launch on its own waves; never taken unless asked for
-    const char* ew = getenv("RS_CONV1X1_EW");
-    if (ew && ew[0] == '1' && epi == EPI_EVAL && !phase4 && !relu_mask && !out2 && !mask_bits && rs_conv1x1_ew_f32_ok(d))
-      return rs_conv1x1_ew_f32_launch(a, (hipStream_t)stream);
+    if (ew_f32_mode(d, phase4, epi == EPI_EVAL && !relu_mask && !out2 && !mask_bits)) return rs_conv1x1_ew_f32_launch(a, (hipStream_t)stream);
   }
   if constexpr (sizeof(T) == 2) {
     int bn = 0, bm = 256;
-    const int hm = halo_mode(d, phase4, out2 ? csplit : 0, &bn, &bm);
+    const int hm = halo_mode(d, phase4, out2 ? csplit : 0, epi, &bn, &bm);
     if (hm != HALO_NONE) {
       const int gh = hm == HALO_PHASE ? d->Hs : d->Ho, gw = hm == HALO_PHASE ? d->Ws : d->Wo;
       const int ctot = d->C1 + d->C2;
@@ -398,7 +390,7 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
       if (bm == 512) bn |= 0x1000;
       if (hm == HALO_33) rs_conv_launch_bf16_halo33(bn, epi, grid, hs, a);
 #ifdef RS_HALO_KO_BUILD  // (`make KO=1`: the knock-out instantiations of conv_halo_ko.hip, measurement only -- not in the default library)
-      else if (hm == HALO_PHASE && bn == 128 && getenv("RS_HALO_KO")) rs_conv_launch_bf16_halo_phase_ko(atoi(getenv("RS_HALO_KO")), grid, hs, a);
+      else if (hm == HALO_PHASE && bn == 128 && rs_knobs().halo_ko) rs_conv_launch_bf16_halo_phase_ko(rs_knobs().halo_ko, grid, hs, a);
 #endif
       else if (hm == HALO_PHASE) rs_conv_launch_bf16_halo_phase(bn, 0, grid, hs, a);
       else rs_conv_launch_bf16_halo_dg4(bn, 0, grid, hs, a);
@@ -407,6 +399,13 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   }
 
   const int tile = pick_tile(d, phase4, (int)ES, stats != nullptr);
+  if constexpr (sizeof(T) == 2) {
+    // conv1x1_ew_bf16.hip (train-mode 1x1 forward, statistics epilogue on its own waves); its partial rows are per 128-pixel
+    // tile, as the generic 128-row tiles'
+    if (rs_knobs().conv1x1_ew_bf16 > 0 && tuning().tile < 0 && epi == EPI_STATS && !phase4 && kTileBM[tile] == 128 &&
+        rs_conv1x1_ew_bf16_stats_ok(d))
+      return rs_conv1x1_ew_bf16_stats_launch(a, (hipStream_t)stream);
+  }
   if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
   a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);
@@ -426,9 +425,9 @@ int rs_conv_dma_f32(const rs_conv_desc* d, const float* src1, const float* src2,
 int rs_conv_dma_tile(const rs_conv_desc* d) { return valid(d) ? pick_tile(d) : RS_EINVAL; }
 
 extern "C" int rs_conv2d_set_tuning(int tile, int rowb) {
-  if (tile < -1 || tile >= NTILES || tile == TSTEM_RESERVED || (rowb != 0 && rowb != 64 && rowb != 128)) return RS_EINVAL;
-  tuning().tile = tile;
-  tuning().rowb = rowb;
+  if (tile < -1 || tile >= NTILES || tile == TSTEM_RESERVED || tile == TEW || (rowb != 0 && rowb != 64 && rowb != 128)) return RS_EINVAL;
+  rs_knobs().conv_tile = tile;
+  rs_knobs().conv_rowb = rowb;
   return 0;
 }
 
@@ -445,11 +444,16 @@ extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* 
   }
   if (es == 2) {  // halo-once forms: reported as THALO with the N tile in `rowb` (the K-chunk rows are always 128 bytes)
     int bn = 0, bm = 256;
-    if (halo_mode(d, phase4 != 0, 0, &bn, &bm) != HALO_NONE) {
+    if (halo_mode(d, phase4 != 0, 0, EPI_EVAL, &bn, &bm) != HALO_NONE) {
       if (tile) *tile = THALO;
       if (rowb) *rowb = bn | (bm == 512 ? 0x1000 : 0);  // (N tile; + 0x1000: the 512-pixel patch)
       return 0;
     }
+  }
+  if (es == 4 && ew_f32_mode(d, phase4 != 0, true)) {  // (as for a launch with a plain eval epilogue)
+    if (tile) *tile = TEW;
+    if (rowb) *rowb = 64;
+    return 0;
   }
   if (tile) *tile = pick_tile(d, phase4 != 0, es);
   if (rowb) *rowb = (can128 && pick_rowb(d, es, phase4 != 0) == 128) ? 128 : 64;
@@ -591,7 +595,7 @@ extern "C" long rs_conv2d_bnstats_rows(const rs_conv_desc* d) {
 extern "C" long rs_conv2d_bnstats_rows_dt(const rs_conv_desc* d, int dtype) {
   if (!valid(d) || (dtype != RS_F32 && dtype != RS_BF16)) return RS_EINVAL;
   int bn = 0, bm = 256;
-  if (dtype == RS_BF16 && halo_mode(d, false, 0, &bn, &bm) != HALO_NONE) return (long)d->N * (d->Ho / (bm / 32)) * (d->Wo / 32);  // one row per patch
+  if (dtype == RS_BF16 && halo_mode(d, false, 0, EPI_STATS, &bn, &bm) != HALO_NONE) return (long)d->N * (d->Ho / (bm / 32)) * (d->Wo / 32);  // one row per patch
   return rs_conv2d_bnstats_rows(d);
 }
 

@@ -17,7 +17,8 @@ constexpr int kMaxK = 4;  // filter height / width up to 4 (the 4x4 stride-2 dat
 // TTHIN: the all-taps kernels of conv_thin_bf16.hip (the 32-channel decoder tail in bf16), reported through the same index space
 // THALO: the halo-once forms of this kernel (HALO template parameter below; bf16, 8 waves, a 2-D patch of 8 x 32 pixels
 // per block), reported through the same index space
-enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, TTHIN, THALO, NTILES };
+// TEW: conv1x1_ew_f32.hip (fp32 1x1 launches with the epilogue on its own waves), reported through the same index space
+enum Tile { T128x128 = 0, T128x64, T128x32, T64x64, TSTEM_RESERVED, T256x128, T256x256, TTHIN, THALO, TEW, NTILES };
 // HALO forms: the block's rows are a 2-D PATCH of the output grid; per K-group (one 128-byte channel chunk of one source
 // plane) the patch's source HALO lands in LDS once and every filter tap reads it at a row offset -- the implicit-GEMM
 // form above fetches each source pixel once per tap.  HALO_33: 3x3 / stride 1 / pad 1 (9 taps);  HALO_PHASE: one output
@@ -74,9 +75,12 @@ RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo33, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_phase, bf16_t);
 RS_CONV_LAUNCHER(rs_conv_launch_bf16_halo_dg4, bf16_t);
 __attribute__((visibility("hidden"))) void rs_conv_launch_bf16_halo_phase_ko(int ko, int grid, hipStream_t s, const ConvArgsT<bf16_t>& a);
-// conv1x1_ew_f32.hip: fp32 1x1 / stride-1 launches with the epilogue on its own waves (measurement candidate, RS_CONV1X1_EW=1)
+// conv1x1_ew_f32.hip: fp32 1x1 / stride-1 launches with the epilogue on its own waves (knob conv1x1_ew: by rule K <= 64)
 __attribute__((visibility("hidden"))) int rs_conv1x1_ew_f32_ok(const rs_conv_desc* d);
 __attribute__((visibility("hidden"))) int rs_conv1x1_ew_f32_launch(const ConvArgsT<float>& a, hipStream_t s);
+// conv1x1_ew_bf16.hip: the train-mode forward's bf16 1x1 launches (statistics epilogue) in the same layout (knob conv1x1_ew_bf16)
+__attribute__((visibility("hidden"))) int rs_conv1x1_ew_bf16_stats_ok(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) int rs_conv1x1_ew_bf16_stats_launch(const ConvArgsT<bf16_t>& a, hipStream_t s);
 
 #ifdef RS_CONV_INSTANTIATE  // ---- kernel + launcher body: only in the instantiating translation units --------------------
 namespace {

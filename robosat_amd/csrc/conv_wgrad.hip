@@ -316,7 +316,7 @@ struct Plan {
 
 bool phase_ok(const rs_conv_desc* d) {
   return !d->stem && d->ups == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Ho == 2 * d->Hs &&
-         d->Wo == 2 * d->Ws && getenv("RS_WGRAD_F32_PHASE") == nullptr;  // (RS_WGRAD_F32_PHASE=0: the direct form, for A/B runs)
+         d->Wo == 2 * d->Ws && rs_knobs().wgrad_f32_phase != 0;  // (knob wgrad_f32_phase / RS_WGRAD_F32_PHASE=0: the direct form, for A/B runs)
 }
 
 enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32, VSTEM };

@@ -413,21 +413,13 @@ Plan plan(const rs_conv_desc* d) {
   pl.pk = 64;  // pixels per chunk (32 was measured for the short reductions: no gain)
   const int PK = pl.pk;
   const long chunks = (M + PK - 1) / PK;
-  // blocks a launch aims at (RS_WGRAD_BLOCKS / RS_WGRAD_BLOCKS_PHASE: measurement knobs).  Measured on the bf16 bs-32 step
+  // blocks a launch aims at (knobs wgrad_blocks / wgrad_blocks_phase, seeded by RS_WGRAD_BLOCKS / RS_WGRAD_BLOCKS_PHASE).  Measured on the bf16 bs-32 step
   // (scripts/wgrad_blocks_ab.sh; step time, not kernel time, is what counts: these launches run on the side stream BESIDE
   // the data-gradient chain).  The tap-per-block launches of the encoder: in isolation they are fastest at 512 blocks (a
   // block is prologue + few chunks + a 64 KB partial tile, and every extra split is another partial to write and reduce),
   // but one block per CU (256) leaves room for the main stream's kernels and gives the shortest step (25.3-25.4 ms vs 25.6
   // at 512 and 26.1 at the former 1024).  The phase form's 16-tap launches are long reductions and want more, shorter blocks.
-  static const long target_plain = [] {
-    const char* e = getenv("RS_WGRAD_BLOCKS");
-    return e ? atol(e) : 256L;
-  }();
-  static const long target_phase = [] {
-    const char* e = getenv("RS_WGRAD_BLOCKS_PHASE");
-    return e ? atol(e) : 1536L;
-  }();
-  const long target = pl.phase ? target_phase : target_plain;
+  const long target = pl.phase ? rs_knobs().wgrad_blocks_phase : rs_knobs().wgrad_blocks;
   long s = (target + tiles - 1) / tiles;          // aim at >= `target` blocks ...
   const long smax = (chunks * PK / 64 + 7) / 8;   // ... of at least 512 pixels each
   if (s > smax) s = smax;

@@ -376,8 +376,7 @@ int wino_cus() {
 }
 
 bool wino_wide() {  // (A/B knob while the wide block is being measured: ROBOSAT_WINO_WIDE=0 keeps 64 tiles x 64 couts)
-  static const bool w = !(getenv("ROBOSAT_WINO_WIDE") && atoi(getenv("ROBOSAT_WINO_WIDE")) == 0);
-  return w;
+  return rs_knobs().wino_wide != 0;
 }
 
 struct WinoPlan {

@@ -113,22 +113,22 @@ def run_per_gpu(nprocs, args, module=None, script=None):
     return spawn_ranks(argv, nprocs)
 
 
-def check_ranks_fit_devices(world, device_count, backend, local_world=None, local_rank=None):
+def check_ranks_fit_devices(world, device_count, backend, local_world=None):
     """RCCL refuses two ranks on one device; say so before the communicator does (with a stack of C++ frames).
 
     What must fit is the NODE-LOCAL rank count (``LOCAL_WORLD_SIZE``, set by torchrun and by ``spawn_ranks``), not the job's
     world size: a 2-node job (WORLD_SIZE 16, 8 local GPUs) is fine, and so is a job that isolates one GPU per rank with
     ``HIP_VISIBLE_DEVICES`` (every rank sees ONE device and its LOCAL_RANK maps onto it: ``local % device_count`` below the
-    call sites).  Rejected: more local ranks than visible devices when the ranks can see more than one device (two of them
-    would resolve to the same index) -- and, with one visible device, only when nothing says the ranks were isolated."""
+    call sites).  Rejected: more local ranks than visible devices -- unless the launcher STATES that it gave every rank a device
+    of its own (``ROBOSAT_RANK_ISOLATED=1`` next to a per-rank ``HIP_VISIBLE_DEVICES``).  A single-entry
+    ``HIP_VISIBLE_DEVICES`` alone says nothing: exported globally on a 1-GPU box it is the same device for every rank, which
+    is exactly the RCCL failure this check exists to pre-empt."""
 
     if backend != "nccl":
         return
     device_count = max(1, device_count)
     if local_world is None:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    if local_rank is None:
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if local_world <= device_count:
         return
     if device_count == 1 and _one_device_per_rank():
@@ -138,9 +138,11 @@ def check_ranks_fit_devices(world, device_count, backend, local_world=None, loca
 
 
 def _one_device_per_rank():
-    """Whether this rank's single visible device was picked FOR it (a per-rank ``HIP_VISIBLE_DEVICES`` /
-    ``ROCR_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` naming exactly one device): the launcher isolated the GPUs."""
+    """Whether the launcher states that this rank's single visible device was picked FOR it: ``ROBOSAT_RANK_ISOLATED=1``
+    together with a ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` naming exactly one device."""
 
+    if os.environ.get("ROBOSAT_RANK_ISOLATED", "0") != "1":
+        return False
     for key in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(key, "").strip()
         if v and len([x for x in v.split(",") if x.strip()]) == 1:

@@ -114,7 +114,7 @@ def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=No
     check(rc, "rs_conv2d_fwd_bf16" if bf else "rs_conv2d_fwd")
     if PROFILE is not None:
         ev1.record()
-        name = conv_tile_name(d, bf)
+        name = conv_tile_name(d, bf, plain=relu_mask is None)
         if alg_scale != 1.0 and not name.startswith(("conv_thin", "conv_halo")):  # phase-form data gradient: 16 taps at source resolution stand for 9 at the upsampled one
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
@@ -145,19 +145,19 @@ def conv2d_bnstats(src1, weight, src2=None, ups=0, stride=1, pad=0):
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+        _record(conv_tile_name(d, bf, plain=False), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                         conv_bytes(d, 2 if bf else 4))
     return out, partial
 
 
 def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0, residual=None, relu_mask=None,
-                         relu_mask_bits=None):
+                         relu_mask_bits=None, stride=1):
     """Data-gradient convolution whose output g is the gradient at a BatchNorm+ReLU output: ``rs_conv2d_fwd`` semantics
     (``wd`` = packed dgrad weights, optional residual, relu_mask = z) + per-tile partial sums of BatchNorm's two backward
     reductions (``rs_conv2d_dgrad_bnstats_dt``).  ``relu_mask_bits`` (from ``bn_apply(..., want_bits=True)``) replaces
     ``relu_mask`` by one bit per element (``rs_conv2d_dgrad_bnstats_bits_dt``).  Returns (g, partial [tiles,2,C])."""
 
-    d = conv_desc(dy, wd, None, ups, 1, pad, False, 0, out_hw)
+    d = conv_desc(dy, wd, None, ups, stride, pad, False, 0, out_hw)
     act = dy.dtype
     lib = _lib.lib()
     out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=dy.device, dtype=act)
@@ -185,7 +185,7 @@ def conv2d_dgrad_bnstats(dy, wd, out_hw, bn_y, bn_mean, bn_invstd, ups=0, pad=0,
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        _record(conv_tile_name(d, bf), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+        _record(conv_tile_name(d, bf, plain=False), conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                         conv_bytes(d, 2 if bf else 4, 1 + (residual is not None) + (relu_mask is not None))
                         + (out.numel() // 8 if relu_mask_bits is not None else 0))
     return out, partial
@@ -271,7 +271,7 @@ def conv2d_split(src, weight, c1, stride=1, pad=0, out_hw=None, mask1=None, mask
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        name = conv_tile_name(d, bf)
+        name = conv_tile_name(d, bf, plain=relu_mask is None)
         if alg_scale != 1.0 and not name.startswith("conv_halo"):
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
@@ -480,11 +480,15 @@ def conv2d_wino33_head(src, u, final_w, final_b, mode="logits", overlap=0, relu=
     return out if m <= 1 else qout
 
 
-def conv_tile_name(d, bf16=False, phase=False):
+def conv_tile_name(d, bf16=False, phase=False, plain=True):
     """Report name of the kernel a convolution launch runs, 1:1 with the launched symbol:
-    ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel)."""
+    ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel).  ``plain=False``: a launch with fused
+    BatchNorm statistics / a ReLU mask (never the plain-epilogue 1x1 kernel of conv1x1_ew_f32.hip)."""
 
     lib = _lib.lib()
+    if not plain and not bf16 and not d.stem:
+        with knob("conv1x1_ew", 0):
+            return conv_tile_name(d, bf16, phase)
     if d.stem:
         return lib.rs_conv2d_tile_name(lib.rs_conv2d_tile(ctypes.byref(d))).decode()
     tile, rowb = ctypes.c_int(0), ctypes.c_int(0)
@@ -516,6 +520,37 @@ class tuning:
 
     def __exit__(self, *exc):
         check(_lib.lib().rs_conv2d_set_tuning(-1, 0), "rs_conv2d_set_tuning")
+        return False
+
+
+def get_knob(name):
+    """Current value of one of the library's measurement switches (``rs_get_knob``; the table is in csrc/knobs.hip)."""
+
+    v = ctypes.c_int(0)
+    check(_lib.lib().rs_get_knob(name.encode(), ctypes.byref(v)), "rs_get_knob({})".format(name))
+    return v.value
+
+
+def set_knob(name, value):
+    """``rs_set_knob`` (process-global; prefer ``with ops.knob(...)`` where the old value should come back)."""
+
+    check(_lib.lib().rs_set_knob(name.encode(), int(value)), "rs_set_knob({})".format(name))
+
+
+class knob:
+    """``with ops.knob("conv1x1_ew", 0): ...`` -- set a measurement switch of the library (``rs_set_knob``) for the launches
+    inside and restore it on exit.  Process-global, like ``ops.tuning``: for tests and A/B scripts, not a tuning API."""
+
+    def __init__(self, name, value):
+        self.name, self.value, self.old = name, int(value), None
+
+    def __enter__(self):
+        self.old = get_knob(self.name)
+        check(_lib.lib().rs_set_knob(self.name.encode(), self.value), "rs_set_knob({})".format(self.name))
+        return self
+
+    def __exit__(self, *exc):
+        check(_lib.lib().rs_set_knob(self.name.encode(), self.old), "rs_set_knob({})".format(self.name))
         return False
 
 
@@ -805,9 +840,7 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
         form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d)) if bf else 0
         if not bf and not stem and ups == 1 and (kh, kw, stride, pad) == (3, 3, 1, 1):
-            import os
-
-            form = 2 if os.environ.get("RS_WGRAD_F32_PHASE") is None else 0  # conv_wgrad.hip: the fp32 phase form (16 / 36 of the MACs)
+            form = 2 if get_knob("wgrad_f32_phase") else 0  # conv_wgrad.hip: the fp32 phase form (16 / 36 of the MACs)
         name = wgrad_kernel_name(d, form) if bf else "conv_wgrad_f32"
         _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes,
                 conv_flops(d) * (4.0 / 9.0 if form == 2 else 1.0))

@@ -112,14 +112,8 @@ class GradReducer:
             # dividing afterwards loses mantissa to the larger partial sums and overflows earlier
             wire = ops.cast_bf16_scaled(flat, 1.0 / self.world)
             work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            if self.backend == "nccl":
-                # `wire` was allocated under the current (side) stream and is consumed on RCCL's communicator stream:
-                # ProcessGroupNCCL records that itself unless TORCH_NCCL_AVOID_RECORD_STREAMS=1 -- then the reference kept in
-                # _pending until the cast back is what holds the memory; say it explicitly as well
-                try:
-                    wire.record_stream(torch.cuda.current_stream(wire.device))
-                except RuntimeError:
-                    pass
+            # (`wire` is consumed on RCCL's communicator stream; the reference held in _pending until wait() has cast it back
+            # is what keeps its memory from being recycled)
             self._pending.append((work, flat, wire))
         elif self.backend == "nccl":
             work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)

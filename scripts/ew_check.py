@@ -14,12 +14,12 @@ dev = torch.device("cuda:0")
 
 def run(x, w, sc, sh, res, relu, ew):
     if ew:
-        os.environ["RS_CONV1X1_EW"] = "1"
+        ops.set_knob("conv1x1_ew", 1)
     else:
-        os.environ.pop("RS_CONV1X1_EW", None)
+        ops.set_knob("conv1x1_ew", 0)
     y = ops.conv2d(x, w, pad=0, scale=sc, shift=sh, residual=res, relu=relu)
     torch.cuda.synchronize()
-    os.environ.pop("RS_CONV1X1_EW", None)
+    ops.set_knob("conv1x1_ew", -1)
     return y
 
 
@@ -70,9 +70,9 @@ for cin, hw, cout, use_res in layers:
     t = {}
     for ew in (False, True, False, True):
         if ew:
-            os.environ["RS_CONV1X1_EW"] = "1"
+            ops.set_knob("conv1x1_ew", 1)
         else:
-            os.environ.pop("RS_CONV1X1_EW", None)
+            ops.set_knob("conv1x1_ew", 0)
         for i in range(3):
             ops.conv2d(xs[i % nb], wd, pad=0, scale=sc, shift=sh, residual=rs[i % nb], relu=True, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,6 +82,6 @@ for cin, hw, cout, use_res in layers:
         e1.record()
         torch.cuda.synchronize()
         t.setdefault(ew, []).append(e0.elapsed_time(e1) / 24 * 1e3)
-    os.environ.pop("RS_CONV1X1_EW", None)
+    ops.set_knob("conv1x1_ew", -1)
     print("{:>5d} -> {:<5d} at {:>3d}^2 res={:d}   generic {:7.1f} {:7.1f} us   ew {:7.1f} {:7.1f} us   x{:.2f}".format(
         cin, cout, hw, use_res, t[False][0], t[False][1], t[True][0], t[True][1], min(t[False]) / min(t[True])))

@@ -37,6 +37,8 @@ for _dt in ("f32", "bf16"):
 # non-implicit-GEMM symbols of the step have their own parity tests (test_gpu_ops / test_gpu_train_ops / test_gpu_bf16)
 COVERED |= {"conv_thin_bf16<3x3>", "conv_thin_bf16<phase>", "conv_thin_bf16<dgrad4x4>"}  # test_thin_* below
 COVERED |= {"conv_igemm_f32<128x64,stem>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_f32"}
+# fp32 1x1 launches with K <= 64 (layer1) take the epilogue-wave kernel by rule: test_epilogue_wave_1x1_kernel_* below
+COVERED |= {"conv1x1_ew_f32<128x64,r64>"}
 # all-taps weight gradient: per input-channel slab, with / without the fused upsample (test_wgrad_bf16 "thin_*" cases assert the
 # names; test_wgrad_bf16_thin_upsample runs the ",ups" forms)
 COVERED |= {"conv_wgrad_thin_bf16<{}>".format(t) for t in ("32", "64", "128", "32,ups", "64,ups", "128,ups")}
@@ -293,6 +295,45 @@ def _halo_name(d, phase=False):
     name = ops.conv_tile_name(d, True, phase=phase)
     assert name in COVERED, name
     return name
+
+
+def test_fused_statistics_on_a_4x4_stride2_bf16_launch_keep_the_implicit_gemm_kernel():
+    """only the 3x3 halo form carries the statistics / into-BatchNorm epilogues.  A bf16 4x4 / stride-2 /
+    pad-1 launch of the data-gradient halo form's geometry that asks for fused BatchNorm statistics must therefore keep the
+    implicit-GEMM kernel -- and write every partial row it sized (rs_conv2d_bnstats_rows_dt and the launch agree)."""
+    from robosat_amd import ops
+
+    n, c, cout, hs = 12, 128, 128, 64  # unforced, >= 192 blocks of 8 x 32 output pixels: the plain launch takes the halo form
+    x = prep(rnd(n, c, hs, hs, seed=71), BF)
+    wt = prep(rnd(cout, c, 4, 4, seed=72) * (2.0 / (c * 16)) ** 0.5, BF)
+    xd, wd = nhwc(x, BF), krsc(wt, BF)
+    d = ops.conv_desc(xd, wd, stride=2, pad=1)
+    assert _halo_name(d) == "conv_halo_bf16<dgrad4x4,256x128>"  # (what a plain launch of this shape runs)
+    base = F.conv2d(x, wt, stride=2, padding=1)
+    close(nchw(ops.conv2d(xd, wd, stride=2, pad=1)), base, BF, "plain 4x4/s2 (halo form)")
+    y, partial = ops.conv2d_bnstats(xd, wd, stride=2, pad=1)
+    torch.cuda.synchronize()
+    assert partial.shape[0] == n * (hs // 2) * (hs // 2) // 128  # one row per 128-pixel implicit-GEMM tile
+    close(nchw(y), base, BF, "bnstats y")
+    yf = y.float()
+    s = partial.sum(0).cpu()
+    want0, want1 = yf.sum((0, 1, 2)).cpu(), (yf * yf).sum((0, 1, 2)).cpu()
+    assert torch.isfinite(partial).all()
+    assert float((s[0] - want0).abs().max()) <= 1e-3 * float(want0.abs().max() + 1)
+    assert float((s[1] - want1).abs().max()) <= 1e-3 * float(want1.abs().max() + 1)
+    # the into-BatchNorm epilogue on the same geometry
+    bn_y = prep(rnd(n, cout, hs // 2, hs // 2, seed=73), BF)
+    mean, invstd = rnd(cout, seed=74) * 0.1, rnd(cout, seed=75).abs() + 0.5
+    mask = prep(rnd(n, cout, hs // 2, hs // 2, seed=76), BF)
+    g, part = ops.conv2d_dgrad_bnstats(xd, wd, (hs // 2, hs // 2), nhwc(bn_y, BF), mean.to(DEV), invstd.to(DEV), pad=1,
+                                       relu_mask=nhwc(mask, BF), stride=2)
+    close(nchw(g), base * (mask > 0), BF, "dgrad-into-bn g on 4x4/s2")
+    gf = nchw(g)
+    xhat = (bn_y - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    ps = part.sum(0).cpu()
+    w0, w1 = gf.sum((0, 2, 3)), (gf * xhat).sum((0, 2, 3))
+    assert float((ps[0] - w0).abs().max()) <= 2e-3 * float(w0.abs().max() + 1)
+    assert float((ps[1] - w1).abs().max()) <= 2e-3 * float(w1.abs().max() + 1)
 
 
 @pytest.mark.parametrize("n,c,cout,h,w", [
@@ -724,10 +765,11 @@ def test_winograd_3x3_declines_what_it_cannot_run():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,h,w,cin,cout,res", [(2, 16, 16, 64, 256, True), (3, 17, 13, 32, 64, False), (2, 32, 32, 512, 128, True)])
-def test_epilogue_wave_1x1_kernel_is_bit_identical_to_the_generic_one(n, h, w, cin, cout, res, monkeypatch):
-    """conv1x1_ew_f32 (RS_CONV1X1_EW=1, a measurement candidate: main loop and epilogue of an fp32 1x1 launch on separate
-    waves of a persistent block) computes the generic kernel's K order and epilogue arithmetic: the same bits, ragged last
-    pixel tile included (reference: Bottleneck conv1 / conv3 with the folded eval-mode BatchNorm, unet.py:94,122-130)."""
+def test_epilogue_wave_1x1_kernel_is_bit_identical_to_the_generic_one(n, h, w, cin, cout, res):
+    """conv1x1_ew_f32 (main loop and epilogue of an fp32 1x1 launch on separate waves of a persistent block; dispatched by
+    rule for K <= 64, knob ``conv1x1_ew``) computes the generic kernel's K order and epilogue arithmetic: the same bits,
+    ragged last pixel tile included (reference: Bottleneck conv1 / conv3 with the folded eval-mode BatchNorm,
+    unet.py:94,122-130).  Also: the rule is geometry only (K <= 64 takes it, K = 512 does not) and the report name follows."""
     from robosat_amd import ops
 
     x = rnd(n, cin, h, w, seed=91)
@@ -735,12 +777,18 @@ def test_epilogue_wave_1x1_kernel_is_bit_identical_to_the_generic_one(n, h, w, c
     sc, sh = (torch.rand(cout) + 0.5).to(DEV), (rnd(cout, seed=93) * 0.1).to(DEV)
     r = nhwc(rnd(n, cout, h, w, seed=94), torch.float32) if res else None
     s, wk = nhwc(x, torch.float32), krsc(wt, torch.float32)
-    monkeypatch.delenv("RS_CONV1X1_EW", raising=False)
-    generic = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
-    monkeypatch.setenv("RS_CONV1X1_EW", "1")
-    ew = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
+    d = ops.conv_desc(s, wk, pad=0)
+    assert ops.get_knob("conv1x1_ew") == -1  # the shipped setting: by rule
+    assert (ops.conv_tile_name(d) == "conv1x1_ew_f32<128x64,r64>") == (cin <= 64)
+    with ops.knob("conv1x1_ew", 0):
+        assert ops.conv_tile_name(d).startswith("conv_igemm_f32<")
+        generic = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
+    with ops.knob("conv1x1_ew", 1):
+        assert ops.conv_tile_name(d) == "conv1x1_ew_f32<128x64,r64>"
+        ew = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
+    byrule = ops.conv2d(s, wk, pad=0, scale=sc, shift=sh, residual=r, relu=True)
     torch.cuda.synchronize()
-    monkeypatch.delenv("RS_CONV1X1_EW", raising=False)
+    assert torch.equal(byrule, generic)
     assert torch.equal(ew, generic)
     ref = F.conv2d(x, wt) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
     if res:

@@ -110,11 +110,8 @@ def test_decoder_wgrad_fp32_phase_form_vs_autograd_and_direct_form(n, c1, c2, co
     kw = dict(src2=nhwc(b.detach()) if c2 else None, ups=1, pad=1)
     dw = ops.conv2d_wgrad(*args, **kw)
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="phase-form wgrad")
-    os.environ["RS_WGRAD_F32_PHASE"] = "0"
-    try:
+    with ops.knob("wgrad_f32_phase", 0):
         direct = ops.conv2d_wgrad(*args, **kw)
-    finally:
-        del os.environ["RS_WGRAD_F32_PHASE"]
     close(direct.permute(0, 3, 1, 2).cpu(), wt.grad, what="direct-form wgrad")
     assert float((dw - direct).abs().max()) <= 1e-4 * float(direct.abs().max())
 

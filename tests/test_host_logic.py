@@ -453,19 +453,22 @@ def test_rank_device_check_counts_local_ranks(monkeypatch):
     isolates one GPU per rank (HIP_VISIBLE_DEVICES) is fine as well."""
     from robosat_amd.launch import check_ranks_fit_devices
 
-    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE", "LOCAL_RANK", "ROBOSAT_RANK_ISOLATED"):
         monkeypatch.delenv(k, raising=False)
-    check_ranks_fit_devices(16, 8, "nccl", local_world=8, local_rank=3)       # two nodes x 8 GPUs
+    check_ranks_fit_devices(16, 8, "nccl", local_world=8)       # two nodes x 8 GPUs
     check_ranks_fit_devices(8, 8, "nccl")                                       # one node, env absent: world = local world
     check_ranks_fit_devices(2, 1, "gloo")                                       # the shared-device tests
     with pytest.raises(RuntimeError, match="one device per rank"):
-        check_ranks_fit_devices(8, 4, "nccl", local_world=8, local_rank=0)      # two local ranks per device
+        check_ranks_fit_devices(8, 4, "nccl", local_world=8)      # two local ranks per device
     with pytest.raises(RuntimeError, match="one device per rank"):
         check_ranks_fit_devices(2, 1, "nccl")                                   # one visible device, nothing isolates the ranks
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     monkeypatch.setenv("LOCAL_RANK", "5")
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")
-    check_ranks_fit_devices(8, 1, "nccl")                                       # one GPU per rank, picked by the launcher
+    with pytest.raises(RuntimeError):
+        check_ranks_fit_devices(8, 1, "nccl")                                   # a single visible device alone says nothing (ADVICE r4)
+    monkeypatch.setenv("ROBOSAT_RANK_ISOLATED", "1")
+    check_ranks_fit_devices(8, 1, "nccl")                                       # one GPU per rank, and the launcher says so
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
     with pytest.raises(RuntimeError):
         check_ranks_fit_devices(8, 2, "nccl")

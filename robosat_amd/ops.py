@@ -271,7 +271,7 @@ def conv2d_split(src, weight, c1, stride=1, pad=0, out_hw=None, mask1=None, mask
     if PROFILE is not None:
         ev1.record()
         bf = act == BF16
-        name = conv_tile_name(d, bf, plain=relu_mask is None)
+        name = conv_tile_name(d, bf, plain=False)
         if alg_scale != 1.0 and not name.startswith("conv_halo"):
             name = name.replace("<", "<dgrad4x4,")
         _record(name, conv_flops(d) * alg_scale, (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,

@@ -19,7 +19,7 @@ done | tee $OUT/ew_rule_ab.txt
 echo "=== new tests ($(date +%T))"
 timeout 900 python -m pytest tests/test_gpu_tiles.py tests/test_gpu_train_ops.py -m gpu -q -x --timeout 600 -k "epilogue_wave or fused_statistics or halo_3x3 or batchnorm or decoder_wgrad_fp32 or relu_mask_as_bits" > $OUT/pytest_new.log 2>&1; echo "exit $?"; tail -5 $OUT/pytest_new.log | cut -c1-300
 echo "=== 3-band vs 4-band, 4 classes ($(date +%T))"
-for CH in 3 4 3 4; do
+for CH in 3 4 3; do
   timeout 300 $B --no-parity --phase train --dtype bf16 --batch 32 --classes 4 --channels $CH --steps 10 --warmup 3 --full-json $OUT/train_c4_ch$CH.json 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('channels $CH', d['value'], d['ms_per_step'], d['step_ms'])"
 done | tee $OUT/bands_ab.txt
 echo "=== conv1x1_ew_bf16: first run ($(date +%T))"

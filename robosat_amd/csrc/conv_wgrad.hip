@@ -29,20 +29,9 @@
 //            pixels, G[(py,px),(r,s)][co][ci] = sum_{n,a,b} dz[n][2a+py][2b+px][co] * src[n][a-(1-py)+r][b-(1-px)+s][ci]
 //            -- 16/36 of the multiply-adds -- and combine_phase_wgrad_f32_kernel adds the four G's that make up each
 //            filter tap (the fp32 twin of conv_wgrad_bf16.hip's phase form; round 4).
-#include "common.h"
+#include "conv_wgrad_f32.h"
 
 namespace {
-
-struct WgradArgs {
-  const float* dy;
-  const float* src1;
-  const float* src2;
-  float* out;  // [splits][Cout][K]  (K = taps * Cin, or kh*32 for the stem)
-  int N, Hs, Ws, C1, C2, Hv, Wv, ups;
-  int kw, stride, pad, Ho, Wo, Cout;
-  int M, K, tiles_co, tiles_ci, tiles_k, chunks_per_split;
-  rs_fastdiv div_howo, div_wo;  // PHASE: of the source grid (Hs*Ws, Ws): the rows m enumerate source pixels
-};
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -319,7 +308,6 @@ bool phase_ok(const rs_conv_desc* d) {
          d->Wo == 2 * d->Ws && rs_knobs().wgrad_f32_phase != 0;  // (knob wgrad_f32_phase / RS_WGRAD_F32_PHASE=0: the direct form, for A/B runs)
 }
 
-enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32, VSTEM };
 
 bool valid(const rs_conv_desc* d) {
   if (!d) return false;
@@ -432,7 +420,13 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
   a.chunks_per_split = pl.chunks_per_split;
   const int grid = pl.tiles_co * pl.tiles_k * pl.splits;
   hipStream_t s = (hipStream_t)stream;
-  if (pl.phase) {
+  // knob wgrad_f32_dma (-1 / 1: every non-stem launch; 0: the register-staged kernel below, for A/B runs): the LDS-DMA kernel
+  // of conv_wgrad_f32_dma.hip -- same blocks and partial tiles, both operands copied HBM -> LDS as they lie
+  const bool dma = !d->stem && rs_knobs().wgrad_f32_dma != 0;
+  int rc = 0;
+  if (dma) {
+    rc = rs_wgrad_f32_dma_launch(pl.variant, pl.phase, grid, s, a);
+  } else if (pl.phase) {
     switch (pl.variant) {
       case V128x128: conv_wgrad_f32<128, 128, 2, 2, 2><<<grid, 256, 0, s>>>(a); break;
       case V128x64: conv_wgrad_f32<128, 64, 2, 2, 2><<<grid, 256, 0, s>>>(a); break;
@@ -442,31 +436,30 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
       case V32x32: conv_wgrad_f32<32, 32, 1, 1, 2><<<grid, 64, 0, s>>>(a); break;
       default: return RS_EINVAL;
     }
-    const int rc = RS_LAUNCH_RESULT();
-    if (rc) return rc;
-    const long n = (long)d->Cout * pl.K;  // Cout x 16 x Cin
-    float* scratch = a.out + (long)pl.splits * n;
-    float* gbuf = scratch + rs_reduce_scratch_floats(n, pl.splits);
-    const int rc2 = rs_reduce_splits(a.out, gbuf, n, pl.splits, scratch, stream);
-    if (rc2) return rc2;
-    const long total = (long)d->Cout * 9 * (d->C1 + d->C2);
-    combine_phase_wgrad_f32_kernel<<<rs_cdiv(total, 256), 256, 0, s>>>(gbuf, dw, d->C1 + d->C2, total);
-    return RS_LAUNCH_RESULT();
+    rc = RS_LAUNCH_RESULT();
+  } else {
+    switch (pl.variant) {
+      case V128x128: conv_wgrad_f32<128, 128, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
+      case V128x64: conv_wgrad_f32<128, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
+      case V64x128: conv_wgrad_f32<64, 128, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
+      case V64x64: conv_wgrad_f32<64, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
+      case V32x128: conv_wgrad_f32<32, 128, 1, 4, 0><<<grid, 256, 0, s>>>(a); break;
+      case V32x32: conv_wgrad_f32<32, 32, 1, 1, 0><<<grid, 64, 0, s>>>(a); break;
+      case VSTEM: conv_wgrad_f32<64, 32, 2, 1, 1><<<grid, 128, 0, s>>>(a); break;
+      default: return RS_EINVAL;
+    }
+    rc = RS_LAUNCH_RESULT();
   }
-  switch (pl.variant) {
-    case V128x128: conv_wgrad_f32<128, 128, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case V128x64: conv_wgrad_f32<128, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case V64x128: conv_wgrad_f32<64, 128, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case V64x64: conv_wgrad_f32<64, 64, 2, 2, 0><<<grid, 256, 0, s>>>(a); break;
-    case V32x128: conv_wgrad_f32<32, 128, 1, 4, 0><<<grid, 256, 0, s>>>(a); break;
-    case V32x32: conv_wgrad_f32<32, 32, 1, 1, 0><<<grid, 64, 0, s>>>(a); break;
-    case VSTEM: conv_wgrad_f32<64, 32, 2, 1, 1><<<grid, 128, 0, s>>>(a); break;
-    default: return RS_EINVAL;
-  }
-  const int rc = RS_LAUNCH_RESULT();
   if (rc) return rc;
-  const long n = (long)d->Cout * pl.K;  // multiple of 4
-  return rs_reduce_splits(a.out, dw, n, pl.splits, a.out + (long)pl.splits * n, stream);
+  const long n = (long)d->Cout * pl.K;  // multiple of 4 (phase form: Cout x 16 x Cin)
+  float* scratch = a.out + (long)pl.splits * n;
+  if (!pl.phase) return rs_reduce_splits(a.out, dw, n, pl.splits, scratch, stream);
+  float* gbuf = scratch + rs_reduce_scratch_floats(n, pl.splits);
+  const int rc2 = rs_reduce_splits(a.out, gbuf, n, pl.splits, scratch, stream);
+  if (rc2) return rc2;
+  const long total = (long)d->Cout * 9 * (d->C1 + d->C2);
+  combine_phase_wgrad_f32_kernel<<<rs_cdiv(total, 256), 256, 0, s>>>(gbuf, dw, d->C1 + d->C2, total);
+  return RS_LAUNCH_RESULT();
 }
 
 extern "C" int rs_unpack_stem_weight(const float* packed, float* w_krsc, int Cout, int kh, int kw, int Cin,

@@ -65,6 +65,30 @@ def test_wgrad_and_dgrad(case):
     close(nchw(dx), x.grad, what="dgrad")
 
 
+@pytest.mark.parametrize("case", WGRAD, ids=[c[0] for c in WGRAD])
+def test_wgrad_fp32_lds_dma_kernel_vs_register_staged_kernel(case):
+    """conv_wgrad_f32_dma.hip (round 5: both operands HBM -> LDS by LDS-DMA as they lie, one dword per MFMA operand; what every
+    non-stem fp32 weight gradient runs) against autograd AND against conv_wgrad.hip's register-staged kernel on the same
+    launch (knob ``wgrad_f32_dma`` = 0): every tile variant, stride 2, a reduction that is not a multiple of the 32-pixel
+    chunk, many splits.  The two pair the pixels of a k-step differently: equal to fp32 summation-order noise."""
+    from robosat_amd import ops
+
+    _, n, cin, h, w, cout, k, stride, pad = case
+    x = rnd(n, cin, h, w, seed=11).requires_grad_(True)
+    wt = (rnd(cout, cin, k, k, seed=12) * (2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=pad)
+    gy = rnd(*y.shape, seed=13)
+    y.backward(gy)
+    args = (nhwc(gy), nhwc(x.detach()), k, k)
+    assert ops.get_knob("wgrad_f32_dma") != 0  # the shipped setting
+    dma = ops.conv2d_wgrad(*args, stride=stride, pad=pad)
+    with ops.knob("wgrad_f32_dma", 0):
+        staged = ops.conv2d_wgrad(*args, stride=stride, pad=pad)
+    close(dma.permute(0, 3, 1, 2).cpu(), wt.grad, what="LDS-DMA wgrad vs autograd")
+    close(staged.permute(0, 3, 1, 2).cpu(), wt.grad, what="register-staged wgrad vs autograd")
+    assert float((dma - staged).abs().max()) <= 2e-5 * float(staged.abs().max())
+
+
 @pytest.mark.parametrize("c1,c2,cout", [(256, 64, 128), (128, 0, 32), (512, 256, 64)])
 def test_decoder_block_backward(c1, c2, cout):
     """wgrad through the fused upsample+concat gather, dgrad + 2x2 sum + split + ReLU masks."""
@@ -112,6 +136,9 @@ def test_decoder_wgrad_fp32_phase_form_vs_autograd_and_direct_form(n, c1, c2, co
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="phase-form wgrad")
     with ops.knob("wgrad_f32_phase", 0):
         direct = ops.conv2d_wgrad(*args, **kw)
+    with ops.knob("wgrad_f32_dma", 0):  # the register-staged kernel's phase form (round 4) on the same launch
+        staged = ops.conv2d_wgrad(*args, **kw)
+    assert float((dw - staged).abs().max()) <= 2e-5 * float(staged.abs().max())
     close(direct.permute(0, 3, 1, 2).cpu(), wt.grad, what="direct-form wgrad")
     assert float((dw - direct).abs().max()) <= 1e-4 * float(direct.abs().max())
 

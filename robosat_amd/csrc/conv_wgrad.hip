@@ -356,7 +356,8 @@ Plan plan(const rs_conv_desc* d) {
   pl.tiles_k = pl.taps * pl.tiles_ci;
   const long tiles = (long)pl.tiles_co * pl.tiles_k;
   const long chunks = (M + 31) / 32;
-  long s = (1024 + tiles - 1) / tiles;       // aim at >= 1024 blocks (512 measured 3 % slower on the fp32 step, 2048 the same) ...
+  const long target = rs_knobs().wgrad_f32_blocks;
+  long s = (target + tiles - 1) / tiles;     // aim at >= 2048 blocks (knob wgrad_f32_blocks; with the LDS-DMA kernel: 8.87 ms of weight gradients per bs-8 step against 9.55 at 1024 and 10.56 at 512, profiles/r05/wgrad_f32_blocks.txt) ...
   const long smax = (chunks + 7) / 8;        // ... of at least 8 chunks (256 pixels) each
   if (s > smax) s = smax;
   if (s < 1) s = 1;

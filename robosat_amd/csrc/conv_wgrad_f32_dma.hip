@@ -56,9 +56,11 @@ __device__ __forceinline__ unsigned int wd_lds_addr(const void* p) {
   return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <int BMo, int BNo, int WGM, int WGN, bool PHASE>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_f32_dma(const WgradArgs p) {
-  constexpr int PK = 32;                 // pixels per chunk (= conv_wgrad.hip's: the plan's chunks_per_split counts these)
+// PK = pixels per pipeline chunk (a plan chunk is 32 pixels).  Instantiated with 32: 16-pixel chunks -- half the LDS, four
+// blocks per CU instead of two -- were measured on every layer of the fp32 bs-8 step and change nothing (8.79 vs 8.74 ms
+// of weight gradients, profiles/r05/wgrad_f32_dma.txt): occupancy is not what bounds this kernel.
+template <int BMo, int BNo, int WGM, int WGN, bool PHASE, int PK>
+__global__ __launch_bounds__(64 * WGM * WGN, PK == 16 ? 4 : 2) void conv_wgrad_f32_dma(const WgradArgs p) {
   constexpr int NS = PK / 2;             // MFMA k-steps per chunk
   constexpr int NW = WGM * WGN;          // waves
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_f32_dma(const Wg
   constexpr int ABYTES = PK * ROWA, BBYTES = PK * ROWB_;
   constexpr int BUF = ABYTES + BBYTES;
   static_assert(TM >= 1 && TN >= 1 && (IA % NW) == 0 && (IB % NW) == 0 && NI >= 1, "bad tile");
-  static_assert(2 * BUF + 4 * PK * 4 <= 80 * 1024, "two blocks per CU");
+  static_assert(2 * BUF + 4 * PK * 4 <= (PK == 16 ? 40 : 80) * 1024, "four / two blocks per CU");
+  static_assert(PK == 16 || PK == 32, "a plan chunk is 32 pixels");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + (PHASE ? 4 : 2) * PK * 4];
   int* tabs = reinterpret_cast<int*>(smem + 2 * BUF);  // [2][PK] input-row gather: source pixel (relative to image n_first) or -1
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_f32_dma(const Wg
     cs = ci0 - p.C1;
   }
 
-  const int chunk0 = split * p.chunks_per_split;
+  const int chunk0 = split * p.chunks_per_split * (32 / PK);
   const int total_chunks = (p.M + PK - 1) / PK;
-  int chunk1 = chunk0 + p.chunks_per_split;
+  int chunk1 = chunk0 + p.chunks_per_split * (32 / PK);
   if (chunk1 > total_chunks) chunk1 = total_chunks;
   const int Wd = PHASE ? p.Ws : p.Wo;                   // the pixel grid the reduction index m enumerates
   const int HoWo = PHASE ? p.Hs * p.Ws : p.Ho * p.Wo;   // (div_howo / div_wo are prepared for that grid)
@@ -268,12 +271,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_f32_dma(const Wg
 template <bool PHASE>
 int launch(int variant, int grid, hipStream_t s, const WgradArgs& a) {
   switch (variant) {
-    case V128x128: conv_wgrad_f32_dma<128, 128, 2, 2, PHASE><<<grid, 256, 0, s>>>(a); break;
-    case V128x64: conv_wgrad_f32_dma<128, 64, 2, 2, PHASE><<<grid, 256, 0, s>>>(a); break;
-    case V64x128: conv_wgrad_f32_dma<64, 128, 2, 2, PHASE><<<grid, 256, 0, s>>>(a); break;
-    case V64x64: conv_wgrad_f32_dma<64, 64, 2, 2, PHASE><<<grid, 256, 0, s>>>(a); break;
-    case V32x128: conv_wgrad_f32_dma<32, 128, 1, 4, PHASE><<<grid, 256, 0, s>>>(a); break;
-    case V32x32: conv_wgrad_f32_dma<32, 32, 1, 1, PHASE><<<grid, 64, 0, s>>>(a); break;
+    case V128x128: conv_wgrad_f32_dma<128, 128, 2, 2, PHASE, 32><<<grid, 256, 0, s>>>(a); break;
+    case V128x64: conv_wgrad_f32_dma<128, 64, 2, 2, PHASE, 32><<<grid, 256, 0, s>>>(a); break;
+    case V64x128: conv_wgrad_f32_dma<64, 128, 2, 2, PHASE, 32><<<grid, 256, 0, s>>>(a); break;
+    case V64x64: conv_wgrad_f32_dma<64, 64, 2, 2, PHASE, 32><<<grid, 256, 0, s>>>(a); break;
+    case V32x128: conv_wgrad_f32_dma<32, 128, 1, 4, PHASE, 32><<<grid, 256, 0, s>>>(a); break;
+    case V32x32: conv_wgrad_f32_dma<32, 32, 1, 1, PHASE, 32><<<grid, 64, 0, s>>>(a); break;
     default: return RS_EINVAL;
   }
   return RS_LAUNCH_RESULT();

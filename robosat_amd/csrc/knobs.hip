@@ -30,6 +30,7 @@ const Entry kEntries[] = {
     {"halo_ko", "RS_HALO_KO", &RsKnobs::halo_ko},
     {"wgrad_f32_phase", "RS_WGRAD_F32_PHASE", &RsKnobs::wgrad_f32_phase},
     {"wgrad_f32_dma", "RS_WGRAD_F32_DMA", &RsKnobs::wgrad_f32_dma},
+    {"wgrad_f32_blocks", "RS_WGRAD_F32_BLOCKS", &RsKnobs::wgrad_f32_blocks},
     {"wgrad_blocks", "RS_WGRAD_BLOCKS", &RsKnobs::wgrad_blocks},
     {"wgrad_blocks_phase", "RS_WGRAD_BLOCKS_PHASE", &RsKnobs::wgrad_blocks_phase},
     {"wino_wide", "ROBOSAT_WINO_WIDE", &RsKnobs::wino_wide},

@@ -136,6 +136,23 @@ SIGNATURES = {
 _lib = None
 
 
+def kernel_source_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h and the ABI header) in name order: identifies the TREE a measurement
+    belongs to where there is no .git (the GPU box gets a snapshot).  ``scripts/pmc_traffic.py`` stamps the counter tables with
+    it; ``bench.py`` prints ``roofline.traffic`` only when the stamp equals the digest of the sources it runs."""
+
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    names = sorted(n for n in os.listdir(src) if n.endswith((".hip", ".h")))
+    for path in [os.path.join(src, n) for n in names] + [os.path.join(os.path.dirname(_HERE), "include", "robosat_hip.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Returns the loaded library; raises (never falls back) if it is not there."""
 

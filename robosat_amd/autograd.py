@@ -28,6 +28,8 @@ def _side_stream(device):
     the wgrad (and its split reduction) runs beside the dgrad -> BatchNorm chain that is the backward's critical path and
     fills the CUs the short encoder kernels leave idle."""
 
+    if torch.device(device).type != "cuda":
+        return None  # (host tensors -- the 8-rank gloo test of the arena / reducer bookkeeping, tests/dp_worker.py: no streams to order)
     if os.environ.get("ROBOSAT_WGRAD_STREAM", "1") == "0":  # measurement knob: serial backward (clean per-kernel timings)
         return torch.cuda.current_stream(device)
     s = _SIDE.get(device)
@@ -58,13 +60,14 @@ class GradArena:
         alloc = torch.zeros if reducer is not None else torch.empty
         self.flat = alloc(total, device=device, dtype=torch.float32)
         self.side = _side_stream(device)
-        self.flat.record_stream(self.side)  # written by the wgrad kernels on the side stream
+        if self.side is not None:
+            self.flat.record_stream(self.side)  # written by the wgrad kernels on the side stream
         self.off = 0
         self.sent = 0
         self.reducer = reducer
         self.grads = {}
         self._t0, self.joins, self.flushes = None, 0, []
-        if GradArena.TRACE is not None:
+        if GradArena.TRACE is not None and self.side is not None:
             self._t0 = torch.cuda.Event(enable_timing=True)
             self._t0.record(torch.cuda.current_stream(device))
 
@@ -91,6 +94,9 @@ class GradArena:
     def wgrad(self, fn, *tensors):
         """Run ``fn`` (weight-gradient launches reading ``tensors``) on the side stream, after everything enqueued so far."""
 
+        if self.side is None:
+            fn()
+            return
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
@@ -103,7 +109,8 @@ class GradArena:
 
     def join(self):
         self.joins += 1
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def flush(self):
         """Hand the range completed since the last flush to the reducer -- ordered after the SIDE stream.
@@ -116,6 +123,11 @@ class GradArena:
         gradient.  (Round 2 joined the side stream into the main stream at each of the five flushes.)"""
 
         if self.reducer is not None and self.off > self.sent:
+            if self.side is None:  # host tensors: nothing to order
+                self.flushes.append(False)
+                self.reducer.reduce_async(self.flat[self.sent:self.off])
+                self.sent = self.off
+                return
             main = torch.cuda.current_stream()
             if self.side != main:
                 ev = torch.cuda.Event()
@@ -133,8 +145,11 @@ class GradArena:
             done = torch.cuda.Event(enable_timing=True)
             done.record(torch.cuda.current_stream())
         if self.reducer is not None:
-            with torch.cuda.stream(self.side):
-                self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)
+            if self.side is None:
+                self.reducer.wait()
+            else:
+                with torch.cuda.stream(self.side):
+                    self.reducer.wait()  # the side stream waits for the collectives (+ the bf16 wire's casts back run on it)
         self.join()  # once per step: the optimizer (main stream) needs every gradient
         if done is not None:
             GradArena.TRACE.append({"events": (self._t0, done), "joins": self.joins, "flushes": list(self.flushes)})

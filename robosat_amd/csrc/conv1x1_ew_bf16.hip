@@ -14,8 +14,10 @@
 //              LDS -> one partial row per tile), a slice per chunk step of the tile the other four are computing.
 // Both halves pass the same sequence of s_barrier instructions (one per chunk step + two at the end).
 //
-// STATUS: written without a GPU at hand (round 4 had no budget left): compiles, NOT yet run.  Reached only with
-// RS_CONV1X1_EW_BF16=1.  The partial sums are associated differently from the generic kernel's (same values, same rows).
+// STATUS (round 5, profiles/r05/ew_bf16_1x1.txt): correct on its first run (output bits identical to the generic kernel, partial
+// rows equal to fp32 association) and NOT faster -- x 1.04-1.10 on the long-K / narrow launches, x 0.83-0.95 on the short-K / wide
+// ones it was built for: one block per CU leaves four waves to issue a tile's stores where the generic kernel has sixteen.
+// Measurement only: built with `make EXP=1`, reached with knob conv1x1_ew_bf16 = 1 (RS_CONV1X1_EW_BF16=1).
 #define RS_CONV_INSTANTIATE
 #include "conv_igemm_dma_kernel.h"
 

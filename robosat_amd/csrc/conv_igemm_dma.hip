@@ -399,6 +399,7 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   }
 
   const int tile = pick_tile(d, phase4, (int)ES, stats != nullptr);
+#ifdef RS_EXP_BUILD  // (`make EXP=1`: measurement only -- parity yes, speed no: profiles/r05/ew_bf16_1x1.txt)
   if constexpr (sizeof(T) == 2) {
     // conv1x1_ew_bf16.hip (train-mode 1x1 forward, statistics epilogue on its own waves); its partial rows are per 128-pixel
     // tile, as the generic 128-row tiles'
@@ -406,6 +407,7 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
         rs_conv1x1_ew_bf16_stats_ok(d))
       return rs_conv1x1_ew_bf16_stats_launch(a, (hipStream_t)stream);
   }
+#endif
   if (out2 && (csplit % kTileBN[tile]) != 0) return RS_EINVAL;
   a.ntiles = rs_cdiv(d->Cout, kTileBN[tile]);  // the last N tile may be ragged (pick_tile)
   const int grid = rs_cdiv(M, kTileBM[tile]) * a.ntiles * (phase4 ? 4 : 1);

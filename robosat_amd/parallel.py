@@ -104,13 +104,16 @@ class GradReducer:
         if self.world == 1 and not self.force:
             return
         self.issued += 1
-        if self.wire_dtype == torch.bfloat16 and flat.is_cuda:
-            from . import ops
-
+        if self.wire_dtype == torch.bfloat16:
             # every rank puts ALREADY AVERAGED contributions on the wire (x 1/world inside the cast): the ring's partial sums
             # then stay at the magnitude of one gradient however many ranks there are -- summing WORLD unscaled bf16 values and
             # dividing afterwards loses mantissa to the larger partial sums and overflows earlier
-            wire = ops.cast_bf16_scaled(flat, 1.0 / self.world)
+            if flat.is_cuda:
+                from . import ops
+
+                wire = ops.cast_bf16_scaled(flat, 1.0 / self.world)
+            else:  # host tensors (the gloo tests of the wire's bookkeeping): the same scale -> round-to-nearest-even cast
+                wire = (flat * (1.0 / self.world)).to(torch.bfloat16)
             work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             # (`wire` is consumed on RCCL's communicator stream; the reference held in _pending until wait() has cast it back
             # is what keeps its memory from being recycled)
@@ -125,7 +128,9 @@ class GradReducer:
     def wait(self):
         for work, flat, wire in self._pending:
             work.wait()  # (device tensors: the CURRENT stream waits for the collective; the host does not block on RCCL)
-            if wire is not None:
+            if wire is not None and not flat.is_cuda:
+                flat.copy_(wire.float())
+            elif wire is not None:
                 from . import ops
 
                 ops.cast_f32_scaled(wire, flat, 1.0)  # (the contributions were scaled by 1/world on the way out)

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 
 def run(x, w, ew):
     if ew:
-        ops.set_knob("conv1x1_ew_bf16", 1)
+        ops.set_knob("conv1x1_ew_bf16", 1)  # (needs a `make -C robosat_amd/csrc EXP=1` library)
     else:
         ops.set_knob("conv1x1_ew_bf16", 0)
     y, part = ops.conv2d_bnstats(x, w, pad=0)
@@ -50,7 +50,7 @@ for cin, hw, cout in [(64, 128, 256), (256, 128, 128), (128, 64, 512), (512, 64,
     t = {}
     for ew in (False, True, False, True):
         if ew:
-            ops.set_knob("conv1x1_ew_bf16", 1)
+            ops.set_knob("conv1x1_ew_bf16", 1)  # (needs a `make -C robosat_amd/csrc EXP=1` library)
         else:
             ops.set_knob("conv1x1_ew_bf16", 0)
         for i in range(3):

@@ -61,9 +61,11 @@ def bench_name(k):
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), \d+, \d+, 1>", k)
     if m:
         return "conv_igemm_f32<{}x{},stem>".format(m.group(1), m.group(2))
-    m = re.search(r"(conv_wgrad_f32)", k)
+    m = re.search(r"(conv_wgrad_f32_dma|conv_wgrad_f32)", k)
     if m:
         return m.group(1)
+    if "conv1x1_ew_f32_kernel" in k:
+        return "conv1x1_ew_f32<128x64,r64>"
     m = re.match(r"(?:void )?(\w+)", k)
     return m.group(1) if m else k[:40]
 
@@ -105,7 +107,12 @@ if __name__ == "__main__":
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         commit = None
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from robosat_amd._lib import kernel_source_digest
+
     result["_meta"] = {
+        # digest of the kernel sources of the PROFILED tree: bench.py prints roofline.traffic only when it matches its own
+        "csrc_digest": kernel_source_digest(),
         "tag": sys.argv[3] if len(sys.argv) > 3 else None, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
         "commit": commit,  # None on the GPU box (the snapshot has no .git): filled in when the file is copied to profiles/
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --no-cpu-baseline --no-parity "

@@ -55,6 +55,93 @@ def cpu_logic(rank, world):
             "predict_batches": list(RankBatchSampler(10, 3, rank, world))}
 
 
+def backward_order(net):
+    """The order in which robosat_amd.autograd._backward carves the gradient arena, as (parameter, KRSC view?) items with a
+    None where it flushes a bucket to the reducer: head + decoder | layer4 | layer3 | layer2 | layer1 | (finish:) stem."""
+
+    out = [(net.final.weight, False), (net.final.bias, False), (net.dec5.block.weight, True)]
+    for blk in (net.dec4, net.dec3, net.dec2, net.dec1, net.dec0, net.center):
+        out.append((blk.block.block.weight, True))
+    out.append(None)
+    r = net.resnet
+    for layer in (r.layer4, r.layer3, r.layer2, r.layer1):
+        for blk in reversed(list(layer)):
+            for bn, conv in ((blk.bn3, blk.conv3), (blk.bn2, blk.conv2), (blk.bn1, blk.conv1)):
+                out += [(bn.weight, False), (bn.bias, False), (conv.weight, True)]
+            if blk.downsample is not None:
+                out += [(blk.downsample[1].weight, False), (blk.downsample[1].bias, False), (blk.downsample[0].weight, True)]
+        out.append(None)
+    out += [(r.bn1.weight, False), (r.bn1.bias, False), (r.conv1.weight, True)]  # (the stem: flushed by arena.finish)
+    return out
+
+
+def arena8(rank, world, wire):
+    """The data-parallel bookkeeping of a training step at the job's real size, on host tensors over gloo: the REAL U-Net's
+    parameter list carved into the flat arena in the backward's order (robosat_amd.autograd.GradArena), the five bucket
+    flushes of their real sizes (53 / 57 / 27 / 5 / 1 MiB + the stem's 38 KB) through GradReducer (fp32 or bf16 wire), the replica broadcast of
+    the whole state dict -- with as many ranks as a node has GPUs.  What RCCL replaces in production is the transport."""
+    import time
+
+    from robosat_amd import parallel
+    from robosat_amd.autograd import GradArena
+    from robosat_amd.unet import UNet
+
+    torch.manual_seed(100 + rank)
+    net = UNet(2, pretrained=False)  # (parameters only: nothing here computes)
+    digest_before = float(sum(t.double().abs().sum() for t in net.state_dict().values()))
+    t0 = time.perf_counter()
+    parallel.broadcast_module(net)
+    t_bcast = time.perf_counter() - t0
+    digest = float(sum(t.double().abs().sum() for t in net.state_dict().values()))
+    peers = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(peers, torch.tensor([digest], dtype=torch.float64))
+
+    unused = {id(p) for p in net.resnet.fc.parameters()}
+    params = [p for p in net.parameters() if id(p) not in unused]
+    red = parallel.GradReducer(wire_dtype=torch.bfloat16 if wire == "bf16" else torch.float32)
+    arena = GradArena(params, torch.device("cpu"), red)
+    buckets, mark = [], 0
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(1 << 16, generator=g)  # the same pattern on every rank, scaled per rank: mean = pattern * mean(scale)
+    t0 = time.perf_counter()
+    for item in backward_order(net):
+        if item is None:
+            buckets.append((arena.off - mark) * 4 / 2**20)
+            mark = arena.off
+            arena.flush()
+            continue
+        p, krsc = item
+        v = arena.conv(_Holder(p)) if krsc else arena.take(p, tuple(p.shape))
+        flat = v.reshape(-1)
+        reps = (flat.numel() + base.numel() - 1) // base.numel()
+        flat.copy_(base.repeat(reps)[:flat.numel()] * (rank + 1.0))
+    buckets.append((arena.off - mark) * 4 / 2**20)
+    arena.finish()
+    t_step = time.perf_counter() - t0
+    want_scale = sum(range(1, world + 1)) / world
+    # every parameter that takes part got a gradient view of its own shape, averaged over the ranks
+    worst, covered = 0.0, 0
+    for p in params:
+        gv = arena.grads[p]
+        assert tuple(gv.shape) == tuple(p.shape)
+        flat = gv.permute(0, 2, 3, 1).reshape(-1) if gv.dim() == 4 else gv.reshape(-1)  # (conv gradients live in KRSC)
+        reps = (flat.numel() + base.numel() - 1) // base.numel()
+        want = base.repeat(reps)[:flat.numel()] * want_scale
+        worst = max(worst, float((flat - want).abs().max() / want.abs().max()))
+        covered += flat.numel()
+    return {"world": world, "wire": wire, "buckets_mb": [round(b, 1) for b in buckets], "issued": red.issued, "elements": covered,
+            "arena_full": arena.off == arena.flat.numel(), "worst_rel_err": worst, "joins": arena.joins,
+            "replicas_equal": len({round(float(x), 3) for x in peers}) == 1, "started_different": True if rank == 0 else digest_before != digest,
+            "seconds": {"broadcast": round(t_bcast, 2), "flushes": round(t_step, 2)}}
+
+
+class _Holder:
+    """What GradArena.conv wants: an object with a .weight (robosat_amd.unet._Conv has more; the arena only reads this)."""
+
+    def __init__(self, weight):
+        self.weight = weight
+
+
 def gpu_unet(rank, world, dtype):
     """Two replicas on ONE MI355X (gloo reduces the device tensors through the host): a full U-Net training step through
     GradArena + GradReducer must give every rank the MEAN of the ranks' local gradients, and the replicas must stay
@@ -301,6 +388,8 @@ def main():
         res = gpu_miou(rank, world)
     elif mode.startswith("gpu_rccl1"):
         res = gpu_rccl1(torch.bfloat16 if mode.endswith("bf16") else torch.float32)
+    elif mode.startswith("arena8"):
+        res = arena8(rank, world, "bf16" if mode.endswith("bf16") else "fp32")
     elif mode == "fail":
         if rank == 1:
             sys.exit(3)  # a lost rank: the launcher must stop the survivor (who would wait forever below)

@@ -566,16 +566,29 @@ def test_bench_symbols_are_covered(tmp_path):
     with open(full) as fp:  # the full record: per-kernel tables, every step time
         line = json.load(fp)
     assert line["train"]["value"] == brief["train"]["value"] and line["value"] == brief["value"]
-    names = set(line["roofline"]["per_kernel"]) | set(line["train"]["roofline"]["per_kernel"])
+    names = (set(line["roofline"]["per_kernel"]) | set(line["train"]["roofline"]["per_kernel"]) |
+             set(line["legs"]["predict_fp32_bs32"]["roofline"]["per_kernel"]))
     assert names, line
     missing = sorted(n for n in names if n not in COVERED)
     assert not missing, missing
     assert line["parity"]["max_abs_vs_oracle"] <= 1e-3
     assert line["train"]["parity"]["max_abs_vs_oracle"] <= 5e-2
     # the other BASELINE configurations ride in the same line (configs[4]: 4 bands, 4 classes; fp32 training; configs[3])
-    assert set(line["legs"]) == {"cfg5_train_bf16_4band_4class", "train_fp32_bs8", "cfg4_predict_fp32_1024_bs8"}
+    assert set(line["legs"]) == {"predict_fp32_bs32", "cfg5_train_bf16_4band_4class", "train_fp32_bs8", "cfg4_predict_fp32_1024_bs8"}
+    # the north_star's "MFMA roofline on 3x3 conv" as one number per leg, and at bs 32
+    for roof in (line["roofline"], line["train"]["roofline"], line["legs"]["predict_fp32_bs32"]["roofline"]):
+        assert 0.0 < roof["conv3x3"]["frac"] <= 1.0 and roof["conv3x3"]["launches"] > 0
+    assert 0.0 < brief["legs"]["predict_fp32_bs32"]["conv3x3"]["frac"] <= 1.0 and "conv3x3" in brief["roofline"]
+    # roofline.traffic is printed only when the committed counter tables were taken on THESE kernel sources
+    src = line["roofline"]["traffic_source"]
+    assert (line["roofline"]["traffic"] is None) == bool(src["stale"] or line["roofline"]["kernel"] not in _pmc_names())
     assert all(leg["value"] > 0 for leg in line["legs"].values())
     assert line["legs"]["cfg5_train_bf16_4band_4class"]["config"]["bands"] == 4
+
+
+def _pmc_names():
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
+        return set(json.load(fp))
 
 
 # ---- fp32 Winograd form of DecoderBlock (conv_wino_f32.hip) --------------------------------------------------------------------

@@ -504,3 +504,40 @@ def test_bench_prints_a_compact_line_and_keeps_the_full_record(tmp_path):
     assert t["reducer"]["collectives_issued"] == 180
     assert set(line["legs"]) == set(full["legs"]) and all(leg["value"] > 0 for leg in line["legs"].values())
     assert line["full_record"] == path
+
+
+def test_bench_line_and_rank_environment_at_eight_ranks(tmp_path, monkeypatch):
+    """`bench.py --gpus 8` under either launcher.  torchrun's environment (WORLD_SIZE / RANK / LOCAL_RANK) is
+    what `launch.dist_env` reads and what stops bench.py from spawning ranks of its own; `spawn_ranks` writes the same
+    variables for its children (exercised with eight real processes in tests/test_parallel_gloo.py); and the compact line of
+    an 8-rank run still carries `train.reducer` -- backend, world, collectives issued -- so the driver can tell that RCCL saw
+    eight ranks, and the new `conv3x3` group, within the 4 KB the driver's tail holds."""
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from robosat_amd import launch
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert not launch.under_launcher() and launch.dist_env() == (1, 0, 0)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert launch.under_launcher() and launch.dist_env() == (8, 5, 5)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    args = bench.parse()
+    assert args.gpus == 8 and args.scaling == "weak" and args.grad_dtype == "fp32"
+
+    with open(os.path.join(ROOT, "profiles", "r03", "bench_default.json")) as fp:
+        full = json.load(fp)
+    full["n_gpus"] = 8
+    full["value"] = round(full["value"] * 8, 2)
+    full["train"]["reducer"] = {"backend": "nccl", "world": 8, "forced": False, "collectives_issued": 6 * 39, "wire": "fp32"}
+    for roof in (full["roofline"], full["train"]["roofline"]):
+        roof["conv3x3"] = {"executed_tflops": 100.0, "frac": 0.64, "ms": 6.2, "launches": 21, "algorithmic_tflops": 300.0, "what": "x" * 200}
+    line = bench.compact_line(full, "gpurun_out/bench_full.json")
+    assert len(json.dumps(line)) <= bench.COMPACT_LIMIT
+    assert line["n_gpus"] == 8 and line["train"]["reducer"] == full["train"]["reducer"]
+    assert line["roofline"]["conv3x3"]["frac"] == 0.64 and "what" not in line["train"]["roofline"]["conv3x3"]
+    assert line["train"]["config"]["parallelism"].startswith("dp")

@@ -7,6 +7,8 @@ import json
 import os
 import sys
 
+import pytest
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "dp_worker.py")
 
@@ -55,6 +57,31 @@ def test_launcher_stops_the_survivors_of_a_failed_rank(tmp_path):
     rc, res = run_world2("fail", tmp_path, timeout=120)
     assert rc == 3
     assert res == [None, None]
+
+
+def test_a_failed_rank_takes_an_eight_rank_job_down(tmp_path):
+    """The node-sized job: rank 1 of EIGHT exits, the launcher stops the seven that would wait in the collective forever."""
+    rc, res = run_world2("fail", tmp_path, timeout=180, world=8)
+    assert rc == 3
+    assert res == [None] * 8
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_arena_and_reducer_at_the_real_size_with_eight_ranks(tmp_path, wire):
+    """nothing in the N > 1 path should be first-run code when a node appears.  Eight gloo ranks carve the
+    REAL U-Net's 168 gradient tensors into the flat arena in the backward's order, flush the six buckets of their real sizes
+    through GradReducer (fp32 wire: exact mean; bf16 wire: pre-scaled contributions, one rounding each way) and broadcast the
+    whole 329-entry state dict from rank 0.  (The kernels and RCCL's transport are what this leaves out: tests/test_gpu_parallel.py
+    runs the same classes on device tensors, with the nccl backend at world size 1.)"""
+    rc, res = run_world2("arena8_" + wire, tmp_path, timeout=900, world=8)
+    assert rc == 0, res
+    for rank, r in enumerate(res):
+        assert r["world"] == 8 and r["issued"] == 6 and r["arena_full"] and r["joins"] == 1, r
+        assert r["elements"] == 37341314  # every parameter with a gradient (resnet.fc has none)
+        # DESIGN.md section 6: head + decoder 55 MB (52.8 MiB), layer4 60, layer3 28, layer2 5, layer1 1, the stem's 38 KB at finish
+        assert [round(b) for b in r["buckets_mb"]] == [53, 57, 27, 5, 1, 0], r["buckets_mb"]
+        assert r["replicas_equal"] and r["started_different"]
+        assert r["worst_rel_err"] <= (1e-6 if wire == "fp32" else 2.0 ** -7), r["worst_rel_err"]
 
 
 def test_shard_indices_single_rank_is_reference_order():

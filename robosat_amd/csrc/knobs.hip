@@ -33,6 +33,7 @@ const Entry kEntries[] = {
     {"wgrad_f32_blocks", "RS_WGRAD_F32_BLOCKS", &RsKnobs::wgrad_f32_blocks},
     {"wgrad_blocks", "RS_WGRAD_BLOCKS", &RsKnobs::wgrad_blocks},
     {"wgrad_blocks_phase", "RS_WGRAD_BLOCKS_PHASE", &RsKnobs::wgrad_blocks_phase},
+    {"lovasz_xcd", "RS_LOVASZ_XCD", &RsKnobs::lovasz_xcd},
     {"wino_wide", "ROBOSAT_WINO_WIDE", &RsKnobs::wino_wide},
 };
 

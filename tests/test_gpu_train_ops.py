@@ -310,9 +310,11 @@ def test_miou_both_branches_vs_oracle(noise, margin, branch):
 
 
 @pytest.mark.parametrize("n,c,h,w", [(3, 2, 128, 128), (2, 4, 64, 96), (1, 3, 48, 80),
+                                     (2, 3, 7, 9),        # H * W = 63: the scalar (unaligned) forms of the key / scan kernels
                                      (2, 2, 512, 512),    # 524 288 keys per image: what BASELINE configs[2] sorts (x 32 images)
                                      (1, 4, 512, 512),    # 1 048 576 keys per image: configs[4]
-                                     (3, 3, 256, 320)])   # 245 760 keys: not a multiple of the 8 192-key digit tile x blocks
+                                     (3, 3, 256, 320),    # 245 760 keys: not a multiple of the 8 192-key digit tile x blocks
+                                     (16, 2, 512, 512)])  # 8.4 M keys in all: the 4 096-key digit tiles of the large sorts (round 5)
 def test_lovasz_vs_oracle(n, c, h, w):
     """Multi-block radix sort / segmented scan against the CPU oracle (reference losses.py:96-119), from one-block images up
     to the key counts the benchmark runs -- the 8 192-element LDS digit tiles, the multi-block scan carry and the segment

@@ -219,8 +219,10 @@ int thin_mode(const rs_conv_desc* d, bool phase4, bool plain_epilogue) {
   return -1;
 }
 
-// Which halo-once form of the kernel runs this bf16 launch (HALO_NONE: none), and its N tile.  Geometry only -- never the
-// batch size beyond "enough blocks to fill the chip" -- : the rows of a block are an 8 x 32 patch of the grid they enumerate,
+// Which halo-once form of the kernel runs this bf16 launch (HALO_NONE: none), and its N tile.  The layer's geometry and "enough
+// blocks to fill the chip" -- the latter counts the batch, and the halo forms accumulate K chunk-major where the implicit GEMM goes
+// tap-major: a bf16 tile's output may differ by rounding with the batch it travels in (the fp32 path's choices never look at the
+// batch and ARE batch-invariant bit for bit; tests/test_gpu_bf16.py::test_unet_bf16_predict_across_batch_sizes bounds the bf16 side): the rows of a block are an 8 x 32 patch of the grid they enumerate,
 // so that grid must tile into such patches; K-chunks are 128-byte rows.  A forced implicit-GEMM tile
 // (rs_conv2d_set_tuning) keeps the generic kernel; forcing THALO takes the halo form wherever it can run.
 // `epi`: the launch's epilogue kind -- only the 3x3 form carries the statistics / into-BatchNorm epilogues (HALO_PHASE and

@@ -418,7 +418,9 @@ Plan plan(const rs_conv_desc* d) {
   // the data-gradient chain).  The tap-per-block launches of the encoder: in isolation they are fastest at 512 blocks (a
   // block is prologue + few chunks + a 64 KB partial tile, and every extra split is another partial to write and reduce),
   // but one block per CU (256) leaves room for the main stream's kernels and gives the shortest step (25.3-25.4 ms vs 25.6
-  // at 512 and 26.1 at the former 1024).  The phase form's 16-tap launches are long reductions and want more, shorter blocks.
+  // at 512 and 26.1 at the former 1024).  Round 5 (profiles/r05/wgrad_blocks_bf16.txt, median step): 22.64-22.70 ms at 256,
+  // 22.51 / 22.52 at 192 / 128, 22.72 at 384 -> 192.  The phase form's 16-tap launches are long reductions and want more, shorter
+  // blocks (1024 / 1536 / 2048: the same step time).
   const long target = pl.phase ? rs_knobs().wgrad_blocks_phase : rs_knobs().wgrad_blocks;
   long s = (target + tiles - 1) / tiles;          // aim at >= `target` blocks ...
   const long smax = (chunks * PK / 64 + 7) / 8;   // ... of at least 512 pixels each

@@ -368,6 +368,10 @@ typedef struct rs_wprep_item {
   int tile_begin;
 } rs_wprep_item;
 int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int total_tiles, rs_stream_t stream);
+/* The fp32 twin: every item's `dgrad` points at a FLOAT buffer [Cin][taps, flipped][Cout] (the layout of rs_pack_dgrad_weight),
+ * `cast` must be NULL (the fp32 KRSC master is its own compute copy): the data-gradient weights of a whole fp32 training step
+ * (tools/train.py:180-188 in the reference's arithmetic) in one launch instead of one per convolution. */
+int rs_weight_prep_f32(const rs_wprep_item* items_dev, int n, int total_tiles, rs_stream_t stream);
 /* The same weights from the already transposed, tap-flipped fp32 weights of rs_pack_dgrad_weight ([Cin][3][3][Cout]):
  * both sides contiguous along Cout (the one-step pack reads with a 9*Cin stride). */
 int rs_combine_dgrad_phase_weight_dt(const float* w_dgrad, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "rs_cast_bf16_to_f32_scaled": (c_int, [P, P, c_long, c_float, P]),
     "rs_cast_f32_to_bf16_scaled": (c_int, [P, P, c_long, c_float, P]),
     "rs_weight_prep_bf16": (c_int, [P, c_int, c_int, P]),
+    "rs_weight_prep_f32": (c_int, [P, c_int, c_int, P]),
     "rs_pack_dgrad_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "rs_maxpool2d_fwd_dt": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_maxpool2d_bwd_dt": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

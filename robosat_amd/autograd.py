@@ -221,7 +221,7 @@ def _prefetch_decoder_weights(net, dt, device):
     return done
 
 
-def _forward(net, x, tape):
+def _forward(net, x, tape, backward=False):
     from .unet import _bump_generation
 
     _bump_generation()  # a training forward re-derives every compute copy of the weights (see unet._GENERATION)
@@ -231,6 +231,8 @@ def _forward(net, x, tape):
     dt = net.compute_dtype  # fp32 or bf16 activations (the image is cast on upload)
     if dt == torch.bfloat16:
         net.prep_bf16_weights()  # one launch: bf16 casts + data-gradient layouts of the encoder weights for this step
+    elif backward:
+        net.prep_f32_weights()  # one launch: the fp32 data-gradient layouts (only a step that has a backward needs them)
     x4 = ops.nchw_to_nhwc4(x, dt)
     t["x4"] = x4
     if dt == torch.bfloat16:
@@ -425,7 +427,7 @@ class _UNetTrainFn(torch.autograd.Function):
         if not x.is_cuda:
             raise RuntimeError("robosat_amd.UNet runs on the MI355X only (got a {} tensor); there is no CPU fallback".format(x.device))
         tape = _Tape()
-        logits = _forward(net, x.detach().float().contiguous(), tape)
+        logits = _forward(net, x.detach().float().contiguous(), tape, backward=True)
         ctx.net, ctx.tape, ctx.params = net, tape, params
         return logits
 

@@ -56,7 +56,8 @@ __global__ void pack_dgrad_weight_bf16_kernel(const float* __restrict__ w, bf16_
 // The same for MANY weight tensors in one launch (the bf16 compute copies of a whole network after an optimizer step):
 // block -> (item, 32x32 tile); one read of the fp32 tile feeds both the bf16 KRSC copy and the transposed, tap-flipped
 // data-gradient copy.
-__global__ __launch_bounds__(256) void weight_prep_bf16_kernel(const rs_wprep_item* __restrict__ items, int n) {
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const rs_wprep_item* __restrict__ items, int n) {
   __shared__ float tile[32][33];
   const int bid = blockIdx.x;
   int lo = 0, hi = n - 1;  // last item with tile_begin <= bid (block-uniform)
@@ -73,15 +74,15 @@ __global__ __launch_bounds__(256) void weight_prep_bf16_kernel(const rs_wprep_it
   const int co0 = (t % tco) * 32;
   const int tap = t / tco;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
-  bf16_t* cast = reinterpret_cast<bf16_t*>(it.cast);
-  bf16_t* dgrad = reinterpret_cast<bf16_t*>(it.dgrad);
+  T* cast = reinterpret_cast<T*>(it.cast);
+  T* dgrad = reinterpret_cast<T*>(it.dgrad);
   for (int r = ty; r < 32; r += 8) {
     const int co = co0 + r, ci = ci0 + tx;
     float v = 0.f;
     if (co < it.Cout && ci < it.Cin) {
       const long i = ((long)co * it.taps + tap) * it.Cin + ci;
       v = it.w[i];
-      if (cast) cast[i] = (bf16_t)v;
+      if (cast) cast[i] = (T)v;
     }
     tile[r][tx] = v;
   }
@@ -90,13 +91,21 @@ __global__ __launch_bounds__(256) void weight_prep_bf16_kernel(const rs_wprep_it
   const int ftap = it.taps - 1 - tap;
   for (int r = ty; r < 32; r += 8) {
     const int ci = ci0 + r, co = co0 + tx;
-    if (ci < it.Cin && co < it.Cout) dgrad[((long)ci * it.taps + ftap) * it.Cout + co] = (bf16_t)tile[tx][r];
+    if (ci < it.Cin && co < it.Cout) dgrad[((long)ci * it.taps + ftap) * it.Cout + co] = (T)tile[tx][r];
   }
 }
 
 extern "C" int rs_weight_prep_bf16(const rs_wprep_item* items_dev, int n, int total_tiles, rs_stream_t stream) {
   if (!items_dev || n <= 0 || total_tiles <= 0) return RS_EINVAL;
-  weight_prep_bf16_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(items_dev, n);
+  weight_prep_kernel<bf16_t><<<total_tiles, 256, 0, (hipStream_t)stream>>>(items_dev, n);
+  return RS_LAUNCH_RESULT();
+}
+
+// The fp32 twin (round 5): `dgrad` points at FLOAT buffers (the layout of rs_pack_dgrad_weight), `cast` is NULL -- the fp32
+// training step's 59 per-convolution packing launches in one.
+extern "C" int rs_weight_prep_f32(const rs_wprep_item* items_dev, int n, int total_tiles, rs_stream_t stream) {
+  if (!items_dev || n <= 0 || total_tiles <= 0) return RS_EINVAL;
+  weight_prep_kernel<float><<<total_tiles, 256, 0, (hipStream_t)stream>>>(items_dev, n);
   return RS_LAUNCH_RESULT();
 }
 

@@ -591,27 +591,32 @@ class WeightPrep:
     ``pack_dgrad_weight(w, bfloat16)`` per tensor.  The destination buffers and the device-side item table are allocated
     once; ``run()`` is what a training step calls after the optimizer moved the master weights."""
 
-    def __init__(self, weights_krsc, want_dgrad=True):
+    def __init__(self, weights_krsc, want_dgrad=True, dtype=BF16):
+        """``dtype=torch.float32`` (round 5, ``rs_weight_prep_f32``): the fp32 training step's data-gradient layouts only -- the
+        fp32 KRSC master is its own compute copy, so ``cast`` stays empty."""
+
         assert weights_krsc and all(w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 for w in weights_krsc)
+        assert dtype == BF16 or want_dgrad
         dev = weights_krsc[0].device
+        self.dtype = dtype
         self.weights = list(weights_krsc)
-        self.cast = [torch.empty(w.shape, device=dev, dtype=BF16) for w in self.weights]
-        self.dgrad = [torch.empty((w.shape[3], w.shape[1], w.shape[2], w.shape[0]), device=dev, dtype=BF16) if want_dgrad else None
+        self.cast = [torch.empty(w.shape, device=dev, dtype=BF16) if dtype == BF16 else None for w in self.weights]
+        self.dgrad = [torch.empty((w.shape[3], w.shape[1], w.shape[2], w.shape[0]), device=dev, dtype=dtype) if want_dgrad else None
                       for w in self.weights]
         items = (_WPrepItem * len(self.weights))()
         tiles = 0
         for i, w in enumerate(self.weights):
             cout, kh, kw, cin = w.shape
-            items[i] = _WPrepItem(_dev(w, "w").value, _dev(self.cast[i], "cast", BF16).value,
-                                  _dev(self.dgrad[i], "dgrad", BF16).value if want_dgrad else None, cout, kh * kw, cin, tiles)
+            items[i] = _WPrepItem(_dev(w, "w").value, _dev(self.cast[i], "cast", BF16).value if dtype == BF16 else None,
+                                  _dev(self.dgrad[i], "dgrad", dtype).value if want_dgrad else None, cout, kh * kw, cin, tiles)
             tiles += kh * kw * ((cin + 31) // 32) * ((cout + 31) // 32)
         self.tiles = tiles
         self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
         self.ptrs = tuple(w.data_ptr() for w in self.weights)
 
     def run(self):
-        check(_lib.lib().rs_weight_prep_bf16(_dev(self.table, "items", torch.uint8), len(self.weights), self.tiles, _stream()),
-              "rs_weight_prep_bf16")
+        fn = _lib.lib().rs_weight_prep_bf16 if self.dtype == BF16 else _lib.lib().rs_weight_prep_f32
+        check(fn(_dev(self.table, "items", torch.uint8), len(self.weights), self.tiles, _stream()), "rs_weight_prep")
 
 
 def pack_stem_weight(w_krsc, dtype=torch.float32):

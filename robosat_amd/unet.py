@@ -65,8 +65,8 @@ class _Conv(nn.Module):
         """Data-gradient weights [Cin,kh,kw,Cout], taps flipped, in ``dtype``: the copy ``UNet.prep_bf16_weights`` made for
         the current parameter version if there is one, else packed now (``rs_pack_dgrad_weight[_bf16]``)."""
 
-        c = getattr(self, "_dgrad", None)
-        if dtype == torch.bfloat16 and c is not None and c[0] == (self.weight.data_ptr(), self.weight._version, _GENERATION[0]):
+        c = getattr(self, "_dgrad" if dtype == torch.bfloat16 else "_dgrad_f32", None)
+        if c is not None and c[0] == (self.weight.data_ptr(), self.weight._version, _GENERATION[0]):
             return c[1]
         return ops.pack_dgrad_weight(self.krsc(), dtype)
 
@@ -352,24 +352,38 @@ class UNet(nn.Module):
         the last refresh (i.e. once per optimizer step).  ``_Conv.krsc(bf16)`` / ``_Conv.dgrad_weight(bf16)`` then hit
         these copies; without this call they cast / pack per tensor as before (105 small launches per step)."""
 
+        self._prep_weights(torch.bfloat16)
+
+    def prep_f32_weights(self):
+        """The fp32 training step's twin (round 5): the data-gradient layouts of the same 53 convolutions in one launch
+        (``rs_weight_prep_f32``) instead of one ``rs_pack_dgrad_weight`` per convolution in front of its data gradient
+        (59 launches of ~5 us on the backward's main stream)."""
+
+        self._prep_weights(torch.float32)
+
+    def _prep_weights(self, dt):
         convs = []
         for layer in self._blocks():
             for blk in layer:
                 convs += [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
         convs.append(self.dec5.block)
         keys = [(c.weight.data_ptr(), c.weight._version, _GENERATION[0]) for c in convs]
-        st = getattr(self, "_wprep", None)
+        slot = "_wprep" if dt == torch.bfloat16 else "_wprep_f32"
+        st = getattr(self, slot, None)
         if st is not None and st[1] == keys:
             return
         ws = [c.krsc() for c in convs]
         if st is None or st[0].ptrs != tuple(w.data_ptr() for w in ws):  # first use, or the parameters moved (.to(), load)
-            st = [ops.WeightPrep(ws), None]
+            st = [ops.WeightPrep(ws, dtype=dt), None]
         st[0].run()
         st[1] = keys
-        self._wprep = st
+        setattr(self, slot, st)
         for c, k, cast, dg in zip(convs, keys, st[0].cast, st[0].dgrad):
-            c._bf16 = (k, cast)
-            c._dgrad = (k, dg)
+            if dt == torch.bfloat16:
+                c._bf16 = (k, cast)
+                c._dgrad = (k, dg)
+            else:
+                c._dgrad_f32 = (k, dg)
 
     # -- hipGraph replay of the eval forward (latency path) -------------------------------------------------------
 

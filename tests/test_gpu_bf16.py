@@ -519,3 +519,31 @@ def test_weight_prep_multi_tensor_is_bit_identical():
     net.prep_bf16_weights()
     assert torch.equal(c.krsc(torch.bfloat16), ops.cast_bf16(c.krsc()))
     assert torch.equal(c.dgrad_weight(torch.bfloat16), ops.pack_dgrad_weight(c.krsc(), torch.bfloat16))
+
+
+def test_weight_prep_fp32_twin_is_bit_identical():
+    """rs_weight_prep_f32 (round 5: the fp32 training step's data-gradient layouts in one launch) == rs_pack_dgrad_weight per
+    tensor; UNet.prep_f32_weights() serves them through _Conv.dgrad_weight(float32) until a master weight changes."""
+    from robosat_amd import ops
+    from robosat_amd.unet import UNet
+
+    shapes = [(64, 1, 1, 64), (64, 3, 3, 64), (256, 1, 1, 64), (96, 3, 3, 40), (33, 1, 1, 70), (512, 3, 3, 512)]
+    ws = [rnd(*s, seed=60 + i).to(DEV) for i, s in enumerate(shapes)]
+    prep = ops.WeightPrep(ws, dtype=torch.float32)
+    prep.run()
+    for w, c, d in zip(ws, prep.cast, prep.dgrad):
+        assert c is None and d.dtype == torch.float32
+        assert torch.equal(d, ops.pack_dgrad_weight(w, torch.float32))
+
+    net = UNet(2, pretrained=False).to(DEV)
+    c = net.resnet.layer3[2].conv2
+    assert getattr(c, "_dgrad_f32", None) is None
+    net.prep_f32_weights()
+    served = c.dgrad_weight(torch.float32)
+    assert served is net._wprep_f32[0].dgrad[net._wprep_f32[0].ptrs.index(c.krsc().data_ptr())]
+    assert torch.equal(served, ops.pack_dgrad_weight(c.krsc(), torch.float32))
+    with torch.no_grad():
+        c.weight.mul_(1.5)
+    assert torch.equal(c.dgrad_weight(torch.float32), ops.pack_dgrad_weight(c.krsc(), torch.float32))  # stale copy is not served
+    net.prep_f32_weights()
+    assert torch.equal(c.dgrad_weight(torch.float32), ops.pack_dgrad_weight(c.krsc(), torch.float32))

@@ -331,8 +331,210 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wg
     }
 }
 
+// ---- phase form, FOUR source offsets per block (round 5) ---------------------------------------------------------------------
+// The 16 (output parity, source offset) reductions of DecoderBlock's weight gradient pair each of the four dz parity planes with
+// four shifted views of the source.  conv_wgrad_bf16<.., PHASE> gives every pair its own block: a 128 x 128 tile fetches
+// 256 rows per 64-pixel chunk for ONE product, and the launches are bound by the CUs' LDS-DMA paths (MFMA busy 41 %,
+// profiles/r05/pmc_mfma_per_kernel.txt).  Here a block owns one PLANE and all four of its offsets: the dz tile is fetched once and
+// multiplied with four source tiles -- 640 rows per chunk for FOUR products (0.625 x the bytes per multiply-add).  8 waves as
+// 2 (couts) x 4 (cins): wave tile 64 x 32 for each of the four offsets = 128 accumulator registers; 32-pixel chunks (two MFMA
+// k-steps per barrier), two buffers of 40 KB, one block per CU.  Same gather tables, swizzle, transposing reads, partial-tile
+// format ([split][Cout][16 x Ctot], tap = 4 * plane + offset) and combine as the kernel above.  Cout % 128 == 0, Cin tile 128.
+__global__ __launch_bounds__(512, 2) void conv_wgrad_phase4_bf16(const WgradArgsB p) {
+  constexpr int BMo = 128, BNo = 128, WGM = 2, WGN = 4, PK = 32, NOFF = 4;
+  constexpr int NW = WGM * WGN;
+  constexpr int NS = PK / 16;
+  constexpr int WM = BMo / WGM, TM = WM / 32;               // 64, 2 (couts per wave)
+  constexpr int ROW = 256;                                  // bytes per LDS row: 128 channels of one pixel (both operands)
+  constexpr int RI = 1024 / ROW;                            // 4 rows per DMA instruction
+  constexpr int IA = PK / RI, IB = PK / RI;                 // 8 instructions for the dz tile, 8 per source tile
+  static_assert(IA == NW && IB == NW, "one dz instruction + one per offset for every wave");
+  constexpr int NI = 1 + NOFF;
+  constexpr int TBYTES = PK * ROW;                          // 8 KB per tile
+  constexpr int BUF = (1 + NOFF) * TBYTES;                  // dz tile, then the four source tiles
+
+  constexpr int RING = 3;  // chunk buffers: two chunks in flight behind the one being multiplied (one block per CU: nobody else
+                           // covers a DMA round trip, and a chunk's 16 MFMAs per wave are a fraction of one)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * BUF + RING * (1 + NOFF) * PK * 4];
+  int* tabs = reinterpret_cast<int*>(smem + RING * BUF);  // [RING][NOFF][PK] source-row gather per offset
+  int* taba = tabs + RING * NOFF * PK;                     // [RING][PK] dz-row gather
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  int bid = rs_xcd_remap(blockIdx.x, gridDim.x);
+  const int tco = bid % p.tiles_co;
+  bid /= p.tiles_co;
+  const int tk = bid % p.tiles_k;  // tiles_k = 4 planes x tiles_ci
+  const int split = bid / p.tiles_k;
+  const int plane = tk / p.tiles_ci, tci = tk - plane * p.tiles_ci;
+  const int py = plane >> 1, px = plane & 1;
+  const int co0 = tco * BMo;
+  const int ci0 = tci * BNo;
+
+  const bf16_t* src = p.src1;
+  int Cs = p.C1, cs = ci0;
+  if (ci0 >= p.C1) {
+    src = p.src2;
+    Cs = p.C2;
+    cs = ci0 - p.C1;
+  }
+
+  // (the plan counts 64-pixel chunks)
+  const int chunk0 = split * p.chunks_per_split * (64 / PK);
+  const int total_chunks = (p.M + PK - 1) / PK;
+  int chunk1 = chunk0 + p.chunks_per_split * (64 / PK);
+  if (chunk1 > total_chunks) chunk1 = total_chunks;
+  const int HsWs = p.Hs * p.Ws;
+
+  const int m_first = chunk0 * PK;
+  const int n_first = (int)rs_div((unsigned)m_first, p.div_howo);
+  const long img = (long)p.Hs * p.Ws * Cs;
+  const long dimg = (long)p.Ho * p.Wo * p.Cout;
+  const __amdgpu_buffer_rsrc_t rsrc_dy = wb_make_rsrc(p.dy + n_first * dimg, (long)(p.N - n_first) * dimg * 2);
+  const __amdgpu_buffer_rsrc_t rsrc_x = wb_make_rsrc(src + n_first * img, (long)(p.N - n_first) * img * 2);
+
+  // pixel m = source pixel (n, a, b): dz row (2a + py, 2b + px); source row of offset (r, s): (a - (1 - py) + r, b - (1 - px) + s)
+  auto fill_table = [&](int chunk, int which) __attribute__((always_inline)) {
+    if (tid < (1 + NOFF) * PK) {
+      const int o = tid / PK, i = tid - o * PK;  // o < NOFF: source offset o = 2 r + s;  o == NOFF: the dz rows
+      const int m = chunk * PK + i;
+      int pix = -1;
+      if (m < p.M) {
+        const int n = (int)rs_div((unsigned)m, p.div_howo);
+        const int rem = m - n * HsWs;
+        const int a = (int)rs_div((unsigned)rem, p.div_wo);
+        const int b = rem - a * p.Ws;
+        if (o == NOFF) {
+          pix = ((n - n_first) * p.Ho + 2 * a + py) * p.Wo + 2 * b + px;
+        } else {
+          const int iy = a - (1 - py) + (o >> 1), ix = b - (1 - px) + (o & 1);
+          if (((unsigned)iy < (unsigned)p.Hs) && ((unsigned)ix < (unsigned)p.Ws)) pix = ((n - n_first) * p.Hs + iy) * p.Ws + ix;
+        }
+      }
+      if (o == NOFF) taba[which * PK + i] = pix;
+      else tabs[(which * NOFF + o) * PK + i] = pix;
+    }
+  };
+
+  // DMA roles: piece 0 = rows RI*wave.. of the dz tile, piece 1 + o = the same rows of source tile o.  Lane: row ra of the
+  // instruction, 16-byte position pp, fetching channel piece gp (64-byte pieces XOR-swizzled by the row: swz(R) = R & 3)
+  const int ra = lane >> 4, pp = lane & 15;
+  const int gp = (((pp >> 2) ^ ra) << 2) | (pp & 3);
+  const int cola = (co0 + gp * 8) * 2;
+  const int colb = (cs + gp * 8) * 2;
+  const int cout2 = p.Cout * 2, cs2 = Cs * 2;
+  const unsigned int lds0 = __builtin_amdgcn_readfirstlane(wb_lds_addr(smem));
+  int voff[NI];
+  unsigned int fL = lds0;
+  // (`live` = 0: a chunk past the block's range -- its five pieces are still issued, out of range (zeros into a buffer nobody
+  // reads), so that every wave issues the same number of DMA instructions per step: what the counted waits rely on)
+  auto prepare_dma = [&](int buf, int which, int live) __attribute__((always_inline)) {
+    fL = lds0 + buf * BUF;
+    const int row = RI * wave + ra;
+    const int pa = live ? taba[which * PK + row] : -1;
+    voff[0] = pa >= 0 ? pa * cout2 + cola : -1;
+#pragma unroll
+    for (int o = 0; o < NOFF; ++o) {
+      const int px_ = live ? tabs[(which * NOFF + o) * PK + row] : -1;
+      voff[1 + o] = px_ >= 0 ? px_ * cs2 + colb : -1;
+    }
+  };
+  auto issue_piece = [&](int j) __attribute__((always_inline)) {  // j: compile-time after unrolling
+    if (j == 0) wb_dma16(rsrc_dy, fL + wave * 1024, voff[0]);
+    else wb_dma16(rsrc_x, fL + j * TBYTES + wave * 1024, voff[j]);
+  };
+
+  f32x16 acc[NOFF][TM];
+#pragma unroll
+  for (int o = 0; o < NOFF; ++o)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[o][a][r] = 0.f;
+
+  // operand addressing for ds_read_b64_tr_b16 (as in conv_wgrad_bf16): lane = 16 g + q; group g covers channels 16 (g & 1) .. + 15
+  // of a 32-wide piece and rows 8 (g >> 1) + 4 t + (q >> 2) of a 16-row k-step; lane q addresses row q >> 2, channels 4 (q & 3) ..
+  const int g = lane >> 4, q = lane & 15, jr = q >> 2;
+  const int chb = (16 * (g & 1) + 4 * (q & 3)) * 2;
+  int aoff[TM][2], boff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rr16 = 8 * (g >> 1) + 4 * t + jr;
+    const int rsw = rr16 & 3;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) aoff[tm][t] = rr16 * ROW + (((wm * TM + tm) ^ rsw) * 64) + chb;
+    boff[t] = TBYTES + rr16 * ROW + ((wn ^ rsw) * 64) + chb;
+  }
+
+  constexpr int NMMA = NS * NOFF * TM;  // 16 MFMAs per chunk per wave
+  auto chunk_mma = [&](const unsigned char* L, auto fetch_tag) __attribute__((always_inline)) {
+    constexpr bool FETCH = decltype(fetch_tag)::value;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x8 fa[TM], fb[NOFF];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[tm] = wb_tr_read8(L + aoff[tm][0] + (16 * s) * ROW, L + aoff[tm][1] + (16 * s) * ROW);
+#pragma unroll
+      for (int o = 0; o < NOFF; ++o)
+        fb[o] = wb_tr_read8(L + boff[0] + o * TBYTES + (16 * s) * ROW, L + boff[1] + o * TBYTES + (16 * s) * ROW);
+#pragma unroll
+      for (int o = 0; o < NOFF; ++o)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int i = (s * NOFF + o) * TM + tm;  // MFMA index within the chunk (compile-time after unrolling)
+          if (FETCH && i % 2 == 0 && i / 2 < NI) issue_piece(i / 2);  // the five pieces of the next chunk under the first ten MFMAs
+          acc[o][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[o], acc[o][tm], 0, 0, 0);
+        }
+    }
+    static_assert(NMMA / 2 >= NI, "every piece finds an MFMA to hide behind");
+  };
+  if (chunk0 < chunk1) {
+    fill_table(chunk0, 0);
+    fill_table(chunk0 + 1, 1);
+    fill_table(chunk0 + 2, 2);
+    __syncthreads();
+    prepare_dma(0, 0, 1);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) issue_piece(j);
+    prepare_dma(1, 1, chunk0 + 1 < chunk1);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) issue_piece(j);
+    int slot = 0;  // ring slot of the chunk being multiplied
+    for (int c = chunk0; c < chunk1; ++c) {
+      // chunk c has landed when at most the NI pieces of chunk c + 1 are still in flight; the barrier publishes everybody's
+      // share and frees the slot chunk c - 1 was read from: chunk c + 2 streams into it between this chunk's MFMAs
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      __syncthreads();
+      const int s2 = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3
+      prepare_dma(s2, s2, c + 2 < chunk1);
+      chunk_mma(smem + slot * BUF, std::true_type());
+      fill_table(c + 3, slot);  // (this slot's table was read by prepare_dma two iterations ago)
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    wb_dma_wait();  // (the out-of-range pieces of the last two steps)
+  }
+
+  // D[i][j]: i = cout (tile-local) = (r&3) + 8*(r>>2) + 4*(lane>>5), j = cin (tile-local) = lane&31; offset o -> tap 4 * plane + o
+  float* out = p.out + (long)split * p.Cout * p.K;
+#pragma unroll
+  for (int o = 0; o < NOFF; ++o) {
+    const int kk = (4 * plane + o) * p.Ctot + p.ci_base + ci0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        out[(long)co * p.K + kk] = acc[o][tm][r];
+      }
+  }
+}
+
 struct Plan {
   int bmo, bno, variant, tiles_co, tiles_ci, taps, tiles_k, splits, chunks_per_split, pk, phase;
+  int phase4;  // the 128 x 128 launch of a phase-form layer runs conv_wgrad_phase4_bf16 (one plane x four offsets per block)
   // two-source layers whose sources allow different Cin tile widths (dec3: 256 + 64 channels) run one launch per source,
   // each with its own widest tile (128-wide tiles feed twice the MFMAs per LDS-DMA byte of 64-wide ones): bno2 != 0
   int bno2, variant2, tiles_ci2;
@@ -409,7 +611,10 @@ Plan plan(const rs_conv_desc* d) {
   pl.K = (long)pl.taps * (d->C1 + d->C2);
   pl.tiles_co = d->Cout / pl.bmo;
   pl.tiles_k = pl.taps * pl.tiles_ci;
-  const long tiles = (long)pl.tiles_co * pl.taps * (pl.tiles_ci + pl.tiles_ci2);
+  // conv_wgrad_phase4_bf16 (round 5): the phase form's 128 x 128 launches -- a quarter of the blocks, four products each
+  pl.phase4 = (pl.phase && pl.variant == V128x128 && rs_knobs().wgrad_phase4 != 0) ? 1 : 0;
+  const long tiles = pl.phase4 ? (long)pl.tiles_co * 4 * pl.tiles_ci  // (a second, narrower source follows the split count of the first)
+                               : (long)pl.tiles_co * pl.taps * (pl.tiles_ci + pl.tiles_ci2);
   pl.pk = 64;  // pixels per chunk (32 was measured for the short reductions: no gain)
   const int PK = pl.pk;
   const long chunks = (M + PK - 1) / PK;
@@ -421,7 +626,7 @@ Plan plan(const rs_conv_desc* d) {
   // at 512 and 26.1 at the former 1024).  Round 5 (profiles/r05/wgrad_blocks_bf16.txt, median step): 22.64-22.70 ms at 256,
   // 22.51 / 22.52 at 192 / 128, 22.72 at 384 -> 192.  The phase form's 16-tap launches are long reductions and want more, shorter
   // blocks (1024 / 1536 / 2048: the same step time).
-  const long target = pl.phase ? rs_knobs().wgrad_blocks_phase : rs_knobs().wgrad_blocks;
+  const long target = pl.phase4 ? rs_knobs().wgrad_blocks_phase4 : (pl.phase ? rs_knobs().wgrad_blocks_phase : rs_knobs().wgrad_blocks);
   long s = (target + tiles - 1) / tiles;          // aim at >= `target` blocks ...
   const long smax = (chunks * PK / 64 + 7) / 8;   // ... of at least 512 pixels each
   if (s > smax) s = smax;
@@ -537,7 +742,10 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
     }
     a.tiles_k = pl.taps * a.tiles_ci;
     const int grid = pl.tiles_co * a.tiles_k * pl.splits;
-    if (pl.phase) {
+    if (pl.phase4 && variant == V128x128) {
+      a.tiles_k = 4 * a.tiles_ci;  // planes x Cin tiles
+      conv_wgrad_phase4_bf16<<<pl.tiles_co * a.tiles_k * pl.splits, 512, 0, s>>>(a);
+    } else if (pl.phase) {
       switch (variant) {
         case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;
         case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, true><<<grid, 256, 0, s>>>(a); break;

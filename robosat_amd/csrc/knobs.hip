@@ -33,6 +33,8 @@ const Entry kEntries[] = {
     {"wgrad_f32_blocks", "RS_WGRAD_F32_BLOCKS", &RsKnobs::wgrad_f32_blocks},
     {"wgrad_blocks", "RS_WGRAD_BLOCKS", &RsKnobs::wgrad_blocks},
     {"wgrad_blocks_phase", "RS_WGRAD_BLOCKS_PHASE", &RsKnobs::wgrad_blocks_phase},
+    {"wgrad_phase4", "RS_WGRAD_PHASE4", &RsKnobs::wgrad_phase4},
+    {"wgrad_blocks_phase4", "RS_WGRAD_BLOCKS_PHASE4", &RsKnobs::wgrad_blocks_phase4},
     {"lovasz_xcd", "RS_LOVASZ_XCD", &RsKnobs::lovasz_xcd},
     {"wino_wide", "ROBOSAT_WINO_WIDE", &RsKnobs::wino_wide},
 };

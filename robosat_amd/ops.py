@@ -668,7 +668,9 @@ def wgrad_kernel_name(d, form=None):
     if t <= 0:
         raise ValueError("rs_conv2d_wgrad_bf16_tile: invalid arguments")
     tile = "{}x{}".format(t >> 16, t & 255) + ("+{}x{}".format(t >> 16, (t >> 8) & 255) if (t >> 8) & 255 else "")
-    return "conv_wgrad_bf16<{}{}>".format("phase," if form == 2 else "", tile)
+    # phase form: its 128 x 128 launch is conv_wgrad_phase4_bf16 (one dz plane x four source offsets per block) unless knob wgrad_phase4 = 0
+    phase = "" if form != 2 else ("phase4," if (t >> 16, t & 255) == (128, 128) and get_knob("wgrad_phase4") else "phase,")
+    return "conv_wgrad_bf16<{}{}>".format(phase, tile)
 
 
 def stem_conv_wgrad_bf16(dy, x4):

@@ -52,6 +52,8 @@ def bench_name(k):
     m = re.search(r"conv_wgrad_thin_bf16<(\d+), (\d)>", k)
     if m:
         return "conv_wgrad_thin_bf16<{}{}>".format(32 * int(m.group(1)), ",ups" if m.group(2) == "1" else "")
+    if "conv_wgrad_phase4_bf16" in k:
+        return "conv_wgrad_bf16<phase4,128x128>"
     m = re.search(r"conv_wgrad_bf16<(\d+), (\d+), \d+, \d+, \d+, (true|false)>", k)
     if m:  # (a two-launch layer -- "128x128+128x64" in the bench's name -- is looked up by its first tile)
         return "conv_wgrad_bf16<{}{}x{}>".format("phase," if m.group(3) == "true" else "", m.group(1), m.group(2))

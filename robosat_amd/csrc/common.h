@@ -168,10 +168,11 @@ struct RsKnobs {
   int wgrad_f32_phase = 1;     // RS_WGRAD_F32_PHASE: fp32 DecoderBlock weight gradient in phase form (0: direct form)
   int wgrad_f32_dma = -1;      // RS_WGRAD_F32_DMA: fp32 weight gradient by LDS-DMA (conv_wgrad_f32_dma.hip): -1 by rule, 0 never, 1 wherever it can run
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
-  int wgrad_blocks = 192;      // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches
+  int wgrad_blocks = 96;       // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
   int wgrad_phase4 = 1;        // RS_WGRAD_PHASE4: the phase form's 128 x 128 launches as one plane x four offsets per block (0: a block per pair)
   int wgrad_blocks_phase4 = 256;  // RS_WGRAD_BLOCKS_PHASE4: block target of those launches (8-wave blocks, one per CU)
+  int wgrad_ring = 3;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel (3: two chunks in flight, counted waits; 2: one)
   int lovasz_xcd = 1;          // RS_LOVASZ_XCD: the Lovasz gradient scatter keeps an image's blocks on one XCD (0: natural order)
   int wino_wide = 1;           // ROBOSAT_WINO_WIDE: the 128 x 64 block of the fp32 Winograd DecoderBlock kernel
 };

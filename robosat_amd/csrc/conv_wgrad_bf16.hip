@@ -101,8 +101,13 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
 // (4/9 of the multiply-adds; dz rows are then gathered too: a second table), and combine_phase_wgrad_kernel adds the four
 // G's that make up each filter tap: dW[ky][kx] = sum_{(py,r) : ky in S(py,r)} sum_{(px,s) : kx in S(px,s)} G, with
 // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2} (the taps that hit the same source pixel).
-template <int BMo, int BNo, int WGM, int WGN, int PK, bool PHASE>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wgrad_bf16(const WgradArgsB p) {
+// RING = chunk buffers.  2: one chunk streams in while one is multiplied, the wave drains its DMA queue before every barrier
+// (two or more blocks per CU cover each other's round trips).  3 (round 5): the tap-per-block launches run ONE block per CU
+// (knob wgrad_blocks = 192) and a chunk's MFMAs are a fraction of a DMA round trip, so every chunk paid one; with two chunks in
+// flight behind the one being multiplied and counted waits (s_waitcnt vmcnt(NI): "all but the newest chunk's pieces have
+// landed") the block keeps its CU's LDS-DMA path busy by itself.
+template <int BMo, int BNo, int WGM, int WGN, int PK, bool PHASE, int RING = 2>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2) void conv_wgrad_bf16(const WgradArgsB p) {
   constexpr int NW = WGM * WGN;          // waves
   constexpr int NS = PK / 16;            // MFMA k-steps per chunk
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
@@ -117,9 +122,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wg
   constexpr int BUF = ABYTES + BBYTES;
   static_assert(TM >= 1 && TN >= 1 && (IA % NW) == 0 && (IB % NW) == 0, "bad tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + (PHASE ? 4 : 2) * PK * 4];
-  int* tabs = reinterpret_cast<int*>(smem + 2 * BUF);  // [2][PK] input-row gather
-  int* taba = tabs + 2 * PK;                            // [2][PK] dz-row gather (PHASE only)
+  static_assert(RING >= 2 && (RING - 2) * NI <= 63, "vmcnt is a 6-bit count");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * BUF + (PHASE ? 2 : 1) * RING * PK * 4];
+  int* tabs = reinterpret_cast<int*>(smem + RING * BUF);  // [RING][PK] input-row gather
+  int* taba = tabs + RING * PK;                            // [RING][PK] dz-row gather (PHASE only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -211,7 +217,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wg
   // wave 60-180 cycles of issue; a burst at the top of the chunk puts that on every wave's critical path at once).
   int voff[NI];
   unsigned int fL = lds0;
-  auto prepare_dma = [&](int chunk, int buf, int which) __attribute__((always_inline)) {
+  // (`live` = false, RING > 2 only: a chunk past the block's range -- its pieces are still issued, out of range (zeros into a
+  // buffer nobody reads), so that every wave issues the same number of DMA instructions per step: what the counted waits rely on)
+  auto prepare_dma = [&](int chunk, int buf, int which, bool live = true) __attribute__((always_inline)) {
     fL = lds0 + buf * BUF;
     int pix[NI];
 #pragma unroll
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wg
       } else {
         voff[j] = pix[j] >= 0 ? pix[j] * cs2 + colb : -1;
       }
+      if (RING > 2 && !live) voff[j] = -1;
     }
   };
   auto issue_piece = [&](int j) __attribute__((always_inline)) {
@@ -293,7 +302,32 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN > 4 ? 1 : 2) void conv_wg
       for (int q = PIN; q < NI; ++q) issue_piece(q);
     }
   };
-  if (chunk0 < chunk1) {
+  if (RING > 2) {
+    if (chunk0 < chunk1) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) fill_table(chunk0 + r, r);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RING - 1; ++r) {
+        prepare_dma(chunk0 + r, r, r, chunk0 + r < chunk1);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) issue_piece(q);
+      }
+      int slot = 0;  // ring slot of the chunk being multiplied
+      for (int c = chunk0; c < chunk1; ++c) {
+        // chunk c has landed when at most the pieces of the RING - 2 chunks behind it are still in flight; the barrier publishes
+        // everybody's share and frees the slot chunk c - 1 was read from: chunk c + RING - 1 streams into it between the MFMAs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NI) : "memory");
+        __syncthreads();
+        const int s2 = slot == 0 ? RING - 1 : slot - 1;
+        prepare_dma(c + RING - 1, s2, s2, c + RING - 1 < chunk1);
+        chunk_mma(smem + slot * BUF, std::true_type());
+        fill_table(c + RING, slot);  // (this slot's table was read by prepare_dma RING - 1 iterations ago)
+        slot = slot == RING - 1 ? 0 : slot + 1;
+      }
+      wb_dma_wait();  // (the out-of-range pieces of the last steps)
+    }
+  } else if (chunk0 < chunk1) {
     fill_table(chunk0, 0);
     fill_table(chunk0 + 1, 1);
     __syncthreads();
@@ -624,8 +658,10 @@ Plan plan(const rs_conv_desc* d) {
   // block is prologue + few chunks + a 64 KB partial tile, and every extra split is another partial to write and reduce),
   // but one block per CU (256) leaves room for the main stream's kernels and gives the shortest step (25.3-25.4 ms vs 25.6
   // at 512 and 26.1 at the former 1024).  Round 5 (profiles/r05/wgrad_blocks_bf16.txt, median step): 22.64-22.70 ms at 256,
-  // 22.51 / 22.52 at 192 / 128, 22.72 at 384 -> 192.  The phase form's 16-tap launches are long reductions and want more, shorter
-  // blocks (1024 / 1536 / 2048: the same step time).
+  // 22.51 / 22.52 at 192 / 128, 22.72 at 384 -> 192.  With the ring of three chunk buffers (RING = 3: a lone block keeps its CU's
+  // LDS-DMA path busy; the launches are 15-30 % shorter in isolation) fewer, longer blocks are the better neighbours: 22.20-22.31
+  // at 96-112 against 22.32-22.39 for two buffers at 192, five alternating pairs (profiles/r05/wgrad_ring.txt) -> 96.  The phase
+  // form's 16-tap launches are long reductions and want more, shorter blocks (1024 / 1536 / 2048: the same step time).
   const long target = pl.phase4 ? rs_knobs().wgrad_blocks_phase4 : (pl.phase ? rs_knobs().wgrad_blocks_phase : rs_knobs().wgrad_blocks);
   long s = (target + tiles - 1) / tiles;          // aim at >= `target` blocks ...
   const long smax = (chunks * PK / 64 + 7) / 8;   // ... of at least 512 pixels each
@@ -727,6 +763,7 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   // one launch, or one per concat source (Plan::bno2): each sees "its" source as a single-source problem whose channels
   // start at ci_base inside the concat
   const int nseg = pl.bno2 ? 2 : 1;
+  const bool ring3 = rs_knobs().wgrad_ring == 3;  // (tap-per-block launches only: the phase form runs several blocks per CU)
   for (int seg = 0; seg < nseg; ++seg) {
     int variant = pl.variant;
     a.ci_base = 0;
@@ -757,13 +794,28 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
       }
     } else {
       switch (variant) {
-        case V128x128: conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-        case V128x64: conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-        case V64x128: conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
-        case V64x64: conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a); break;
+        case V128x128:
+          if (ring3) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          else conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
+          break;
+        case V128x64:
+          if (ring3) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          else conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
+          break;
+        case V64x128:
+          if (ring3) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          else conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
+          break;
+        case V64x64:
+          if (ring3) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          else conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
+          break;
         case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;
         case V32x32: conv_wgrad_bf16<32, 32, 1, 1, 64, false><<<grid, 64, 0, s>>>(a); break;
-        case V256x128: conv_wgrad_bf16<256, 128, 4, 2, 64, false><<<grid, 512, 0, s>>>(a); break;
+        case V256x128:
+          if (ring3) conv_wgrad_bf16<256, 128, 4, 2, 64, false, 3><<<grid, 512, 0, s>>>(a);
+          else conv_wgrad_bf16<256, 128, 4, 2, 64, false><<<grid, 512, 0, s>>>(a);
+          break;
         default: return RS_EINVAL;
       }
     }

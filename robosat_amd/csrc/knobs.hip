@@ -35,6 +35,7 @@ const Entry kEntries[] = {
     {"wgrad_blocks_phase", "RS_WGRAD_BLOCKS_PHASE", &RsKnobs::wgrad_blocks_phase},
     {"wgrad_phase4", "RS_WGRAD_PHASE4", &RsKnobs::wgrad_phase4},
     {"wgrad_blocks_phase4", "RS_WGRAD_BLOCKS_PHASE4", &RsKnobs::wgrad_blocks_phase4},
+    {"wgrad_ring", "RS_WGRAD_RING", &RsKnobs::wgrad_ring},
     {"lovasz_xcd", "RS_LOVASZ_XCD", &RsKnobs::lovasz_xcd},
     {"wino_wide", "ROBOSAT_WINO_WIDE", &RsKnobs::wino_wide},
 };

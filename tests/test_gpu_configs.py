@@ -8,9 +8,10 @@ inferred:
               oracle on the same seeded weights / batch: loss within 2 %, decoder + head gradients cosine >= 0.98, every
               gradient finite, mean cosine over all 168 tensors reported and held to >= 0.90;
 
-  configs[3]  rs predict 1024x1024 3-band tiles, bs 8, fp32      -> oracle parity on one 1024^2 tile (the CPU oracle needs
-              ~15 s per such tile) + the size-independent property that a tile's probabilities do not depend on its
-              batch neighbours (bs 8 vs bs 1, bit-for-bit: every output pixel's reduction order is fixed by the kernel);
+  configs[3]  rs predict 1024x1024 3-band tiles, bs 8, fp32      -> oracle parity on three of the eight 1024^2 tiles (the
+              CPU oracle needs ~15 s per such tile) + the size-independent property that a tile's probabilities do not
+              depend on its batch neighbours (bs 8 vs bs 1, bit-for-bit, all eight tiles: every output pixel's reduction
+              order is fixed by the kernel);
   configs[4]  4-band (RGB+IR) multi-class (4 classes) train with the Lovasz loss -> one full fp32 training step against
               the CPU oracle on the same seeded weights (loss, logits, every parameter gradient) at 2 x 4 x 128^2, and the
               configuration AS BASELINE WORDS IT -- bs 32, 4 x 512^2, 4 classes, bf16 -- as one training step against the
@@ -45,11 +46,12 @@ def test_cfg4_predict_1024_bs8():
     x = seeded.synthetic_images(8, 3, 1024, 1024, seed=9)
     got8 = net.predict_probs(x.to(DEV))
     assert got8.shape == (8, 2, 1024, 1024)
-    want0 = R.predict_probs(ref, x[:1])  # one tile through the CPU oracle
-    err = float((got8[:1].cpu() - want0).abs().max())
-    print("cfg4 1024^2: max|dprob| vs oracle", err)
+    pick = [0, 3, 7]  # three of the eight tiles through the CPU oracle (~15 s each), the first, a middle one and the last
+    want = R.predict_probs(ref, x[pick])
+    err = float((got8[pick].cpu() - want).abs().max())
+    print("cfg4 1024^2: max|dprob| vs oracle over tiles", pick, err)
     assert err <= 1e-3  # north_star tolerance (fp32)
-    for i in (0, 3, 7):  # batch independence: same numbers whether the tile travels alone or in a batch of 8
+    for i in range(8):  # batch independence, EVERY tile: same numbers whether it travels alone or in the batch of 8
         got1 = net.predict_probs(x[i:i + 1].to(DEV))
         assert torch.equal(got1[0], got8[i]), i
     s = got8.sum(1)

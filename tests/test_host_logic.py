@@ -195,6 +195,8 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_thin_bf16<1>((anonymous namespace)::ThinConvArgs)": "conv_thin_bf16<phase>",
         ns + "conv_wgrad_thin_bf16<4, 1>((anonymous namespace)::ThinArgs)": "conv_wgrad_thin_bf16<128,ups>",
         ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",
+        ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false, 3>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",
+        ns + "conv_wgrad_bf16<128, 64, 2, 2, 64, true, 2>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase,128x64>",
         ns + "conv_wgrad_bf16<128, 128, 2, 2, 64, true>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase,128x128>",
         "(anonymous namespace)::conv_wgrad_phase4_bf16((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase4,128x128>",
         "_ZN12_GLOBAL__N_122conv_wgrad_phase4_bf16ENS_10WgradArgsBE": "conv_wgrad_bf16<phase4,128x128>",

@@ -546,3 +546,33 @@ def test_bench_line_and_rank_environment_at_eight_ranks(tmp_path, monkeypatch):
     assert line["n_gpus"] == 8 and line["train"]["reducer"] == full["train"]["reducer"]
     assert line["roofline"]["conv3x3"]["frac"] == 0.64 and "what" not in line["train"]["roofline"]["conv3x3"]
     assert line["train"]["config"]["parallelism"].startswith("dp")
+
+
+def test_every_knob_is_documented_with_its_default():
+    """robosat_amd/csrc/knobs.hip is the ONE table of measurement switches; INTEGRATION.md's knob table is what
+    a maintainer reads.  Pin the two against each other -- every (name, environment seed) pair of the library appears in the
+    document's table, in a row whose default column carries the value the library reports (rs_get_knob on a fresh table; no
+    GPU involved) -- and that the Python side refuses names the library does not know."""
+    import ctypes
+    import re
+
+    from robosat_amd import _lib
+
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(here, "robosat_amd", "csrc", "knobs.hip")).read()
+    pairs = re.findall(r'\{"(\w+)", "(\w+)", &RsKnobs::(\w+)\}', src)
+    assert len(pairs) >= 20 and all(name == field for name, _, field in pairs)
+    rows = [r for r in open(os.path.join(here, "INTEGRATION.md")).read().splitlines() if r.startswith("| `")]
+    lib = _lib.lib()
+    for name, env, _ in pairs:
+        assert env not in os.environ, env + " is set: this test reads the defaults"
+        row = [r for r in rows if "`{}`".format(name) in r.split("|")[1]]
+        assert len(row) == 1, name
+        cells = [c.strip() for c in row[0].split("|")[1:-1]]
+        names = re.findall(r"`(\w+)`", cells[0])
+        assert re.findall(r"`(\w+)`", cells[1])[names.index(name)] == env, (name, env)
+        value = ctypes.c_int(12345)
+        assert lib.rs_get_knob(name.encode(), ctypes.byref(value)) == 0
+        assert int(cells[2].split(",")[names.index(name)]) == value.value, (name, cells[2], value.value)
+    assert lib.rs_get_knob(b"no_such_knob", ctypes.byref(ctypes.c_int())) != 0
+    assert lib.rs_set_knob(b"no_such_knob", 1) != 0

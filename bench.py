@@ -44,6 +44,12 @@ PREWARM_SLEEP_S = 0.3 if PREWARM_STEPS > 0 else 0.0
 # was seen to run its first six timed steps at 22-40 ms instead of 21.7 (profiles/r05/bench_settle.txt): clocks and queues
 # come back over more steps than a fixed warm-up covers on some boxes.  Steady-state throughput is what is measured.
 SETTLE_MAX = int(os.environ.get("ROBOSAT_BENCH_SETTLE", "40"))
+# Host flow control inside the timed loop: before issuing step i the host waits for step i - RUNAHEAD to have finished on the
+# device (0 = never waits).  The host issues a train step in half the time the device takes, so an unthrottled loop gets
+# further ahead than any warm-up did, the caching allocator runs out of blocks whose side-stream events have completed and
+# grows -- hipMalloc inside the timed region, 15-20 ms each time (profiles/r05/bench_settle.txt).  With two steps queued the
+# device never idles; the reference's own loop synchronises EVERY step (`loss.item()`, train.py:190).
+RUNAHEAD = int(os.environ.get("ROBOSAT_BENCH_RUNAHEAD", "2"))
 EMPTY_CACHE_BETWEEN_LEGS = os.environ.get("ROBOSAT_BENCH_EMPTY_CACHE", "0") == "1"
 
 
@@ -442,11 +448,15 @@ def run_phase(leg, steps, warmup, device, dist, rank, no_parity=False, grad_dtyp
         t0 = time.perf_counter()
         last = None
         marks[0].record()
+        allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
         for i in range(steps):
+            if RUNAHEAD > 0 and i >= RUNAHEAD:
+                marks[i + 1 - RUNAHEAD].synchronize()  # (end of step i - RUNAHEAD)
             last = timed()
             marks[i + 1].record()
         barrier()
         el = time.perf_counter() - t0
+        run_phase.device_allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0
     finally:
         if gc_was_on:
             gc.enable()
@@ -735,7 +745,8 @@ def main():
         line = {
             "metric": "512x512 tiles/sec train+predict, 1/2/4/8 MI355X; mIoU vs CPU ref",
             "value": round(world * main_leg.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "prewarm": {"steps": PREWARM_STEPS, "sleep_s": PREWARM_SLEEP_S, "settle_max": SETTLE_MAX, "settle_steps": run_phase.settle_steps,
+            "warmup": args.warmup, "prewarm": {"steps": PREWARM_STEPS, "sleep_s": PREWARM_SLEEP_S, "settle_max": SETTLE_MAX, "settle_steps": run_phase.settle_steps, "runahead": RUNAHEAD,
+                                               "device_allocs_in_timed_steps": run_phase.device_allocs,
                                                "what": "untimed, every leg: `steps` steps + a pause before the W warm-up steps (allocator growth, queue restore), then up to `settle_max` more until three in a row are within 5 % of the fastest (`settle_steps` = how many this leg took)"},
             "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(step_ms),
             "hipgraph": hipgraph,
@@ -769,6 +780,7 @@ def main():
                              # tiles/s at the MEDIAN step time: what the leg sustains when no step stalls (`value` is the mean)
                              "value_median": round(world * tleg.batch / step_stats(tstep_ms)["median"] * 1e3, 2), "dtype": "bf16",
                              "hipgraph": tgraph, "peak_hbm_gb": run_phase.peak_gb, "settle_steps": run_phase.settle_steps,
+                             "device_allocs_in_timed_steps": run_phase.device_allocs,
                              "scaling": args.scaling, "config": workload(tleg, world, baseline_config(tleg)),
                              "roofline": troof, "parity": tparity()}
             if reducer_record() is not None:  # which exchange ran inside the timed steps

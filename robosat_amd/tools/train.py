@@ -314,7 +314,16 @@ def _epoch_loop(loader, num_classes, device, net, criterion, master, optimizer, 
     """The batches of one pass; returns the number of samples seen (``running_loss`` and ``metrics`` accumulate in place)."""
 
     num_samples = 0
+    # Host flow control: at most two batches queued behind the one the device is working on.  The host issues a step in half the
+    # time the device takes; unthrottled (a loader that keeps up, or cached tiles) it gets dozens of steps ahead, the caching
+    # allocator runs out of blocks whose side-stream events have completed and grows in the middle of the epoch -- hipMalloc
+    # stalls of 15-20 ms (profiles/r05/bench_settle.txt).  The reference's loop synchronises every step (`loss.item()`,
+    # train.py:190); two steps of slack never idle the device.
+    fence = []
     for images, masks, tiles in tqdm(loader, desc=desc, unit="batch", ascii=True, disable=not master):
+        if device.type == "cuda":
+            if len(fence) >= 2:
+                fence.pop(0).synchronize()
         images = images.to(device, non_blocking=True)
         masks = masks.to(device, non_blocking=True)
 
@@ -339,6 +348,9 @@ def _epoch_loop(loader, num_classes, device, net, criterion, master, optimizer, 
 
         running_loss += loss.detach()  # stays on the device: no per-step host sync
         metrics.add_batch(masks, outputs.detach())
+        if device.type == "cuda":
+            fence.append(torch.cuda.Event())
+            fence[-1].record()
 
     return num_samples
 

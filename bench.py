@@ -747,7 +747,7 @@ def main():
             "value": round(world * main_leg.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "prewarm": {"steps": PREWARM_STEPS, "sleep_s": PREWARM_SLEEP_S, "settle_max": SETTLE_MAX, "settle_steps": run_phase.settle_steps, "runahead": RUNAHEAD,
                                                "device_allocs_in_timed_steps": run_phase.device_allocs,
-                                               "what": "untimed, every leg: `steps` steps + a pause before the W warm-up steps (allocator growth, queue restore), then up to `settle_max` more until three in a row are within 5 % of the fastest (`settle_steps` = how many this leg took)"},
+                                               "what": "untimed, every leg: `steps` steps + a pause, gc, W warm-up steps, then <= `settle_max` more until 3 in a row are within 5 % of the fastest; timed loop keeps <= `runahead` steps queued"},
             "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(step_ms),
             "hipgraph": hipgraph,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,

@@ -170,7 +170,7 @@ struct RsKnobs {
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
   int wgrad_blocks = 96;       // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
-  int wgrad_phase4 = 1;        // RS_WGRAD_PHASE4: the phase form's 128 x 128 launches as one plane x four offsets per block (0: a block per pair)
+  int wgrad_phase4 = 0;        // RS_WGRAD_PHASE4: 1 = the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step); OFF: dec3's gradient was not bit-reproducible between an eager step and its hipGraph replay with it (profiles/r05/wgrad_phase4.txt)
   int wgrad_blocks_phase4 = 256;  // RS_WGRAD_BLOCKS_PHASE4: block target of those launches (8-wave blocks, one per CU)
   int wgrad_ring = 3;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel (3: two chunks in flight, counted waits; 2: one)
   int lovasz_xcd = 1;          // RS_LOVASZ_XCD: the Lovasz gradient scatter keeps an image's blocks on one XCD (0: natural order)

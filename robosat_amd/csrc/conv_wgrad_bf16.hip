@@ -645,7 +645,8 @@ Plan plan(const rs_conv_desc* d) {
   pl.K = (long)pl.taps * (d->C1 + d->C2);
   pl.tiles_co = d->Cout / pl.bmo;
   pl.tiles_k = pl.taps * pl.tiles_ci;
-  // conv_wgrad_phase4_bf16 (round 5): the phase form's 128 x 128 launches -- a quarter of the blocks, four products each
+  // conv_wgrad_phase4_bf16 (round 5; opt-in, knob wgrad_phase4 = 1): the phase form's 128 x 128 launches -- a quarter of the blocks, four
+  // products each.  Not the default: see the note at RsKnobs::wgrad_phase4.
   pl.phase4 = (pl.phase && pl.variant == V128x128 && rs_knobs().wgrad_phase4 != 0) ? 1 : 0;
   const long tiles = pl.phase4 ? (long)pl.tiles_co * 4 * pl.tiles_ci  // (a second, narrower source follows the split count of the first)
                                : (long)pl.tiles_co * pl.taps * (pl.tiles_ci + pl.tiles_ci2);

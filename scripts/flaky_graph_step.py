@@ -1,0 +1,59 @@
+"""Bisect for tests/test_gpu_train_step.py::test_graphed_train_step_is_the_eager_step[bf16-Lovasz] (failed once in the round-5 closing
+suite, passed in the one before on the same kernels): the test's seven steps, eager and graphed, several times per knob setting;
+prints which runs differ from the first eager run of the setting, at which step the loss first differs and which parameters."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from oracle import robosat_ref as R, seeded
+from robosat_amd import losses, ops
+from robosat_amd.graph import TrainStepGraph
+from robosat_amd.unet import UNet
+
+DEV = "cuda:0"
+init = seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 9)
+batches = [(seeded.synthetic_images(2, 3, 128, 192, 40 + i).to(DEV), seeded.synthetic_targets(2, 2, 128, 192, 40 + i).to(DEV)) for i in range(6)]
+odd = (seeded.synthetic_images(1, 3, 64, 64, 77).to(DEV), seeded.synthetic_targets(1, 2, 64, 64, 77).to(DEV))
+order = batches[:4] + [odd] + batches[4:]
+
+
+def run(graphed):
+    net = UNet(2, pretrained=False, compute_dtype="bf16")
+    net.load_state_dict(init)
+    net = net.to(DEV).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)
+    crit = losses.LovaszLoss2d().to(DEV)
+    stepper = TrainStepGraph(net, crit, opt, warmup=2, enabled=graphed)
+    ls, snaps = [], []
+    for x, t in order:
+        loss, _ = stepper(x, t)
+        ls.append(float(loss))
+        snaps.append({k: v.detach().clone() for k, v in net.named_parameters()})
+    torch.cuda.synchronize()
+    return ls, snaps
+
+
+def diff(a, b):
+    la, sa = a
+    lb, sb = b
+    first = next((i for i, (x, y) in enumerate(zip(la, lb)) if x != y), None)
+    pstep = next((i for i, (x, y) in enumerate(zip(sa, sb)) if any(not torch.equal(x[k], y[k]) for k in x)), None)
+    names = [] if pstep is None else [k for k in sa[pstep] if not torch.equal(sa[pstep][k], sb[pstep][k])]
+    return first, pstep, names[:6], len(names)
+
+
+settings = [{}, {"wgrad_ring": 2}, {"wgrad_phase4": 0}, {"lovasz_xcd": 0}, {"wgrad_ring": 2, "wgrad_phase4": 0, "wgrad_blocks": 192}]
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for st in settings:
+    for k, v in st.items():
+        ops.set_knob(k, v)
+    base = run(False)
+    out = []
+    for r in range(reps):
+        for g in (False, True):
+            out.append(("graph" if g else "eager", diff(base, run(g))))
+    print(st or "default", [(n, d[0], d[1], d[3], d[2][:3]) for n, d in out if d[0] is not None or d[1] is not None] or "all equal", flush=True)
+    for k in st:
+        ops.set_knob(k, {"wgrad_ring": 3, "wgrad_phase4": 1, "lovasz_xcd": 1, "wgrad_blocks": 96}[k])

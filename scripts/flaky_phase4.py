@@ -1,0 +1,46 @@
+"""Determinism screen of the phase-form weight gradient on dec3-like shapes (see scripts/flaky_graph_step.py)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from robosat_amd import ops
+
+DEV, BF = "cuda:0", torch.bfloat16
+g = torch.Generator(device=DEV).manual_seed(3)
+side = torch.cuda.Stream()
+buf = torch.ones(64 << 20, device=DEV)
+
+
+def screen(n, c1, c2, cout, h, w, rounds=200, noise=True, **knobs):
+    for k, v in knobs.items():
+        ops.set_knob(k, v)
+    bad = 0
+    where = set()
+    for r in range(rounds):
+        a = torch.randn(n, h, w, c1, device=DEV, generator=g).to(BF)
+        b = torch.randn(n, h, w, c2, device=DEV, generator=g).to(BF) if c2 else None
+        dz = torch.randn(n, 2 * h, 2 * w, cout, device=DEV, generator=g).to(BF)
+        if noise:
+            with torch.cuda.stream(side):
+                buf.mul_(1.0001)
+        one = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
+        two = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
+        if not torch.equal(one, two):
+            bad += 1
+            d = (one != two).nonzero()
+            where |= {(int(i[3]) // 64) for i in d[:50]}  # which 64-channel slab of Cin
+    for k in knobs:
+        ops.set_knob(k, {"wgrad_phase4": 1, "wgrad_blocks_phase4": 256, "wgrad_blocks_phase": 1536}[k])
+    print((n, c1, c2, cout, h, w), knobs, "noise" if noise else "quiet", "unequal rounds:", bad, "of", rounds, "cin slabs:", sorted(where), flush=True)
+
+
+screen(2, 256, 64, 128, 32, 48)
+screen(2, 256, 64, 128, 32, 48, noise=False)
+screen(2, 256, 0, 128, 32, 48)
+screen(2, 256, 64, 128, 32, 48, wgrad_phase4=0)
+screen(2, 256, 128, 128, 32, 48)
+screen(2, 256, 64, 128, 32, 48, wgrad_blocks_phase4=8)
+screen(32, 256, 64, 128, 128, 128, rounds=20)
+screen(2, 1024, 256, 256, 8, 12)

@@ -205,8 +205,8 @@ def test_wgrad_bf16_upsample_concat(n, c1, c2, cout, h, w):
     close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
     from robosat_amd import _lib
     d = _lib.ConvDesc(n, h, w, c1, c2, 1, 3, 3, 1, 1, 2 * h, 2 * w, cout, 0, 0)
-    expected = {(128, 64, 64): "conv_wgrad_bf16<phase,64x128+64x64>", (256, 0, 128): "conv_wgrad_bf16<phase4,128x128>",
-                (64, 64, 256): "conv_wgrad_bf16<phase,128x64>", (256, 64, 128): "conv_wgrad_bf16<phase4,128x128+128x64>",
+    expected = {(128, 64, 64): "conv_wgrad_bf16<phase,64x128+64x64>", (256, 0, 128): "conv_wgrad_bf16<phase,128x128>",
+                (64, 64, 256): "conv_wgrad_bf16<phase,128x64>", (256, 64, 128): "conv_wgrad_bf16<phase,128x128+128x64>",
                 (512, 256, 64): "conv_wgrad_bf16<phase,64x128>"}
     assert ops.wgrad_kernel_name(d) == expected[(c1, c2, cout)]
 
@@ -214,10 +214,10 @@ def test_wgrad_bf16_upsample_concat(n, c1, c2, cout, h, w):
 @pytest.mark.parametrize("n,c1,c2,cout,h,w", [(1, 256, 0, 128, 9, 7), (3, 256, 128, 256, 9, 13), (2, 256, 64, 128, 16, 16), (4, 128, 0, 128, 32, 32)])
 def test_wgrad_bf16_phase_form_four_offsets_per_block(n, c1, c2, cout, h, w):
     """conv_wgrad_phase4_bf16 (round 5: a block owns one dz parity plane and all four of its source offsets -- the dz tile is
-    fetched once for four products; what the phase form's 128 x 128 launches run) against autograd on the reference
-    formulation (unet.py:63-73) and against the block-per-pair kernel on the same launch (knob ``wgrad_phase4`` = 0): ragged
+    fetched once for four products; knob ``wgrad_phase4`` = 1, not the default) against autograd on the reference
+    formulation (unet.py:63-73) and against the block-per-pair kernel on the same launch (the default): ragged
     32-pixel chunks, splits that straddle images, two sources incl. a narrower second one, image borders on every side."""
-    from robosat_amd import ops
+    from robosat_amd import _lib, ops
 
     a = q(rnd(n, c1, h, w, seed=24))
     b = q(rnd(n, c2, h, w, seed=25)) if c2 else None
@@ -228,10 +228,12 @@ def test_wgrad_bf16_phase_form_four_offsets_per_block(n, c1, c2, cout, h, w):
     y.backward(gy)
     args = (nhwc(gy), nhwc(a), 3, 3)
     kw = dict(src2=nhwc(b) if c2 else None, ups=1, pad=1)
-    assert ops.get_knob("wgrad_phase4") == 1
-    new = ops.conv2d_wgrad(*args, **kw)
-    with ops.knob("wgrad_phase4", 0):
-        old = ops.conv2d_wgrad(*args, **kw)
+    assert ops.get_knob("wgrad_phase4") == 0  # (opt-in since the end of round 5: profiles/r05/wgrad_phase4.txt)
+    with ops.knob("wgrad_phase4", 1):
+        new = ops.conv2d_wgrad(*args, **kw)
+        d = _lib.ConvDesc(n, h, w, c1, c2, 1, 3, 3, 1, 1, 2 * h, 2 * w, cout, 0, 0)
+        assert "phase4" in ops.wgrad_kernel_name(d) or cout % 128 or c1 % 128
+    old = ops.conv2d_wgrad(*args, **kw)
     close(new.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
     close(old.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
     assert float((new - old).abs().max()) <= 2e-5 * float(old.abs().max())  # (exact bf16 products, fp32 sums in another order)

@@ -58,10 +58,11 @@ def test_wgrad_bf16_phase_four_offsets_is_deterministic_many_rounds():
         a = torch.randn(n, h, w, c1, device=DEV, generator=g).to(BF)
         b = torch.randn(n, h, w, c2, device=DEV, generator=g).to(BF)
         dz = torch.randn(n, 2 * h, 2 * w, cout, device=DEV, generator=g).to(BF)
-        _noise(side, buf)
-        one = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
-        _noise(side, buf)
-        two = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
+        with ops.knob("wgrad_phase4", 1):  # (opt-in kernel)
+            _noise(side, buf)
+            one = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
+            _noise(side, buf)
+            two = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
         assert torch.equal(one, two), "round {}: {} elements differ".format(r, int((one != two).sum()))
     torch.cuda.synchronize()
 

@@ -46,7 +46,7 @@ COVERED |= {"conv_wgrad_thin_bf16<{}>".format(t) for t in ("32", "64", "128", "3
 # that these are the instantiations they ran (the last one is dec3's per-source split)
 COVERED |= {"conv_wgrad_bf16<{}>".format(t) for t in ("256x128", "128x128", "128x64", "64x128", "64x64", "32x128", "32x32")}
 COVERED |= {"conv_wgrad_bf16<phase,{}>".format(t) for t in ("128x128", "128x64", "64x128", "64x128+64x64", "128x128+128x64")}
-# ... and the 128 x 128 launches as one dz plane x four source offsets per block (test_wgrad_bf16_phase_form_four_offsets_per_block)
+# ... and, with knob wgrad_phase4 = 1, the 128 x 128 launches as one dz plane x four source offsets per block (test_wgrad_bf16_phase_form_four_offsets_per_block)
 COVERED |= {"conv_wgrad_bf16<phase4,128x128>", "conv_wgrad_bf16<phase4,128x128+128x64>"}
 
 

@@ -54,13 +54,14 @@ def first_diff(a, b):
     return None
 
 
-for knobs in ({"wgrad_ring": 2}, {}):
+for knobs in ({"wgrad_phase4": 1, "wgrad_ring": 2}, {"wgrad_phase4": 1}):  # (the kernel was the default when this was written)
+    saved = {k: ops.get_knob(k) for k in knobs}
     for k, v in knobs.items():
         ops.set_knob(k, v)
     for mode in ("normal", "poison", "onestream"):
         os.environ["ROBOSAT_WGRAD_STREAM"] = "0" if mode == "onestream" else "1"
         runs = [run(mode == "poison") for _ in range(4)]
         print(knobs or "default", mode, [first_diff(runs[0], r) for r in runs[1:]], flush=True)
-    for k in knobs:
-        ops.set_knob(k, 3)
+    for k, v in saved.items():
+        ops.set_knob(k, v)
 os.environ["ROBOSAT_WGRAD_STREAM"] = "1"

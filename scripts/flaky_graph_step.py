@@ -44,9 +44,12 @@ def diff(a, b):
     return first, pstep, names[:6], len(names)
 
 
-settings = [{}, {"wgrad_ring": 2}, {"wgrad_phase4": 0}, {"lovasz_xcd": 0}, {"wgrad_ring": 2, "wgrad_phase4": 0, "wgrad_blocks": 192}]
+# (written when wgrad_phase4 = 1 was the default: "{}" then meant the kernel ON; now say so explicitly)
+settings = [{"wgrad_phase4": 1}, {"wgrad_phase4": 1, "wgrad_ring": 2}, {"wgrad_phase4": 0}, {"wgrad_phase4": 1, "lovasz_xcd": 0},
+            {"wgrad_ring": 2, "wgrad_phase4": 0, "wgrad_blocks": 192}]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for st in settings:
+    saved = {k: ops.get_knob(k) for k in st}
     for k, v in st.items():
         ops.set_knob(k, v)
     base = run(False)
@@ -55,5 +58,5 @@ for st in settings:
         for g in (False, True):
             out.append(("graph" if g else "eager", diff(base, run(g))))
     print(st or "default", [(n, d[0], d[1], d[3], d[2][:3]) for n, d in out if d[0] is not None or d[1] is not None] or "all equal", flush=True)
-    for k in st:
-        ops.set_knob(k, {"wgrad_ring": 3, "wgrad_phase4": 1, "lovasz_xcd": 1, "wgrad_blocks": 96}[k])
+    for k, v in saved.items():
+        ops.set_knob(k, v)

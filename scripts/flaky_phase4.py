@@ -14,6 +14,8 @@ buf = torch.ones(64 << 20, device=DEV)
 
 
 def screen(n, c1, c2, cout, h, w, rounds=200, noise=True, **knobs):
+    knobs = dict({"wgrad_phase4": 1}, **knobs)  # (the kernel under test is opt-in since the end of round 5)
+    saved = {k: ops.get_knob(k) for k in knobs}
     for k, v in knobs.items():
         ops.set_knob(k, v)
     bad = 0
@@ -31,8 +33,8 @@ def screen(n, c1, c2, cout, h, w, rounds=200, noise=True, **knobs):
             bad += 1
             d = (one != two).nonzero()
             where |= {(int(i[3]) // 64) for i in d[:50]}  # which 64-channel slab of Cin
-    for k in knobs:
-        ops.set_knob(k, {"wgrad_phase4": 1, "wgrad_blocks_phase4": 256, "wgrad_blocks_phase": 1536}[k])
+    for k, v in saved.items():
+        ops.set_knob(k, v)
     print((n, c1, c2, cout, h, w), knobs, "noise" if noise else "quiet", "unequal rounds:", bad, "of", rounds, "cin slabs:", sorted(where), flush=True)
 
 

@@ -168,11 +168,11 @@ struct RsKnobs {
   int wgrad_f32_phase = 1;     // RS_WGRAD_F32_PHASE: fp32 DecoderBlock weight gradient in phase form (0: direct form)
   int wgrad_f32_dma = -1;      // RS_WGRAD_F32_DMA: fp32 weight gradient by LDS-DMA (conv_wgrad_f32_dma.hip): -1 by rule, 0 never, 1 wherever it can run
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
-  int wgrad_blocks = 96;       // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches
+  int wgrad_blocks = 192;      // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches (96 with the ring of three)
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
   int wgrad_phase4 = 0;        // RS_WGRAD_PHASE4: 1 = the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step); OFF: dec3's gradient was not bit-reproducible between an eager step and its hipGraph replay with it (profiles/r05/wgrad_phase4.txt)
   int wgrad_blocks_phase4 = 256;  // RS_WGRAD_BLOCKS_PHASE4: block target of those launches (8-wave blocks, one per CU)
-  int wgrad_ring = 3;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel (3: two chunks in flight, counted waits; 2: one)
+  int wgrad_ring = 2;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel.  3 (two chunks in flight, counted waits: -0.1 ms on the step at 96 blocks) is OFF: its loop reads a buffer in the same barrier phase as the counted wait that retires it, and beside an LDS-using neighbour on the CU that is not enough -- 86 of 150 launches not bit-reproducible (profiles/r05/wgrad_ring.txt)
   int lovasz_xcd = 1;          // RS_LOVASZ_XCD: the Lovasz gradient scatter keeps an image's blocks on one XCD (0: natural order)
   int wino_wide = 1;           // ROBOSAT_WINO_WIDE: the 128 x 64 block of the fp32 Winograd DecoderBlock kernel
 };

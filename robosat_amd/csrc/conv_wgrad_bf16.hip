@@ -101,7 +101,13 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
 // (4/9 of the multiply-adds; dz rows are then gathered too: a second table), and combine_phase_wgrad_kernel adds the four
 // G's that make up each filter tap: dW[ky][kx] = sum_{(py,r) : ky in S(py,r)} sum_{(px,s) : kx in S(px,s)} G, with
 // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2} (the taps that hit the same source pixel).
-// RING = chunk buffers.  2: one chunk streams in while one is multiplied, the wave drains its DMA queue before every barrier
+// RING = chunk buffers.  SHIPPED: 2.  RING = 3 (below) is opt-in (knob wgrad_ring) and NOT SAFE as written: it reads a chunk buffer
+// right behind the barrier that follows the counted wait retiring it -- the same phase -- and with another kernel's LDS traffic on the CU
+// a wave's vmcnt can say "landed" before its pieces are visible to the other waves' reads (cdna_hip_programming.md: "read a staged
+// buffer one phase AFTER the wait that retires it, never in the same phase"): bit-reproducible alone and beside HBM-bound
+// neighbours (300-round screens), 86 of 150 launches unequal beside a convolution with 29 KB of LDS per block
+// (scripts/flaky_coresident_others.py).  The fix is one more buffer and the read one iteration later; not done this round.
+// 2: one chunk streams in while one is multiplied, the wave drains its DMA queue before every barrier
 // (two or more blocks per CU cover each other's round trips).  3 (round 5): the tap-per-block launches run ONE block per CU
 // (knob wgrad_blocks = 192) and a chunk's MFMAs are a fraction of a DMA round trip, so every chunk paid one; with two chunks in
 // flight behind the one being multiplied and counted waits (s_waitcnt vmcnt(NI): "all but the newest chunk's pieces have
@@ -659,7 +665,7 @@ Plan plan(const rs_conv_desc* d) {
   // block is prologue + few chunks + a 64 KB partial tile, and every extra split is another partial to write and reduce),
   // but one block per CU (256) leaves room for the main stream's kernels and gives the shortest step (25.3-25.4 ms vs 25.6
   // at 512 and 26.1 at the former 1024).  Round 5 (profiles/r05/wgrad_blocks_bf16.txt, median step): 22.64-22.70 ms at 256,
-  // 22.51 / 22.52 at 192 / 128, 22.72 at 384 -> 192.  With the ring of three chunk buffers (RING = 3: a lone block keeps its CU's
+  // 22.51 / 22.52 at 192 / 128, 22.72 at 384 -> 192 (SHIPPED).  With the ring of three chunk buffers (opt-in, see RING above) (RING = 3: a lone block keeps its CU's
   // LDS-DMA path busy; the launches are 15-30 % shorter in isolation) fewer, longer blocks are the better neighbours: 22.20-22.31
   // at 96-112 against 22.32-22.39 for two buffers at 192, five alternating pairs (profiles/r05/wgrad_ring.txt) -> 96.  The phase
   // form's 16-tap launches are long reductions and want more, shorter blocks (1024 / 1536 / 2048: the same step time).

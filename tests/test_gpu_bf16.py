@@ -242,9 +242,9 @@ def test_wgrad_bf16_phase_form_four_offsets_per_block(n, c1, c2, cout, h, w):
 @pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [(3, 256, 512, 1, 1, 20, 24), (2, 128, 128, 3, 2, 18, 22), (5, 64, 256, 1, 1, 16, 16),
                                                      (2, 192, 64, 1, 1, 9, 7), (1, 64, 64, 1, 1, 33, 5), (2, 128, 64, 1, 1, 12, 12)])
 def test_wgrad_bf16_ring_of_three_chunk_buffers(n, cin, cout, k, stride, h, w):
-    """conv_wgrad_bf16<.., RING = 3> (round 5: two chunks in flight behind the one being multiplied, counted vmcnt waits; what the
-    tap-per-block launches run) against autograd, and BIT-IDENTICAL to the two-buffer pipeline at the same split count (the
-    same chunks are summed in the same order): every tile width, ragged last chunks, splits shorter than the ring."""
+    """conv_wgrad_bf16<.., RING = 3> (round 5: two chunks in flight behind the one being multiplied, counted vmcnt waits; opt-in,
+    knob ``wgrad_ring``) against autograd, and BIT-IDENTICAL to the two-buffer pipeline at the same split count (the same chunks
+    are summed in the same order) WHEN IT RUNS ALONE, as here: every tile width, ragged last chunks, splits shorter than the ring."""
     from robosat_amd import ops
 
     x = q(rnd(n, cin, h, w, seed=31))
@@ -252,12 +252,12 @@ def test_wgrad_bf16_ring_of_three_chunk_buffers(n, cin, cout, k, stride, h, w):
     y = F.conv2d(x, wt, stride=stride, padding=k // 2)
     gy = q(rnd(*y.shape, seed=33))
     y.backward(gy)
-    assert ops.get_knob("wgrad_ring") == 3
-    for blocks in (96, 4096):  # (the shipped target, and splits of a chunk or two: shorter than the ring)
+    assert ops.get_knob("wgrad_ring") == 2  # (the ring is opt-in: not reproducible beside LDS-using neighbours, profiles/r05/wgrad_ring.txt)
+    for blocks in (96, 4096):  # (the ring's target, and splits of a chunk or two: shorter than the ring)
         with ops.knob("wgrad_blocks", blocks):
-            new = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
-            with ops.knob("wgrad_ring", 2):
-                old = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
+            with ops.knob("wgrad_ring", 3):
+                new = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
+            old = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
         close(new.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
         assert torch.equal(new, old), blocks
 

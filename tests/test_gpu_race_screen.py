@@ -35,14 +35,13 @@ def test_wgrad_bf16_ring_of_three_against_two_buffers_many_rounds(n, cin, cout, 
     buf = torch.ones(64 << 20, device=DEV)
     ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
     g = torch.Generator(device=DEV).manual_seed(5)
-    assert ops.get_knob("wgrad_ring") == 3
     for r in range(ROUNDS):
         x = torch.randn(n, h, w, cin, device=DEV, generator=g).to(BF)
         dy = torch.randn(n, ho, wo, cout, device=DEV, generator=g).to(BF)
         _noise(side, buf)
-        new = ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2)
-        with ops.knob("wgrad_ring", 2):
-            old = ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2)
+        with ops.knob("wgrad_ring", 3):  # (opt-in)
+            new = ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2)
+        old = ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2)
         assert torch.equal(new, old), "round {}: {} elements differ".format(r, int((new != old).sum()))
     torch.cuda.synchronize()
 

@@ -170,9 +170,9 @@ struct RsKnobs {
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
   int wgrad_blocks = 192;      // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches (96 with the ring of three)
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
-  int wgrad_phase4 = 0;        // RS_WGRAD_PHASE4: 1 = the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step); OFF: dec3's gradient was not bit-reproducible between an eager step and its hipGraph replay with it (profiles/r05/wgrad_phase4.txt)
+  int wgrad_phase4 = 0;        // RS_WGRAD_PHASE4: 1 = the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step); OFF: its ring pads the tail of a split with out-of-range LDS-DMA pieces, which retire ahead of older loads -- dec3's gradient was not bit-reproducible with it (profiles/r05/wgrad_phase4.txt, wgrad_ring.txt); needs the drained tail conv_wgrad_bf16<.., RING = 3> now has
   int wgrad_blocks_phase4 = 256;  // RS_WGRAD_BLOCKS_PHASE4: block target of those launches (8-wave blocks, one per CU)
-  int wgrad_ring = 2;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel.  3 (two chunks in flight, counted waits: -0.1 ms on the step at 96 blocks) is OFF: its loop reads a buffer in the same barrier phase as the counted wait that retires it, and beside an LDS-using neighbour on the CU that is not enough -- 86 of 150 launches not bit-reproducible (profiles/r05/wgrad_ring.txt)
+  int wgrad_ring = 2;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel.  3 = two chunks in flight, counted waits, the tail drained (-0.1 ms on the step at 96 blocks; its first version padded the tail with out-of-range pieces, which retire out of order: not bit-reproducible beside LDS-using neighbours -- fixed at the very end of round 5, 150-round screen only, hence still opt-in); 4 = the padded version with late reads, kept as the screen's control (profiles/r05/wgrad_ring.txt)
   int lovasz_xcd = 1;          // RS_LOVASZ_XCD: the Lovasz gradient scatter keeps an image's blocks on one XCD (0: natural order)
   int wino_wide = 1;           // ROBOSAT_WINO_WIDE: the 128 x 64 block of the fp32 Winograd DecoderBlock kernel
 };

@@ -101,12 +101,17 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
 // (4/9 of the multiply-adds; dz rows are then gathered too: a second table), and combine_phase_wgrad_kernel adds the four
 // G's that make up each filter tap: dW[ky][kx] = sum_{(py,r) : ky in S(py,r)} sum_{(px,s) : kx in S(px,s)} G, with
 // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2} (the taps that hit the same source pixel).
-// RING = chunk buffers.  SHIPPED: 2.  RING = 3 (below) is opt-in (knob wgrad_ring) and NOT SAFE as written: it reads a chunk buffer
-// right behind the barrier that follows the counted wait retiring it -- the same phase -- and with another kernel's LDS traffic on the CU
-// a wave's vmcnt can say "landed" before its pieces are visible to the other waves' reads (cdna_hip_programming.md: "read a staged
-// buffer one phase AFTER the wait that retires it, never in the same phase"): bit-reproducible alone and beside HBM-bound
-// neighbours (300-round screens), 86 of 150 launches unequal beside a convolution with 29 KB of LDS per block
-// (scripts/flaky_coresident_others.py).  The fix is one more buffer and the read one iteration later; not done this round.
+// RING = chunk buffers.  SHIPPED: 2.  RING = 3 / 4 are opt-in (knob wgrad_ring).
+// What went wrong with the first ring of three (and still does with conv_wgrad_phase4_bf16 and the RING = 4 control below): to keep
+// "NI pieces per wave per iteration" uniform -- what a counted s_waitcnt vmcnt(NI) relies on -- chunks past the end of a split were
+// still issued, OUT OF RANGE (the hardware writes zeros into a buffer nobody reads).  Such pieces need no memory access and RETIRE
+// AHEAD of older loads that are still in flight, so in the last iterations of every split vmcnt(NI) was satisfied before the last real
+// chunk had landed.  Alone on the CU, or beside HBM-bound kernels, the real chunk always won the race (bit-identical to the drained
+// pipeline over 300 rounds); beside a kernel with LDS traffic on the CU 42-96 % of launches read a chunk too early
+// (scripts/flaky_coresident_others.py).  Moving the read one iteration behind the wait (RING = 4) changes nothing; draining the tail
+// instead of padding it (RING = 3 as it is now) does: 0 of 150 unequal, bit-identical to two buffers (scripts/flaky_ring4.py,
+// profiles/r05/wgrad_ring.txt).  The halo forms and conv_thin_bf16 also issue past-the-end pieces, but need a piece three steps / a
+// whole write-out after it was issued, not two 0.2-us iterations: reproducible in the same screens.
 // 2: one chunk streams in while one is multiplied, the wave drains its DMA queue before every barrier
 // (two or more blocks per CU cover each other's round trips).  3 (round 5): the tap-per-block launches run ONE block per CU
 // (knob wgrad_blocks = 192) and a chunk's MFMAs are a fraction of a DMA round trip, so every chunk paid one; with two chunks in
@@ -308,7 +313,44 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
       for (int q = PIN; q < NI; ++q) issue_piece(q);
     }
   };
-  if (RING > 2) {
+  if (RING == 3) {
+    // (second version, end of round 5) no out-of-range "dead" pieces to keep the counts uniform: the tail DRAINS instead -- the wait at the
+    // top of iteration c allows the pieces of chunk c + 1 only if that chunk exists.  (The first version issued past-the-end chunks out of
+    // range -- zeros into a buffer nobody reads -- so that vmcnt(NI) held in every iteration; if such pieces retire ahead of older in-flight
+    // loads, the count says "landed" too early for the last chunks of every split: scripts/flaky_ring4.py asks exactly that.)
+    if (chunk0 < chunk1) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) fill_table(chunk0 + r, r);
+      __syncthreads();
+      prepare_dma(chunk0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NI; ++q) issue_piece(q);
+      if (chunk0 + 1 < chunk1) {
+        prepare_dma(chunk0 + 1, 1, 1);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) issue_piece(q);
+      }
+      int slot = 0;  // ring slot of the chunk being multiplied
+      for (int c = chunk0; c < chunk1; ++c) {
+        if (c + 1 < chunk1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");  // chunk c landed, chunk c + 1 may still fly
+        else wb_dma_wait();
+        __syncthreads();
+        const int s2 = slot == 0 ? RING - 1 : slot - 1;
+        if (c + 2 < chunk1) {
+          prepare_dma(c + 2, s2, s2);
+          chunk_mma(smem + slot * BUF, std::true_type());
+        } else {
+          chunk_mma(smem + slot * BUF, std::false_type());
+        }
+        fill_table(c + RING, slot);  // (this slot's table was read by prepare_dma RING - 1 iterations ago)
+        slot = slot == RING - 1 ? 0 : slot + 1;
+      }
+    }
+  } else if (RING > 3) {
+    // RING = 4 (LATE), first version kept as the control of scripts/flaky_ring4.py: out-of-range dead pieces, reads one iteration behind the wait: the same two chunks in flight, but the counted wait at the top of iteration c retires chunk c + 1 -- chunk c, read
+    // in this iteration, was retired one iteration (two barriers) ago: "read a staged buffer one phase AFTER the wait that retires it".
+    constexpr bool LATE = RING >= 4;
+    constexpr int LOOPWAIT = (LATE ? RING - 3 : RING - 2) * NI;
     if (chunk0 < chunk1) {
 #pragma unroll
       for (int r = 0; r < RING; ++r) fill_table(chunk0 + r, r);
@@ -319,11 +361,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
 #pragma unroll
         for (int q = 0; q < NI; ++q) issue_piece(q);
       }
+      if (LATE) {  // chunk0 retired, and a barrier behind that wait, before the loop's first read
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NI) : "memory");
+        __syncthreads();
+      }
       int slot = 0;  // ring slot of the chunk being multiplied
       for (int c = chunk0; c < chunk1; ++c) {
-        // chunk c has landed when at most the pieces of the RING - 2 chunks behind it are still in flight; the barrier publishes
+        // RING = 3: chunk c has landed when at most the pieces of the chunk behind it are still in flight; the barrier publishes
         // everybody's share and frees the slot chunk c - 1 was read from: chunk c + RING - 1 streams into it between the MFMAs
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NI) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOOPWAIT) : "memory");
         __syncthreads();
         const int s2 = slot == 0 ? RING - 1 : slot - 1;
         prepare_dma(c + RING - 1, s2, s2, c + RING - 1 < chunk1);
@@ -771,6 +817,7 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   // start at ci_base inside the concat
   const int nseg = pl.bno2 ? 2 : 1;
   const bool ring3 = rs_knobs().wgrad_ring == 3;  // (tap-per-block launches only: the phase form runs several blocks per CU)
+  const bool ring4 = rs_knobs().wgrad_ring == 4;  // (four buffers, reads one iteration behind the wait; tiles up to 128 wide)
   for (int seg = 0; seg < nseg; ++seg) {
     int variant = pl.variant;
     a.ci_base = 0;
@@ -802,19 +849,23 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
     } else {
       switch (variant) {
         case V128x128:
-          if (ring3) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring4) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
+          else if (ring3) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V128x64:
-          if (ring3) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring4) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
+          else if (ring3) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V64x128:
-          if (ring3) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring4) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
+          else if (ring3) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V64x64:
-          if (ring3) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring4) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
+          else if (ring3) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;

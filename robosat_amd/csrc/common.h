@@ -102,6 +102,13 @@ __device__ __forceinline__ void rs_st_row32(float* p, const float (&v)[32]) {
 
 #define RS_LAUNCH_RESULT() ((int)hipGetLastError())
 
+// An LDS write that OTHER waves read behind the next barrier: the writing wave waits for its own DS operations first.  __syncthreads()
+// is supposed to (its release fence carries `s_waitcnt lgkmcnt(0)`), but in the pipelined kernels whose LDS-DMA waits are inline asm hipcc
+// DROPS that wait inside loops -- the barrier comes out as a bare s_barrier (round 6: a gather table written by wave 0 and read by the other
+// waves three instructions behind the barrier was stale in 40-85 % of launches beside an LDS-using neighbour; profiles/r06/dma_order.txt).
+// scripts/isa_audit.py (tests/test_isa_audit.py) checks every kernel of the library for exactly this: no s_barrier with a DS write pending.
+__device__ __forceinline__ void rs_lds_writes_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; speed only, never
 // correctness).  Remap so each XCD works on a contiguous run of tile indices and neighbouring tiles (which share
 // input halos and weight panels) hit the same private L2.  Bijective for any grid size.
@@ -110,6 +117,21 @@ __device__ __forceinline__ int rs_xcd_remap(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + k;
+}
+
+// v[lane] + v[lane ^ 16] / v[lane] + v[lane ^ 32] in every lane, on the VALU (gfx950's v_permlane16_swap / v_permlane32_swap: rows of 16 / 32 lanes
+// change places between the two operands) instead of two ds_bpermute round trips through the LDS crossbar.  Same sums as
+// `v += __shfl_xor(v, 16)` bit for bit (one commutative add per lane).  Inline asm: the builtin with the same value in both operands is
+// folded by hipcc into `v + v` (ROCm 7.2); `s_nop 1` = the wait states the swap needs behind a VALU write of its operands.
+__device__ __forceinline__ float rs_xor16_sum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float rs_xor32_sum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
 }
 
 __device__ __forceinline__ float rs_wave_sum(float v) {
@@ -168,11 +190,11 @@ struct RsKnobs {
   int wgrad_f32_phase = 1;     // RS_WGRAD_F32_PHASE: fp32 DecoderBlock weight gradient in phase form (0: direct form)
   int wgrad_f32_dma = -1;      // RS_WGRAD_F32_DMA: fp32 weight gradient by LDS-DMA (conv_wgrad_f32_dma.hip): -1 by rule, 0 never, 1 wherever it can run
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
-  int wgrad_blocks = 192;      // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches (96 with the ring of three)
+  int wgrad_blocks = 96;       // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches (192 for two chunk buffers; 96 with the ring of three: profiles/r05/wgrad_ring.txt)
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
-  int wgrad_phase4 = 0;        // RS_WGRAD_PHASE4: 1 = the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step); OFF: its ring pads the tail of a split with out-of-range LDS-DMA pieces, which retire ahead of older loads -- dec3's gradient was not bit-reproducible with it (profiles/r05/wgrad_phase4.txt, wgrad_ring.txt); needs the drained tail conv_wgrad_bf16<.., RING = 3> now has
+  int wgrad_phase4 = 1;        // RS_WGRAD_PHASE4: the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step).  Round 5 withdrew it for a reproducibility failure whose cause round 6 found (a gather table published through a bare s_barrier: profiles/r06/dma_order.txt) and fixed
   int wgrad_blocks_phase4 = 256;  // RS_WGRAD_BLOCKS_PHASE4: block target of those launches (8-wave blocks, one per CU)
-  int wgrad_ring = 2;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel.  3 = two chunks in flight, counted waits, the tail drained (-0.1 ms on the step at 96 blocks; its first version padded the tail with out-of-range pieces, which retire out of order: not bit-reproducible beside LDS-using neighbours -- fixed at the very end of round 5, 150-round screen only, hence still opt-in); 4 = the padded version with late reads, kept as the screen's control (profiles/r05/wgrad_ring.txt)
+  int wgrad_ring = 3;          // RS_WGRAD_RING: chunk buffers of the tap-per-block bf16 weight-gradient kernel.  3 = two chunks in flight, counted waits (-0.1 ms on the step at 96 blocks); 2 = the drained two-buffer pipeline; 4 = the race screen's positive control (the round-5 defect kept on purpose, one tile); 5-7 = the bisect's variants (`make EXP=1`)
   int lovasz_xcd = 1;          // RS_LOVASZ_XCD: the Lovasz gradient scatter keeps an image's blocks on one XCD (0: natural order)
   int wino_wide = 1;           // ROBOSAT_WINO_WIDE: the 128 x 64 block of the fp32 Winograd DecoderBlock kernel
 };

@@ -70,6 +70,8 @@ __device__ __forceinline__ void wb_dma16(__amdgpu_buffer_rsrc_t r, unsigned int 
       : "memory", "m0");
 }
 
+__device__ unsigned int wb_zero_line[256];  // 1 KiB of zeros (a __device__ array is zero-initialised): DEAD == 1
+
 __device__ __forceinline__ void wb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ unsigned int wb_lds_addr(const void* p) {
@@ -101,25 +103,31 @@ __device__ __forceinline__ bf16x8 wb_tr_read8(const unsigned char* p0, const uns
 // (4/9 of the multiply-adds; dz rows are then gathered too: a second table), and combine_phase_wgrad_kernel adds the four
 // G's that make up each filter tap: dW[ky][kx] = sum_{(py,r) : ky in S(py,r)} sum_{(px,s) : kx in S(px,s)} G, with
 // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2} (the taps that hit the same source pixel).
-// RING = chunk buffers.  SHIPPED: 2.  RING = 3 / 4 are opt-in (knob wgrad_ring).
-// What went wrong with the first ring of three (and still does with conv_wgrad_phase4_bf16 and the RING = 4 control below): to keep
-// "NI pieces per wave per iteration" uniform -- what a counted s_waitcnt vmcnt(NI) relies on -- chunks past the end of a split were
-// still issued, OUT OF RANGE (the hardware writes zeros into a buffer nobody reads).  Such pieces need no memory access and RETIRE
-// AHEAD of older loads that are still in flight, so in the last iterations of every split vmcnt(NI) was satisfied before the last real
-// chunk had landed.  Alone on the CU, or beside HBM-bound kernels, the real chunk always won the race (bit-identical to the drained
-// pipeline over 300 rounds); beside a kernel with LDS traffic on the CU 42-96 % of launches read a chunk too early
-// (scripts/flaky_coresident_others.py).  Moving the read one iteration behind the wait (RING = 4) changes nothing; draining the tail
-// instead of padding it (RING = 3 as it is now) does: 0 of 150 unequal, bit-identical to two buffers (scripts/flaky_ring4.py,
-// profiles/r05/wgrad_ring.txt).  The halo forms and conv_thin_bf16 also issue past-the-end pieces, but need a piece three steps / a
-// whole write-out after it was issued, not two 0.2-us iterations: reproducible in the same screens.
-// 2: one chunk streams in while one is multiplied, the wave drains its DMA queue before every barrier
-// (two or more blocks per CU cover each other's round trips).  3 (round 5): the tap-per-block launches run ONE block per CU
-// (knob wgrad_blocks = 192) and a chunk's MFMAs are a fraction of a DMA round trip, so every chunk paid one; with two chunks in
-// flight behind the one being multiplied and counted waits (s_waitcnt vmcnt(NI): "all but the newest chunk's pieces have
-// landed") the block keeps its CU's LDS-DMA path busy by itself.
-template <int BMo, int BNo, int WGM, int WGN, int PK, bool PHASE, int RING = 2>
+// RING = chunk buffers.  SHIPPED: 3 for the tap-per-block launches (knob wgrad_ring), 2 for the phase form.
+// 2: one chunk streams in while one is multiplied, the wave drains its DMA queue before every barrier (two or more blocks per CU cover
+// each other's round trips).  3 (round 5): the tap-per-block launches run ONE block per CU (knob wgrad_blocks = 96) and a chunk's MFMAs
+// are a fraction of a DMA round trip, so with two buffers every chunk paid one; with two chunks in flight behind the one being multiplied
+// and counted waits (s_waitcnt vmcnt(NI): "all but the newest chunk's pieces have landed") the block keeps its CU's LDS-DMA path busy
+// by itself.  The tail of a split drains (the last iterations wait with vmcnt(0) and issue nothing).
+// History (profiles/r05/wgrad_ring.txt, profiles/r06/dma_order.txt): round 5 shipped the ring and conv_wgrad_phase4_bf16 as defaults, found
+// 42-96 % of their launches not bit-reproducible beside an LDS-using neighbour on the CU, blamed the out-of-range pieces that padded the tail
+// of a split ("they retire ahead of older loads, so the counted wait lies") and withdrew both.  Round 6 asked the hardware
+// (scripts/probes/probe_dma_order.hip: LDS-DMA pieces retire IN ORDER whatever their lanes address -- 0 stale of 2.9 M pieces) and the
+// kernel (scripts/dma_order_forensics.py: a wrong launch multiplies dy with the x rows of the chunk RING iterations EARLIER): the defect was
+// the gather table.  Wave 0 writes chunk c + RING's table at the end of iteration c, everybody reads it behind the next barrier -- and hipcc
+// emits that __syncthreads() as a BARE s_barrier in these loops (its `s_waitcnt lgkmcnt(0)` is dropped; see rs_lds_writes_done in common.h),
+// so with LDS traffic from a neighbour the other waves' ds_read_b32 overtook the ds_write_b32 and fetched the old chunk's rows again.
+// fill_table now waits for its own write.  With that one line every variant of the tail -- padded out of range, padded with real loads,
+// drained -- is bit-identical to two buffers in 100 of 100 rounds; without it (RING = 4 / DEAD = 0, kept as the race screen's positive
+// control and flagged by scripts/isa_audit.py) 43-85 of 100 are not.
+// DEAD (RING = 4 only; round 6, the bisect of what exactly goes wrong with the padded tail -- profiles/r06/dma_order.txt): what a chunk past
+// the end of the split issues.  0: out-of-range pieces into the dead ring slot (the round-5 control);  1: in-range loads of a 1 KiB zero
+// line into the dead slot;  2: out-of-range pieces into a scratch KiB nobody ever reads;  3: whatever follows the split in memory (the next
+// split's chunk: ordinary loads, out of range only behind the last pixel).
+template <int BMo, int BNo, int WGM, int WGN, int PK, bool PHASE, int RING = 2, int DEAD = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2) void conv_wgrad_bf16(const WgradArgsB p) {
   constexpr int NW = WGM * WGN;          // waves
+  constexpr bool FIXLGKM = !(RING == 4 && DEAD == 0);  // (the RING = 4 / DEAD = 0 instantiation stays as it was: the race screen's positive control)
   constexpr int NS = PK / 16;            // MFMA k-steps per chunk
   constexpr int WM = BMo / WGM, WN = BNo / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
   static_assert(TM >= 1 && TN >= 1 && (IA % NW) == 0 && (IB % NW) == 0, "bad tile");
 
   static_assert(RING >= 2 && (RING - 2) * NI <= 63, "vmcnt is a 6-bit count");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * BUF + (PHASE ? 2 : 1) * RING * PK * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * BUF + (PHASE ? 2 : 1) * RING * PK * 4 + (DEAD == 2 ? 1024 : 0)];
+  constexpr int SCRATCH = RING * BUF + (PHASE ? 2 : 1) * RING * PK * 4;
   int* tabs = reinterpret_cast<int*>(smem + RING * BUF);  // [RING][PK] input-row gather
   int* taba = tabs + RING * PK;                            // [RING][PK] dz-row gather (PHASE only)
 
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
       }
       tabs[which * PK + tid] = pix;
       if (PHASE) taba[which * PK + tid] = pixa;
+      if (FIXLGKM) rs_lds_writes_done();
     }
   };
 
@@ -228,6 +238,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
   // wave 60-180 cycles of issue; a burst at the top of the chunk puts that on every wave's critical path at once).
   int voff[NI];
   unsigned int fL = lds0;
+  bool fdead = false;  // (wave-uniform) the chunk being fetched lies past the split
+  const __amdgpu_buffer_rsrc_t rsrc_zero = wb_make_rsrc(wb_zero_line, 1024);
   // (`live` = false, RING > 2 only: a chunk past the block's range -- its pieces are still issued, out of range (zeros into a
   // buffer nobody reads), so that every wave issues the same number of DMA instructions per step: what the counted waits rely on)
   auto prepare_dma = [&](int chunk, int buf, int which, bool live = true) __attribute__((always_inline)) {
@@ -250,12 +262,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
       } else {
         voff[j] = pix[j] >= 0 ? pix[j] * cs2 + colb : -1;
       }
-      if (RING > 2 && !live) voff[j] = -1;
+      if (RING > 2 && !live && DEAD != 3) voff[j] = DEAD == 1 ? lane * 16 : -1;
     }
+    fdead = RING > 2 && !live;
   };
   auto issue_piece = [&](int j) __attribute__((always_inline)) {
     const int ii = wave + NW * j;
-    if (NW * j < IA) wb_dma16(rsrc_dy, fL + ii * 1024, voff[j]);
+    if (DEAD == 1 && fdead) wb_dma16(rsrc_zero, NW * j < IA ? fL + ii * 1024 : fL + ABYTES + (ii - IA) * 1024, voff[j]);
+    else if (DEAD == 2 && fdead) wb_dma16(rsrc_dy, lds0 + SCRATCH, voff[j]);
+    else if (NW * j < IA) wb_dma16(rsrc_dy, fL + ii * 1024, voff[j]);
     else wb_dma16(rsrc_x, fL + ABYTES + (ii - IA) * 1024, voff[j]);
   };
 
@@ -314,10 +329,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
     }
   };
   if (RING == 3) {
-    // (second version, end of round 5) no out-of-range "dead" pieces to keep the counts uniform: the tail DRAINS instead -- the wait at the
-    // top of iteration c allows the pieces of chunk c + 1 only if that chunk exists.  (The first version issued past-the-end chunks out of
-    // range -- zeros into a buffer nobody reads -- so that vmcnt(NI) held in every iteration; if such pieces retire ahead of older in-flight
-    // loads, the count says "landed" too early for the last chunks of every split: scripts/flaky_ring4.py asks exactly that.)
+    // the tail DRAINS: the wait at the top of iteration c allows the pieces of chunk c + 1 only if that chunk exists (padding the tail with
+    // out-of-range pieces instead, as RING = 4 below does, is equally correct -- LDS-DMA pieces retire in order -- and costs a few dead pieces)
     if (chunk0 < chunk1) {
 #pragma unroll
       for (int r = 0; r < RING; ++r) fill_table(chunk0 + r, r);
@@ -347,8 +360,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 || RING > 2) ? 1 : 2
       }
     }
   } else if (RING > 3) {
-    // RING = 4 (LATE), first version kept as the control of scripts/flaky_ring4.py: out-of-range dead pieces, reads one iteration behind the wait: the same two chunks in flight, but the counted wait at the top of iteration c retires chunk c + 1 -- chunk c, read
-    // in this iteration, was retired one iteration (two barriers) ago: "read a staged buffer one phase AFTER the wait that retires it".
+    // RING = 4 (LATE): round 5's first version (padded tail, reads one iteration behind the wait).  DEAD = 0 is the race screen's POSITIVE
+    // CONTROL: it keeps the defect (FIXLGKM = false: the gather table is published through a bare s_barrier); DEAD = 1-3 (`make EXP=1`) are
+    // the bisect's variants of the padded tail, all with the fix, all clean.
     constexpr bool LATE = RING >= 4;
     constexpr int LOOPWAIT = (LATE ? RING - 3 : RING - 2) * NI;
     if (chunk0 < chunk1) {
@@ -502,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_phase4_bf16(const WgradArgs
       }
       if (o == NOFF) taba[which * PK + i] = pix;
       else tabs[(which * NOFF + o) * PK + i] = pix;
+      rs_lds_writes_done();
     }
   };
 
@@ -817,7 +832,8 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
   // start at ci_base inside the concat
   const int nseg = pl.bno2 ? 2 : 1;
   const bool ring3 = rs_knobs().wgrad_ring == 3;  // (tap-per-block launches only: the phase form runs several blocks per CU)
-  const bool ring4 = rs_knobs().wgrad_ring == 4;  // (four buffers, reads one iteration behind the wait; tiles up to 128 wide)
+  const bool ring4 = rs_knobs().wgrad_ring >= 4 && rs_knobs().wgrad_ring <= 7;  // (four buffers, reads one iteration behind the wait; tiles up to 128 wide)
+  const int dead = rs_knobs().wgrad_ring - 4;  // 5, 6, 7: the DEAD variants of the 128 x 64 tile (the race screen's bisect)
   for (int seg = 0; seg < nseg; ++seg) {
     int variant = pl.variant;
     a.ci_base = 0;
@@ -849,23 +865,26 @@ extern "C" int rs_conv2d_wgrad_bf16(const rs_conv_desc* d, const rs_bf16* dy, co
     } else {
       switch (variant) {
         case V128x128:
-          if (ring4) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
-          else if (ring3) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring3) conv_wgrad_bf16<128, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<128, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V128x64:
+#ifdef RS_EXP_BUILD  // (`make EXP=1`: the bisect variants of scripts/dma_order_bisect.py)
+          if (ring4 && dead == 1) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 4, 1><<<grid, 256, 0, s>>>(a);
+          else if (ring4 && dead == 2) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 4, 2><<<grid, 256, 0, s>>>(a);
+          else if (ring4 && dead == 3) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 4, 3><<<grid, 256, 0, s>>>(a);
+          else
+#endif
           if (ring4) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
           else if (ring3) conv_wgrad_bf16<128, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<128, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V64x128:
-          if (ring4) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
-          else if (ring3) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring3) conv_wgrad_bf16<64, 128, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<64, 128, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V64x64:
-          if (ring4) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 4><<<grid, 256, 0, s>>>(a);
-          else if (ring3) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
+          if (ring3) conv_wgrad_bf16<64, 64, 2, 2, 64, false, 3><<<grid, 256, 0, s>>>(a);
           else conv_wgrad_bf16<64, 64, 2, 2, 64, false><<<grid, 256, 0, s>>>(a);
           break;
         case V32x128: conv_wgrad_bf16<32, 128, 1, 4, 64, false><<<grid, 256, 0, s>>>(a); break;

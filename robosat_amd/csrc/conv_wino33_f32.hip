@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       }
       tab[rho] = v;
     }
+    rs_lds_writes_done();  // (read by every wave behind a later barrier, which hipcc emits bare: common.h)
   };
 
   // ---- fetch side (see conv_wino_f32.hip): one chunk ahead, across work items --------------------------------------------
@@ -350,8 +351,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
           for (int px = 0; px < 4; ++px) {
             const f32x4 y = Y[px >> 1][px & 1];
             float v = fmaf(y[3], wv[3], fmaf(y[2], wv[2], fmaf(y[1], wv[1], y[0] * wv[0])));
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            v = rs_xor32_sum(rs_xor16_sum(v));  // (the 16 couts: lanes l15 + 16 pc, on the VALU -- not __shfl_xor, see below)
             part[px][c] = v;
           }
         } else {
@@ -361,7 +361,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       }
       // the cg = 1 half goes to LDS; the cg = 0 lanes keep their pixel's half and finish it behind the next barrier (the first
       // chunk of the block's next item, or the one after the loop): no barrier of its own, and the softmax + stores run
-      // beside the other waves' MFMAs
+      // beside the other waves' MFMAs.
+      // Round 6 (profiles/r06/head_race.txt): as round 5 shipped it this epilogue was WRONG whenever an LDS-DMA kernel of another
+      // stream shared the CUs -- up to 0.32 off in ~2 500 probabilities per launch, never alone (tests/test_gpu_race_screen.py
+      // ::test_wino33_fused_head_fp32_beside_an_lds_user was red in 20 of 20 rounds).  Two changes, both needed for a clean screen:
+      // (1) the writer waits for its own LDS stores (hipcc emits the next __syncthreads() as a bare s_barrier: common.h), (2) the
+      // sum over the wave's 16 couts runs on the VALU (v_permlane16/32_swap) instead of two ds_bpermute round trips per value:
+      // with (1) alone the sums of the lanes that receive lanes 48-63 were still stale in most launches of that build.  The
+      // hardware mechanism behind (2) was not isolated (two probes of candidate hazards, scripts/probes/probe_bpermute_dma.hip and
+      // probe_pk_ds_hazard.hip, are negative; a later build with __shfl_xor behind a run-time switch passed too): what is pinned
+      // is the screen, which any later change of this epilogue must keep green.
       hbuf = seq & 1;
       if (cg == 1 && pc == 0) {
         float* xrow = xch + hbuf * XCH + (16 * tg + l15) * XROW;
@@ -370,6 +379,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
           *reinterpret_cast<f32x4*>(xrow + px * kHeadMaxC) = f32x4{part[px][0], part[px][1], part[px][2], part[px][3]};
           *reinterpret_cast<f32x4*>(xrow + px * kHeadMaxC + 4) = f32x4{part[px][4], part[px][5], part[px][6], part[px][7]};
         }
+        rs_lds_writes_done();  // (the cg = 0 waves read it right behind the next barrier, which hipcc emits bare: common.h)
       }
 #pragma unroll
       for (int c = 0; c < kHeadMaxC; ++c) hmine[c] = pc == 0 ? part[0][c] : (pc == 1 ? part[1][c] : (pc == 2 ? part[2][c] : part[3][c]));

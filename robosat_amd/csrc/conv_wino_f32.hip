@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
       }
       tab[rho] = v;
     }
+    rs_lds_writes_done();  // (read by every wave behind a later barrier, which hipcc emits bare: common.h)
   };
 
   // ---- fetch side: runs ONE chunk ahead of the MFMAs, across item boundaries (the next item's first chunk streams in while

@@ -44,9 +44,10 @@ def diff(a, b):
     return first, pstep, names[:6], len(names)
 
 
-# (written when wgrad_phase4 = 1 was the default: "{}" then meant the kernel ON; now say so explicitly)
-settings = [{"wgrad_phase4": 1}, {"wgrad_phase4": 1, "wgrad_ring": 2}, {"wgrad_phase4": 0}, {"wgrad_phase4": 1, "lovasz_xcd": 0},
-            {"wgrad_ring": 2, "wgrad_phase4": 0, "wgrad_blocks": 192}]
+# (round 6: the defaults are wgrad_ring = 3 / wgrad_blocks = 96 / wgrad_phase4 = 1 again; the last setting is round 5's shipped state)
+settings = [{}, {"wgrad_phase4": 1, "wgrad_ring": 3, "wgrad_blocks": 96}, {"wgrad_ring": 2, "wgrad_phase4": 0, "wgrad_blocks": 192}]
+if len(sys.argv) > 2:
+    settings = settings[:int(sys.argv[2])]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for st in settings:
     saved = {k: ops.get_knob(k) for k in st}

@@ -54,7 +54,11 @@ def bench_name(k):
         return "conv_wgrad_thin_bf16<{}{}>".format(32 * int(m.group(1)), ",ups" if m.group(2) == "1" else "")
     if "conv_wgrad_phase4_bf16" in k:
         return "conv_wgrad_bf16<phase4,128x128>"
-    m = re.search(r"conv_wgrad_bf16<(\d+), (\d+), \d+, \d+, \d+, (true|false)(?:, \d+)?>", k)  # (last: chunk buffers, 2 or 3)
+    m = re.search(r"conv_wgrad_bf16<(\d+), (\d+), \d+, \d+, \d+, (true|false)(?:, \d+)*>", k)  # (then: chunk buffers 2 / 3, the race control's variant)
+    if m is None:  # (rocprofv3 on the GPU box prints mangled names)
+        mm = re.search(r"conv_wgrad_bf16ILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb([01])E", k)
+        if mm:
+            return "conv_wgrad_bf16<{}{}x{}>".format("phase," if mm.group(3) == "1" else "", mm.group(1), mm.group(2))
     if m:  # (a two-launch layer -- "128x128+128x64" in the bench's name -- is looked up by its first tile)
         return "conv_wgrad_bf16<{}{}x{}>".format("phase," if m.group(3) == "true" else "", m.group(1), m.group(2))
     m = re.search(r"_ZN\d+_GLOBAL__N_1\d+([a-z_0-9]+?)I", k)

@@ -208,14 +208,15 @@ def test_wgrad_bf16_upsample_concat(n, c1, c2, cout, h, w):
     expected = {(128, 64, 64): "conv_wgrad_bf16<phase,64x128+64x64>", (256, 0, 128): "conv_wgrad_bf16<phase,128x128>",
                 (64, 64, 256): "conv_wgrad_bf16<phase,128x64>", (256, 64, 128): "conv_wgrad_bf16<phase,128x128+128x64>",
                 (512, 256, 64): "conv_wgrad_bf16<phase,64x128>"}
-    assert ops.wgrad_kernel_name(d) == expected[(c1, c2, cout)]
+    # (the 128 x 128 launches of the phase form run conv_wgrad_phase4_bf16 by default: one dz plane x four source offsets per block)
+    assert ops.wgrad_kernel_name(d) == expected[(c1, c2, cout)].replace("phase,128x128", "phase4,128x128")
 
 
 @pytest.mark.parametrize("n,c1,c2,cout,h,w", [(1, 256, 0, 128, 9, 7), (3, 256, 128, 256, 9, 13), (2, 256, 64, 128, 16, 16), (4, 128, 0, 128, 32, 32)])
 def test_wgrad_bf16_phase_form_four_offsets_per_block(n, c1, c2, cout, h, w):
     """conv_wgrad_phase4_bf16 (round 5: a block owns one dz parity plane and all four of its source offsets -- the dz tile is
-    fetched once for four products; knob ``wgrad_phase4`` = 1, not the default) against autograd on the reference
-    formulation (unet.py:63-73) and against the block-per-pair kernel on the same launch (the default): ragged
+    fetched once for four products; knob ``wgrad_phase4`` = 1, the default again since round 6) against autograd on the reference
+    formulation (unet.py:63-73) and against the block-per-pair kernel on the same launch (knob = 0): ragged
     32-pixel chunks, splits that straddle images, two sources incl. a narrower second one, image borders on every side."""
     from robosat_amd import _lib, ops
 
@@ -228,26 +229,24 @@ def test_wgrad_bf16_phase_form_four_offsets_per_block(n, c1, c2, cout, h, w):
     y.backward(gy)
     args = (nhwc(gy), nhwc(a), 3, 3)
     kw = dict(src2=nhwc(b) if c2 else None, ups=1, pad=1)
-    assert ops.get_knob("wgrad_phase4") == 0  # (opt-in since the end of round 5: profiles/r05/wgrad_phase4.txt)
-    with ops.knob("wgrad_phase4", 1):
-        new = ops.conv2d_wgrad(*args, **kw)
-        d = _lib.ConvDesc(n, h, w, c1, c2, 1, 3, 3, 1, 1, 2 * h, 2 * w, cout, 0, 0)
-        assert "phase4" in ops.wgrad_kernel_name(d) or cout % 128 or c1 % 128
-    old = ops.conv2d_wgrad(*args, **kw)
+    assert ops.get_knob("wgrad_phase4") == 1  # (round 5 withdrew it; the defect was its gather table's barrier: profiles/r06/dma_order.txt)
+    new = ops.conv2d_wgrad(*args, **kw)
+    d = _lib.ConvDesc(n, h, w, c1, c2, 1, 3, 3, 1, 1, 2 * h, 2 * w, cout, 0, 0)
+    assert "phase4" in ops.wgrad_kernel_name(d) or cout % 128 or c1 % 128
+    with ops.knob("wgrad_phase4", 0):
+        old = ops.conv2d_wgrad(*args, **kw)
     close(new.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
     close(old.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
     assert float((new - old).abs().max()) <= 2e-5 * float(old.abs().max())  # (exact bf16 products, fp32 sums in another order)
 
 
-# (non-strict xfail: the opt-in kernel was rewritten -- drained tail -- with the round's last seconds of GPU time and screened on one tile only,
-# scripts/flaky_ring4.py; this test has not run against the rewrite.  Expected to XPASS; a plain test again once it has.)
-@pytest.mark.xfail(reason="opt-in kernel rewritten after the last suite run; screened on one tile (profiles/r05/wgrad_ring.txt)", strict=False)
 @pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [(3, 256, 512, 1, 1, 20, 24), (2, 128, 128, 3, 2, 18, 22), (5, 64, 256, 1, 1, 16, 16),
                                                      (2, 192, 64, 1, 1, 9, 7), (1, 64, 64, 1, 1, 33, 5), (2, 128, 64, 1, 1, 12, 12)])
 def test_wgrad_bf16_ring_of_three_chunk_buffers(n, cin, cout, k, stride, h, w):
-    """conv_wgrad_bf16<.., RING = 3> (round 5: two chunks in flight behind the one being multiplied, counted vmcnt waits; opt-in,
+    """conv_wgrad_bf16<.., RING = 3> (round 5: two chunks in flight behind the one being multiplied, counted vmcnt waits; the default,
     knob ``wgrad_ring``) against autograd, and BIT-IDENTICAL to the two-buffer pipeline at the same split count (the same chunks
-    are summed in the same order) WHEN IT RUNS ALONE, as here: every tile width, ragged last chunks, splits shorter than the ring."""
+    are summed in the same order): every tile width, ragged last chunks, splits shorter than the ring.  (Beside an LDS-using
+    neighbour: tests/test_gpu_race_screen.py.)"""
     from robosat_amd import ops
 
     x = q(rnd(n, cin, h, w, seed=31))
@@ -255,12 +254,12 @@ def test_wgrad_bf16_ring_of_three_chunk_buffers(n, cin, cout, k, stride, h, w):
     y = F.conv2d(x, wt, stride=stride, padding=k // 2)
     gy = q(rnd(*y.shape, seed=33))
     y.backward(gy)
-    assert ops.get_knob("wgrad_ring") == 2  # (the ring is opt-in: not reproducible beside LDS-using neighbours, profiles/r05/wgrad_ring.txt)
+    assert ops.get_knob("wgrad_ring") == 3 and ops.get_knob("wgrad_blocks") == 96
     for blocks in (96, 4096):  # (the ring's target, and splits of a chunk or two: shorter than the ring)
         with ops.knob("wgrad_blocks", blocks):
-            with ops.knob("wgrad_ring", 3):
-                new = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
-            old = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
+            new = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
+            with ops.knob("wgrad_ring", 2):
+                old = ops.conv2d_wgrad(nhwc(gy), nhwc(x), k, k, stride=stride, pad=k // 2)
         close(new.permute(0, 3, 1, 2).cpu(), wt.grad, TOL_F32)
         assert torch.equal(new, old), blocks
 

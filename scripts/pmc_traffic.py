@@ -119,6 +119,7 @@ if __name__ == "__main__":
     result["_meta"] = {
         # digest of the kernel sources of the PROFILED tree: bench.py prints roofline.traffic only when it matches its own
         "csrc_digest": kernel_source_digest(),
+        "profiled_csrc_digest": kernel_source_digest(),  # (what bench.py compares; written by this script only -- never edited by hand)
         "tag": sys.argv[3] if len(sys.argv) > 3 else None, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
         "commit": commit,  # None on the GPU box (the snapshot has no .git): filled in when the file is copied to profiles/
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --no-cpu-baseline --no-parity "

@@ -27,18 +27,24 @@ _STATE = {}
 
 
 def _neighbour(k=6):
-    """Queues ``k`` launches of an LDS-using kernel on the second stream: a bf16 1x1 convolution on the 128x64 tile (29 KB of LDS per block,
-    LDS-DMA + ds_read traffic on every CU).  An HBM-bound elementwise neighbour does NOT expose the defect (round 5: 0 of 300)."""
+    """Queues ``k`` launches of an LDS-using kernel on EACH of four side streams: a bf16 1x1 convolution on the 128x64 tile (29 KB of LDS
+    per block, LDS-DMA + ds_read traffic on every CU).  An HBM-bound elementwise neighbour does NOT expose the defect (round 5: 0 of 300).
+    Four streams, not one: HIP multiplexes a process's streams onto a handful of hardware queues, and a side stream that lands on the main
+    stream's queue runs BEHIND the kernel under test instead of beside it -- which is how this module's positive control came out
+    "reproducible" when it ran at the end of the whole suite (other tests had created streams before it) and in round 0 when it ran alone,
+    and very likely why round 5's screen XPASSED a known-defective kernel on the driver's box."""
     from robosat_amd import ops
 
-    if "side" not in _STATE:
+    if "sides" not in _STATE:
         g = torch.Generator(device=DEV).manual_seed(99)
-        _STATE["side"] = torch.cuda.Stream()
+        _STATE["sides"] = [torch.cuda.Stream() for _ in range(4)]
         _STATE["nx"] = torch.randn(32, 64, 64, 256, device=DEV, generator=g).to(BF)
         _STATE["nw"] = (torch.randn(64, 1, 1, 256, device=DEV, generator=g) * 0.05).to(BF)
-    with torch.cuda.stream(_STATE["side"]):
-        for _ in range(k):
-            ops.conv2d(_STATE["nx"], _STATE["nw"])
+        _STATE["no"] = [torch.empty(32, 64, 64, 64, device=DEV, dtype=BF) for _ in range(4)]
+    for side, out in zip(_STATE["sides"], _STATE["no"]):
+        with torch.cuda.stream(side):
+            for _ in range(k):
+                ops.conv2d(_STATE["nx"], _STATE["nw"], out=out)
 
 
 def _same(a, b):
@@ -82,7 +88,7 @@ def control():
     assert ops.wgrad_kernel_name(ops.ConvDesc(16, 64, 64, 64, 0, 0, 3, 3, 2, 1, 32, 32, 128, 0, 0)) == "conv_wgrad_bf16<128x64>"
     tried = []
     with ops.knob("wgrad_ring", 4):
-        for k in (6, 12, 3):
+        for k in (2, 6, 1):
             bad = _twice(lambda: _control_shape(g), lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1), CONTROL_ROUNDS, k=k, stop_at_first=True)
             tried.append((k, bad[0] if bad else None))
             if bad:

@@ -490,8 +490,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     const int hi = lane >> 5, l31 = lane & 31;
     const int ctot = p.C1 + p.C2;
     // this lane's halo rows: instruction ii = wave + NW*j copies halo rows RI*ii .. (R = hyy * HWD + hxx)
-    int hpix[NJH];  // source pixel (within the image) of the lane's row of piece j for the group being FETCHED, or -1
+    // (round 6) per piece the lane's BYTE offset in either concat source, not its pixel: the multiply by the source's channel count, the
+    // swizzled piece and the padding test happen once per patch (DG4: once per parity plane) instead of once per issued piece -- the
+    // main loop was issue-bound on exactly such arithmetic (3.3 VALU + 2.2 SALU per MFMA, profiles/r04/halo_variants.txt)
+    int ho1[NJH], ho2[NJH];  // byte offset of the lane's row of piece j in source 1 / 2 for the group being FETCHED, kDmaOOB = zeros
     auto halo_pix = [&](int pa, int pb) __attribute__((always_inline)) {
+      int hpix[NJH];
 #pragma unroll
       for (int j = 0; j < NJH; ++j) {
         const int R = RI * (wave + NW * j) + ra;
@@ -505,6 +509,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
           if (R < HROWS && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws) v = sy * p.Ws + sx;
         }
         hpix[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < NJH; ++j) {
+        ho1[j] = hpix[j] >= 0 ? hpix[j] * (p.C1 * ES) + gp * 16 : kDmaOOB;
+        ho2[j] = hpix[j] >= 0 ? hpix[j] * (p.C2 * ES) + gp * 16 : kDmaOOB;
       }
     };
     int hwrow[NBW];  // byte offset of this lane's piece in weight row (n0 + RI*ii + ra), tap 0, channel 0
@@ -528,8 +537,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     };
     auto issue_halo = [&](int j, int buf, const Grp& g) __attribute__((always_inline)) {
       const int first = g.c0 < p.C1 ? 1 : 0;
-      const int cs2 = (first ? p.C1 : p.C2) * ES;
-      const int v = (g.live && hpix[j] >= 0) ? hpix[j] * cs2 + gp * 16 : kDmaOOB;
+      const int v = g.live ? (first ? ho1[j] : ho2[j]) : kDmaOOB;
       const int ii = wave + NW * j;  // (wave-uniform) instructions past the halo's last row write their zeros to the scratch KiB
       rb_dma16s(first ? rsrc1 : rsrc2, lds0 + (ii < NHI ? buf * HALOB + ii * 1024 : HSCRATCH), v, (first ? g.c0 : g.c0 - p.C1) * ES);
     };
@@ -544,17 +552,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     int rb0[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) rb0[tm] = (wm * RPT + tm) * HWD + l31;
+    // (round 6) PRE: the HNT x TM fragment row addresses of a lane -- row R = its pixel's halo row shifted by the tap, 16-byte position
+    // `hi` under that row's swizzle key -- are loop invariant: kept in registers where that is <= 18 of them (every phase / 4x4 form, the 3x3
+    // form on 256-pixel patches), one v_xad_u32 per fragment read is left (k-step ^ , halo buffer +) where five VALU were
+    constexpr bool PRE = HNT * TM <= 18;
+    int ab[PRE ? HNT : 1][PRE ? TM : 1];
+    if constexpr (PRE) {
+      rb_for_each(
+          [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int toff = (t / HK) * HWD + (t % HK);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+              const int R = rb0[tm] + toff;
+              const int key = ROWB == 128 ? ((R >> 1) & 7) << 4 : ((R >> 2) & 3) << 4;
+              ab[t][tm] = R * ROWB + ((hi << 4) ^ key);
+              asm volatile("" : "+v"(ab[t][tm]));  // (a register from here on: not rematerialised inside the loop)
+            }
+          },
+          std::make_integer_sequence<int, HNT>());
+    }
     const int bfl = ROWB == 128 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     int bfo[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) bfo[s] = HBOFF + (wn * WN + l31) * ROWB + (((2 * s + hi) ^ bfl) * 16);
     // fragments of k-step `ks` of the step with tap offset `toff` on halo buffer `hbuf`, weight slot `slot` (uniform)
-    auto rd = [&](int hbuf, int slot, int toff, int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) __attribute__((always_inline)) {
+    auto rd = [&](int hbuf, int slot, int toff, int ks, u32x4 (&a)[TM], u32x4 (&b)[TN], int t = 0) __attribute__((always_inline)) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
-        const int R = rb0[tm] + toff;
-        const int key = ROWB == 128 ? ((R >> 1) & 7) << 4 : ((R >> 2) & 3) << 4;
-        a[tm] = *reinterpret_cast<const u32x4*>(smem + hbuf * HALOB + R * ROWB + (((2 * ks + hi) << 4) ^ key));
+        if constexpr (PRE) {  // (t: compile-time after unrolling) ((2 ks + hi) << 4) ^ key == ((hi << 4) ^ key) ^ (ks << 5)
+          a[tm] = *reinterpret_cast<const u32x4*>(smem + ((ab[t][tm] ^ (ks << 5)) + hbuf * HALOB));
+        } else {
+          const int R = rb0[tm] + toff;
+          const int key = ROWB == 128 ? ((R >> 1) & 7) << 4 : ((R >> 2) & 3) << 4;
+          a[tm] = *reinterpret_cast<const u32x4*>(smem + hbuf * HALOB + R * ROWB + (((2 * ks + hi) << 4) ^ key));
+        }
       }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const u32x4*>(smem + slot * BSLOT + 32 * tn * ROWB + bfo[ks]);
@@ -574,13 +606,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
     rb_dma_wait_n<NBW>();  // halo 0 and the weights of steps 0 and 1 have landed (step 2's may still fly)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    rd(0, 0, 0, 0, fa[0], fb[0]);  // first fragments of step 0
+    rd(0, 0, 0, 0, fa[0], fb[0], 0);  // first fragments of step 0
     for (int q = 0; q < Q; ++q) {
       const int hbuf = q & 1, nbuf = (q + 1) & 1;
       // (opaque to the optimiser on purpose: the HNT x TM fragment row addresses are loop-invariant per lane, and hipcc would
       // hoist all of them out of the group loop -- up to 72 registers -- and spill; recomputed per tap they are a few VALU)
+      if constexpr (!PRE) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(rb0[tm]));
+        for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(rb0[tm]));
+      }
       rb_for_each(
           [&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
@@ -591,7 +625,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
             // in flight after this wait: what the previous step issued (NBW weight pieces + its halo pieces)
             if constexpr (KO != 1) {
               rb_dma_wait_n<NBW + halo_pieces_at_tap(tprev, HNT, NJH)>();
+#ifdef RS_HALO_FENCED_BARRIER
               __syncthreads();
+#else
+              // a BARE s_barrier (round 6): __syncthreads() carries `s_waitcnt lgkmcnt(0)`, which here waits for the fragment reads of
+              // THIS step that were issued just above it (the prefetch behind the previous step's last k-step) -- an LDS round trip in
+              // front of every barrier, the very thing the prefetch was there to hide.  Nothing in this loop writes LDS with DS
+              // instructions (the pipeline buffers are filled by LDS-DMA, covered by the counted vmcnt wait above), and a wave's reads
+              // of the slots that are refilled behind this barrier were consumed by the MFMAs it issued before it.
+              __builtin_amdgcn_s_barrier();
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NHT = halo_pieces_at_tap(t, HNT, NJH);  // halo pieces that go with this tap
@@ -623,8 +666,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, conv_waves_per_simd(WGM * WGN, BM, 
             for (int ks = 0; ks < KS; ++ks) {
               // k-step ks + 1 of this step -- or, behind the last one, k-step 0 of the NEXT step (published by this step's barrier)
               if constexpr (KO != 3) {
-                if (ks + 1 < KS) rd(hbuf, slot, toff, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-                else rd(hbuf1, slot1, toff1, 0, fa[0], fb[0]);
+                if (ks + 1 < KS) rd(hbuf, slot, toff, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1], t);
+                else rd(hbuf1, slot1, toff1, 0, fa[0], fb[0], tn1);
               }
 #pragma unroll
               for (int tm = 0; tm < TM; ++tm)

@@ -49,6 +49,14 @@ for STAGE in "$@"; do
       F=$(find $OUT/trace_$T -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/${T}_kernel_stats.csv
       find $OUT/trace_$T -name "*kernel_trace.csv" -size +8M -delete
     done ;;
+  gaps)
+    # where the wall time of one overlapped bf16 train step goes: main-stream busy vs wall, side-stream overlap, idle gaps, copies
+    cd /tmp
+    timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_gaps -o p -- $B --phase train --dtype bf16 --batch 32 --steps 4 --warmup 2 --no-parity > $OUT/trace_gaps.log 2>&1; echo "exit $?"
+    cd $REPO
+    F=$(find $OUT/trace_gaps -name "*kernel_trace.csv" | head -1)
+    [ -n "$F" ] && python scripts/trace_gaps.py $F stem_fwd > $OUT/train_bf16_bs32_512_trace_gaps.txt 2>&1; head -50 $OUT/train_bf16_bs32_512_trace_gaps.txt | cut -c1-220
+    find $OUT/trace_gaps -name "*kernel_trace.csv" -size +8M -delete ;;
   pmc)
     cd /tmp
     C1="SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"

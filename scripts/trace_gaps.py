@@ -94,7 +94,13 @@ for s, e, q, n, g in seg:
 print("kernels of the last step by total time (queue, name, launches, ms):")
 for (q, n), v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:25]:
     print("  q%d %-72s %4d %8.3f" % (q, n, v[0], v[1] / 1e6))
-print("copies:")
-for s, e, q, n, g in seg:
-    if "copyBuffer" in n or "fillBuffer" in n:
-        print("  q%d %-28s grid %9d  %7.1f us  at +%.3f ms" % (q, short(n), g, (e - s) / 1e3, (s - t0) / 1e6))
+print("copies (with the kernel launched before / after each on the same queue):")
+byq = defaultdict(list)
+for r in seg:
+    byq[r[2]].append(r)
+for q, rs in byq.items():
+    for i, (s, e, _, n, g) in enumerate(rs):
+        if "copyBuffer" in n or "fillBuffer" in n:
+            prev = short(rs[i - 1][3])[:44] if i else "-"
+            nxt = short(rs[i + 1][3])[:44] if i + 1 < len(rs) else "-"
+            print("  q%d %-24s grid %9d  %6.1f us  at +%7.3f ms | after %s | before %s" % (q, short(n)[:24], g, (e - s) / 1e3, (s - t0) / 1e6, prev, nxt))

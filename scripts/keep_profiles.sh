@@ -19,13 +19,21 @@ cp $SRC/pmc_mfma_per_kernel.txt $DST/ 2>/dev/null
 cp $SRC/bench_others.txt $SRC/latency.txt $DST/ 2>/dev/null
 python scripts/bench_brief.py $SRC/bench_default.json > $DST/bench_brief.txt
 if [ -d $SRC/pmc ]; then
-  python scripts/pmc_traffic.py $SRC/pmc profiles/pmc_traffic.json $TAG > $DST/pmc_hbm_traffic.txt
-  python - "$COMMIT" <<PY
+  # the table stamped ON THE GPU BOX by the pmc stage (digest of the sources that were profiled) is what is kept; this script only adds
+  # the commit -- and only if the working tree still has those sources (round 5 re-stamped the digest by hand three times: never again)
+  python scripts/pmc_traffic.py $SRC/pmc /tmp/pmc_traffic_here.json $TAG > $DST/pmc_hbm_traffic.txt
+  python - "$COMMIT" "$SRC/pmc_traffic.json" <<PY
 import json, sys
-p = "profiles/pmc_traffic.json"
-d = json.load(open(p))
-d["_meta"]["commit"] = sys.argv[1]
-json.dump(d, open(p, "w"), indent=1, sort_keys=True)
+sys.path.insert(0, ".")
+from robosat_amd._lib import kernel_source_digest
+d = json.load(open(sys.argv[2]))
+m = d["_meta"]
+m.setdefault("profiled_csrc_digest", m.get("csrc_digest"))
+if m["profiled_csrc_digest"] == kernel_source_digest():
+    m["commit"] = sys.argv[1]
+else:
+    print("WARNING: the working tree's kernel sources (%s) are not the profiled ones (%s): commit left unset, bench.py will withhold roofline.traffic" % (kernel_source_digest(), m["profiled_csrc_digest"]))
+json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 PY
 fi
 # the test log without the tool chatter: summary line + every captured line that carries a number a reader may ask for

@@ -99,6 +99,7 @@ if __name__ == "__main__":
     for tag in ("predict", "trainbf16", "trainf32"):
         f, w = collect(root, tag, "FETCH_SIZE"), collect(root, tag, "WRITE_SIZE")
         lines.append("== {} (per launch, averaged over the launches of a kernel; MB = 1e6 bytes)".format(tag))
+        tot_bytes, tot_launches, steps = 0.0, 0, 0
         for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, (0, 0))[0] + w.get(k, (0, 0))[0]) * max(f.get(k, (0, 1))[1], 1)):
             rd = 2.0 * f.get(k, (0, 0))[0] * 1024
             wr = w.get(k, (0, 0))[0] * 1024
@@ -106,6 +107,12 @@ if __name__ == "__main__":
             lines.append("{:42s} launches {:4d}  read {:9.2f} MB  write {:9.2f} MB  total {:9.2f} MB".format(k, n, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
             if tag == "predict" or k not in result:
                 result[k] = round(rd + wr)
+            tot_bytes += (rd + wr) * n
+            tot_launches += n
+            if k in ("conv_igemm_f32<128x64,stem>", "stem_fwd_bf16_kernel", "stem_conv_bf16"):
+                steps = n
+        if steps:  # (the run's untimed steps are steps like the timed one: per-step figures = totals / launches of the stem kernel)
+            lines.append("   => {} steps in the run: {:.1f} launches and {:.2f} GB of HBM traffic per step".format(steps, tot_launches / steps, tot_bytes / steps / 1e9))
     import datetime
     import subprocess
 

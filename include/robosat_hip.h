@@ -209,7 +209,9 @@ int rs_conv2d_fwd_bf16(const rs_conv_desc* d, const rs_bf16* src1, const rs_bf16
 int rs_conv2d_tile_bf16(const rs_conv_desc* d);
 /* Tile index (rs_conv2d_tile_name order) and K-chunk row size (64 | 128 bytes) the dispatcher picks for `d` with `es`-byte
  * activations, direct (phase4 = 0) or phase form: kernel names in reports then map 1:1 to the launched symbols. */
-int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* rowb);
+int rs_conv2d_config(const rs_conv_desc* d, int es, int form, int* tile, int* rowb);
+/* (`form`: bit 0 = phase form; bit 1 = a launch with a fused epilogue beyond scale / shift / residual / ReLU -- BatchNorm statistics,
+ * a ReLU mask, two destinations -- which never takes the plain-epilogue fp32 1x1 kernel.) */
 /* Dispatcher override for the parity tests and A/B measurements (process-global; not a tuning API for callers): force the
  * tile (index as above; honoured for every launch that tile can run, -1 = the measured heuristics) and the K-chunk row
  * size (64 | 128; 0 = heuristics).  rs_conv2d_config reports what a launch will then use, so a test can assert that the

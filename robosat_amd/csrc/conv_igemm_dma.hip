@@ -446,7 +446,13 @@ extern "C" int rs_conv2d_set_tuning(int tile, int rowb) {
 
 // For the roofline report (kernel names that map 1:1 to the launched symbol): tile index and K-chunk row bytes the
 // dispatcher picks for `d` with activations of `es` bytes, in the direct (phase4 = 0) or phase form.
-extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* tile, int* rowb) {
+// `form`: bit 0 = phase form; bit 1 = the launch carries a fused epilogue beyond scale / shift / residual / ReLU (BatchNorm statistics,
+// a ReLU mask, two destinations), i.e. never the plain-epilogue fp32 1x1 kernel -- so that a report can ask for the name of such a
+// launch without flipping the process-global knob around the query.
+extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int form, int* tile, int* rowb) {
+  if (form < 0 || form > 3) return RS_EINVAL;
+  const int phase4 = form & 1;
+  const bool plain = (form & 2) == 0;
   if (!valid(d) || (es != 2 && es != 4) || (phase4 && !phase_ok(d))) return RS_EINVAL;
   const int kc128 = 128 / es;
   const bool can128 = d->C1 % kc128 == 0 && d->C2 % kc128 == 0;
@@ -463,7 +469,7 @@ extern "C" int rs_conv2d_config(const rs_conv_desc* d, int es, int phase4, int* 
       return 0;
     }
   }
-  if (es == 4 && ew_f32_mode(d, phase4 != 0, true)) {  // (as for a launch with a plain eval epilogue)
+  if (es == 4 && ew_f32_mode(d, phase4 != 0, plain)) {
     if (tile) *tile = TEW;
     if (rowb) *rowb = 64;
     return 0;

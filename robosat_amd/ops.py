@@ -486,13 +486,11 @@ def conv_tile_name(d, bf16=False, phase=False, plain=True):
     BatchNorm statistics / a ReLU mask (never the plain-epilogue 1x1 kernel of conv1x1_ew_f32.hip)."""
 
     lib = _lib.lib()
-    if not plain and not bf16 and not d.stem:
-        with knob("conv1x1_ew", 0):
-            return conv_tile_name(d, bf16, phase)
     if d.stem:
         return lib.rs_conv2d_tile_name(lib.rs_conv2d_tile(ctypes.byref(d))).decode()
     tile, rowb = ctypes.c_int(0), ctypes.c_int(0)
-    check(lib.rs_conv2d_config(ctypes.byref(d), 2 if bf16 else 4, int(phase), ctypes.byref(tile), ctypes.byref(rowb)), "rs_conv2d_config")
+    form = int(bool(phase)) | (0 if plain else 2)  # (the library answers for the epilogue kind: no knob is touched around the query)
+    check(lib.rs_conv2d_config(ctypes.byref(d), 2 if bf16 else 4, form, ctypes.byref(tile), ctypes.byref(rowb)), "rs_conv2d_config")
     base = (lib.rs_conv2d_tile_name_bf16 if bf16 else lib.rs_conv2d_tile_name)(tile.value).decode()
     if tile.value == TILES["thin"]:  # conv_thin_bf16.hip: named by the form it computes
         return "{}<{}>".format(base, "phase" if phase else ("dgrad4x4" if d.kh == 4 else "3x3"))

@@ -158,7 +158,12 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ew_f32_kernel(const ConvArgsT<
   } else {
     // ================================================ epilogue waves =================================================
     const int e = tid - 256;
-    const int c4 = e & 15, r16 = e >> 4;
+    // (round 6) the thread's 16-byte column is ROTATED by its row: a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, ... that
+    // mix eight lanes of staging row r with eight of row r + 1, and with the row pitch of 68 floats (what keeps the main-loop waves'
+    // ds_write_b128 conflict free) straight columns put lane 12 (row r, piece 12) and lane 27 (row r + 1, piece 11) on the same
+    // banks: SQ_LDS_BANK_CONFLICT 14.3 % of the kernel's LDS cycles in rounds 4-5.  Rotated, a lane group's (row + piece) mod 16 are
+    // its lanes' own low four bits: all different.  Same elements, same arithmetic, a row's 16 lanes still cover its 256 bytes.
+    const int r16 = e >> 4, c4 = ((e & 15) - r16) & 15;
     const int gpi = nk > 1 ? (EW_NG + nk - 2) / (nk - 1) : EW_NG;  // groups per chunk step (steps 0 .. nk-2 drain a tile)
     // coordinates of a tile as this thread sees them
     auto coords = [&](int seq, long& obase, int& m_first, int& col) __attribute__((always_inline)) {

@@ -81,14 +81,19 @@ def _control_shape(g):
 
 @pytest.fixture(scope="module")
 def control():
-    """The defective kernel must be caught here before any clean result below means anything.  Three neighbour loads are tried."""
+    """The defective kernel must be caught here before any clean result below means anything.  Five neighbour loads are tried, the last two
+    on eight side streams."""
     from robosat_amd import ops
 
     g = _gen(3)
     assert ops.wgrad_kernel_name(ops.ConvDesc(16, 64, 64, 64, 0, 0, 3, 3, 2, 1, 32, 32, 128, 0, 0)) == "conv_wgrad_bf16<128x64>"
     tried = []
     with ops.knob("wgrad_ring", 4):
-        for k in (2, 6, 1):
+        for k in (2, 6, 1, 4, 12):
+            if len(tried) == 3:  # (three loads on four side streams saw nothing: four more streams -- more hardware queues to land on)
+                _neighbour(0)
+                _STATE["sides"] += [torch.cuda.Stream() for _ in range(4)]
+                _STATE["no"] += [torch.empty_like(_STATE["no"][0]) for _ in range(4)]
             bad = _twice(lambda: _control_shape(g), lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, stride=2, pad=1), CONTROL_ROUNDS, k=k, stop_at_first=True)
             tried.append((k, bad[0] if bad else None))
             if bad:

@@ -185,6 +185,7 @@ struct RsKnobs {
   int conv_halo_min = 192;     // RS_CONV_HALO_MIN: ... for launches with at least this many blocks
   int conv_halo512 = -1;       // RS_CONV_HALO512: the 512-pixel patch: -1 by rule, 0 never, 1 wherever it can run
   int conv1x1_ew = -1;         // RS_CONV1X1_EW: conv1x1_ew_f32 -- -1 by rule (K <= 64), 0 never, 1 wherever it can run
+  int conv1x1_np = 0;          // RS_CONV1X1_NP: conv1x1_np_f32 (fp32 1x1 with the epilogue between the next sub-tile's MFMAs): -1 by rule, 0 never, 1 wherever it can run
   int conv1x1_ew_bf16 = 0;     // RS_CONV1X1_EW_BF16: conv1x1_ew_bf16 (train-mode 1x1 forward) -- 0 never, 1 wherever it can run
   int halo_ko = 0;             // RS_HALO_KO: knock-out variant of the halo kernel (`make KO=1` builds only)
   int wgrad_f32_phase = 1;     // RS_WGRAD_F32_PHASE: fp32 DecoderBlock weight gradient in phase form (0: direct form)

@@ -296,6 +296,14 @@ bool ew_f32_mode(const rs_conv_desc* d, bool phase4, bool plain) {
   return ew != 0 && tuning().tile < 0 && !phase4 && plain && rs_conv1x1_ew_f32_ok(d) && (ew > 0 || d->C1 <= 64);
 }
 
+// fp32 1x1 launches that take conv1x1_np_f32.hip (a sub-tile's epilogue issued between the next sub-tile's MFMAs by the same waves;
+// bit-identical to the generic kernel; `make EXP=1` builds only: measured slower, profiles/r06/np_1x1.txt).  Knob -1 would pick launches
+// WITH a residual and 128 <= K <= 512 (Bottleneck.conv3 of layer2 .. layer4), geometry only.
+bool np_f32_mode(const rs_conv_desc* d, bool phase4, bool plain, bool has_res) {
+  const int np = rs_knobs().conv1x1_np;
+  return np != 0 && tuning().tile < 0 && !phase4 && plain && rs_conv1x1_np_f32_ok(d) && (np > 0 || (has_res && d->C1 >= 128 && d->C1 <= 512));
+}
+
 template <typename T>
 int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* scale,
              const float* shift, const void* residual, const void* relu_mask, void* out, rs_stream_t stream,
@@ -383,6 +391,9 @@ int conv_fwd(const rs_conv_desc* d, const void* src1, const void* src2, const vo
   }
   if constexpr (sizeof(T) == 4) {
     if (ew_f32_mode(d, phase4, epi == EPI_EVAL && !relu_mask && !out2 && !mask_bits)) return rs_conv1x1_ew_f32_launch(a, (hipStream_t)stream);
+#ifdef RS_EXP_BUILD  // (`make EXP=1`: measurement only -- parity yes, speed no: profiles/r06/np_1x1.txt)
+    if (np_f32_mode(d, phase4, epi == EPI_EVAL && !relu_mask && !out2 && !mask_bits, residual != nullptr)) return rs_conv1x1_np_f32_launch(a, (hipStream_t)stream);
+#endif
   }
   if constexpr (sizeof(T) == 2) {
     int bn = 0, bm = 256;

@@ -78,6 +78,9 @@ __attribute__((visibility("hidden"))) void rs_conv_launch_bf16_halo_phase_ko(int
 // conv1x1_ew_f32.hip: fp32 1x1 / stride-1 launches with the epilogue on its own waves (knob conv1x1_ew: by rule K <= 64)
 __attribute__((visibility("hidden"))) int rs_conv1x1_ew_f32_ok(const rs_conv_desc* d);
 __attribute__((visibility("hidden"))) int rs_conv1x1_ew_f32_launch(const ConvArgsT<float>& a, hipStream_t s);
+// conv1x1_np_f32.hip: fp32 1x1 / stride-1 launches with a sub-tile's epilogue between the next sub-tile's MFMAs (knob conv1x1_np)
+__attribute__((visibility("hidden"))) int rs_conv1x1_np_f32_ok(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) int rs_conv1x1_np_f32_launch(const ConvArgsT<float>& a, hipStream_t s);
 // conv1x1_ew_bf16.hip: the train-mode forward's bf16 1x1 launches (statistics epilogue) in the same layout (knob conv1x1_ew_bf16)
 __attribute__((visibility("hidden"))) int rs_conv1x1_ew_bf16_stats_ok(const rs_conv_desc* d);
 __attribute__((visibility("hidden"))) int rs_conv1x1_ew_bf16_stats_launch(const ConvArgsT<bf16_t>& a, hipStream_t s);

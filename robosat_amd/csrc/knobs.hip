@@ -34,6 +34,7 @@ const Entry kEntries[] = {
     {"conv_halo_min", "RS_CONV_HALO_MIN", &RsKnobs::conv_halo_min, 0, 1048576},
     {"conv_halo512", "RS_CONV_HALO512", &RsKnobs::conv_halo512, -1, 1},
     {"conv1x1_ew", "RS_CONV1X1_EW", &RsKnobs::conv1x1_ew, -1, 1},
+    {"conv1x1_np", "RS_CONV1X1_NP", &RsKnobs::conv1x1_np, -1, 1},
     {"conv1x1_ew_bf16", "RS_CONV1X1_EW_BF16", &RsKnobs::conv1x1_ew_bf16, 0, 1},
     {"halo_ko", "RS_HALO_KO", &RsKnobs::halo_ko, 0, 4},
     {"wgrad_f32_phase", "RS_WGRAD_F32_PHASE", &RsKnobs::wgrad_f32_phase, 0, 1},

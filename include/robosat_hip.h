@@ -324,6 +324,21 @@ const char* rs_conv2d_phase_wino_name(const rs_conv_desc* d);
 int rs_pack_wino_phase_weight(const float* w_phase, float* u, int Cout, int Cin, rs_stream_t stream);
 int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1, const float* src2, const float* u, float* out,
                              rs_stream_t stream);
+/* The DATA gradient of that DecoderBlock (autograd of unet.py:63-73 under tools/train.py:186) in the same Winograd machinery: the
+ * 4x4 / stride-2 convolution over dz is four 2x2 correlations over dz's parity planes that accumulate into one source-resolution
+ * tile, each of them the forward's parity item on its plane -- 9/16 of rs_conv2d_fwd_dt's multiply-adds on that launch.
+ * `d` = the FORWARD layer's descriptor (as for rs_conv2d_fwd_phase_wino); dz [N][2 Hs][2 Ws][Cout] fp32; `u` = [4][9][C1+C2][Cout]
+ * from rs_pack_wino_dgrad_weight(wd = [C1+C2][4][4][Cout] of rs_combine_dgrad_phase_weight_dt); result d cat[skip, prev]
+ * [N][Hs][Ws][C1+C2] in `out`, or split at channel `csplit` (% 64 == 0) into `out` [..][csplit] and `out2` [..][C1+C2-csplit]
+ * (torch.cat's backward fused into the store; out2 = NULL, csplit = 0: one tensor); `mask` / `mask2`: optional tensors shaped like
+ * their destination, the result is zeroed where they are <= 0 (the ReLU of the layer that produced skip / prev).
+ * rs_conv2d_dgrad_phase_wino_ok: 1 if this form runs the layer's gradient (>= 8 tiles per image side, C1 + C2 a multiple of 64,
+ * Cout % 16 == 0, 32-bit offsets) -- geometry only, never N; else use rs_conv2d_fwd_split_dt / rs_conv2d_fwd_dt on the 4x4 form. */
+int rs_conv2d_dgrad_phase_wino_ok(const rs_conv_desc* d);
+const char* rs_conv2d_dgrad_phase_wino_name(const rs_conv_desc* d);
+int rs_pack_wino_dgrad_weight(const float* wd4x4, float* u, int Cin, int Cout, rs_stream_t stream);
+int rs_conv2d_dgrad_phase_wino(const rs_conv_desc* d, const float* dz, const float* u, float* out, const float* mask, float* out2,
+                               const float* mask2, int csplit, rs_stream_t stream);
 
 /* The stride-1 3x3 / pad-1 convolutions of the fp32 predict path -- Bottleneck.conv2 (torchvision resnet50 via unet.py:94,
  * 122-130) with its eval-mode BatchNorm folded into scale / shift, and dec5's ConvRelu (unet.py:32-44,139) -- as a Winograd

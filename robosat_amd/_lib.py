@@ -103,6 +103,10 @@ SIGNATURES = {
     "rs_conv2d_phase_wino_name": (c_char_p, [POINTER(ConvDesc)]),
     "rs_pack_wino_phase_weight": (c_int, [P, P, c_int, c_int, P]),
     "rs_conv2d_fwd_phase_wino": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    "rs_conv2d_dgrad_phase_wino_ok": (c_int, [POINTER(ConvDesc)]),
+    "rs_conv2d_dgrad_phase_wino_name": (c_char_p, [POINTER(ConvDesc)]),
+    "rs_pack_wino_dgrad_weight": (c_int, [P, P, c_int, c_int, P]),
+    "rs_conv2d_dgrad_phase_wino": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_int, P]),
     "rs_conv2d_wino33_ok": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_wino33_name": (c_char_p, [POINTER(ConvDesc)]),
     "rs_pack_wino33_weight": (c_int, [P, P, c_int, c_int, P]),

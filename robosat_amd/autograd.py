@@ -317,9 +317,17 @@ def _backward(net, tape, dlogits, arena):
         arena.wgrad(lambda: ops.conv2d_wgrad(dz, skip, 3, 3, src2=prev, ups=1, pad=1, out=wo), dz, skip, prev)
         # phase form: the gradient wrt the pre-upsample tensors is ONE 4x4 / stride-2 convolution over dz (the 2x2 sum of
         # interpolate's backward is folded into pre-summed taps): 4/9 of the MACs, output already at source resolution
-        wd = conv.dgrad_phase(dz.dtype)  # (packed beside the forward: _prefetch_decoder_weights)
         hw = (skip.shape[1], skip.shape[2])
         c1 = skip.shape[3]
+        c2 = 0 if prev is None else prev.shape[3]
+        if dz.dtype == torch.float32 and ops.wino_dgrad_ok(dz.shape[0], hw[0], hw[1], c1, c2, dz.shape[3]):
+            # fp32: the same gradient through the Winograd F(2x2, 2x2) machinery of the forward (9/16 of the 4x4 form's multiply-adds)
+            u = conv.dgrad_phase_wino()
+            if prev is not None and skip_grad_out is None and c1 % 64 == 0:
+                return ops.conv2d_dgrad_phase_wino(dz, u, c1, c2, mask1=mask_skip, mask2=mask_prev, split=True)
+            if prev is None and skip_grad_out is None:
+                return ops.conv2d_dgrad_phase_wino(dz, u, c1, 0, mask1=mask_skip)[0], None
+        wd = conv.dgrad_phase(dz.dtype)  # (packed beside the forward: _prefetch_decoder_weights)
         if prev is None and skip_grad_out is None:  # single source: the ReLU mask rides in the epilogue, nothing to split
             return ops.conv2d(dz, wd, stride=2, pad=1, out_hw=hw, relu_mask=mask_skip, alg_scale=2.25), None
         if prev is not None and skip_grad_out is None and c1 % 128 == 0:  # torch.cat's backward fused into the store (two destinations)

@@ -60,6 +60,14 @@ struct WinoArgs {
   int nsub;      // N * BBY * BBX
   int ncb;       // cout blocks: Cout / BN
   int relu;
+  // DG instantiations only -- the DecoderBlock's DATA gradient (autograd of unet.py:63-73 under tools/train.py:186): `src1` is dz
+  // [N][2 Hs][2 Ws][C1] (C2 = 0), `u` the transformed data-gradient filters [4][9][Cout][C1] (rs_pack_wino_dgrad_weight), the output
+  // d cat[skip, prev] at SOURCE resolution [N][Hs][Ws][Cout], optionally split at cout `csplit` into out / out2 (torch.cat's backward
+  // fused into the store) with a ReLU mask each (the tensor whose sign decides: the forward activation; null = none)
+  float* out2;
+  const float* mask1;
+  const float* mask2;
+  int csplit;
 };
 
 template <int PB>
@@ -89,7 +97,13 @@ __device__ __forceinline__ int wino_swz(int row) { return (row ^ (row >> 1)) & 3
 
 // TG tile groups (16 tiles each) x CG cout groups (32 couts each) = 8 waves per block
 // NM = MFMA tiles of 16 couts per wave (a wave owns 16 tiles x 16*NM couts)
-template <int PB, int TG, int CG, int NM = 2>
+// DG (round 6): the 4x4 / stride-2 data gradient of the phase form in the same machinery.  d src(a, b) = sum over the four parity
+// planes of dz, plane(pa, pb)(u, v) = dz(2 u + pa, 2 v + pb), of a 2x2 correlation with taps w4[2 r + 1 - pa][2 s + 1 - pb] at origin
+// (a - pa, b - pb): exactly the forward's parity (py, px) = (1 - pa, 1 - pb) item on that plane -- same halo origin, same 3x3 patches,
+// same transforms -- except that the four parities ACCUMULATE into one output tile instead of interleaving into four.  So a block
+// owns an output item for four consecutive "units" (one per plane: its own halo table, source offsets and filter set, as for a
+// forward item), keeps the accumulators across them and writes A^T M A once: 9/16 of the generic 4x4 kernel's multiply-adds.
+template <int PB, int TG, int CG, int NM = 2, bool DG = false>
 __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p) {
   using G = WinoGeom<PB>;
   constexpr int NW = TG * CG;
@@ -113,11 +127,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
   const int per_img = p.BBY * p.BBX;
   const int Cin = p.C1 + p.C2;
   const int nk = Cin / KC;
-  const int ntiles = ((p.nsub + SB - 1) / SB) * p.ncb * 4;  // work items: (m block, cout block, parity)
+  const int ntiles = ((p.nsub + SB - 1) / SB) * p.ncb * (DG ? 1 : 4);  // work items: (m block, cout block[, parity]); DG: output items
   const int first = rs_xcd_remap(blockIdx.x, gridDim.x);
-  const int nitems = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;  // this block walks items first, first + grid, ...
+  // this block walks items first, first + grid, ...; DG: each output item as four consecutive units (the parity planes of dz)
+  const int nitems = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x * (DG ? 4 : 1);
+  auto item_of = [&](int seq) __attribute__((always_inline)) {  // the (m block, cout block, parity) index of the block's unit `seq`
+    return DG ? (((first + (seq >> 2) * (int)gridDim.x) << 2) | (seq & 3)) : first + seq * (int)gridDim.x;
+  };
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane(rb_lds_addr(smem));
-  const long img1 = (long)p.Hs * p.Ws * p.C1, img2 = (long)p.Hs * p.Ws * p.C2;
+  const long img1 = (long)p.Hs * p.Ws * p.C1 * (DG ? 4 : 1), img2 = (long)p.Hs * p.Ws * p.C2;  // (DG: dz images are 2 Hs x 2 Ws)
 
   // item -> (parity, m block, cout block)
   auto decode = [&](int it, int& py, int& px, int& mblk, int& nblk) __attribute__((always_inline)) {
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
   };
   auto build_table = [&](int seq) __attribute__((always_inline)) {  // all threads; visible after the next barrier
     int py, px, mblk, nblk;
-    decode(first + seq * (int)gridDim.x, py, px, mblk, nblk);
+    decode(item_of(seq), py, px, mblk, nblk);
     const int sub0 = mblk * SB, nfirst = sub0 / per_img;
     int* tab = tabs + (seq & 1) * AROWS_PAD;
     for (int rho = tid; rho < AROWS_PAD; rho += 64 * NW) {
@@ -143,7 +161,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
           const int n = sub / per_img, r2 = sub - n * per_img;
           const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
           const int y = 2 * bby * PB - 1 + py + hy, x = 2 * bbx * PB - 1 + px + hx;
-          if ((unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws) v = ((n - nfirst) * p.Hs + y) * p.Ws + x;
+          if ((unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws)
+            v = DG ? ((n - nfirst) * 2 * p.Hs + 2 * y + 1 - py) * (2 * p.Ws) + 2 * x + 1 - px  // plane (1 - py, 1 - px) of dz, pixel (y, x)
+                   : ((n - nfirst) * p.Hs + y) * p.Ws + x;
         }
       }
       tab[rho] = v;
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
   __amdgpu_buffer_rsrc_t rsrc1 = rb_make_rsrc(p.src1, 0), rsrc2 = rsrc1, rsrcu = rsrc1;
   auto fetch_item = [&]() __attribute__((always_inline)) {  // f_seq changed: descriptors and filter offsets of the new item
     int py, px, mblk, nblk;
-    decode(first + f_seq * (int)gridDim.x, py, px, mblk, nblk);
+    decode(item_of(f_seq), py, px, mblk, nblk);
     const int nfirst = __builtin_amdgcn_readfirstlane((mblk * SB) / per_img);
     rsrc1 = rb_make_rsrc(p.src1 + nfirst * img1, (long)(p.N - nfirst) * img1 * 4);
     rsrc2 = rb_make_rsrc(p.C2 ? p.src2 + nfirst * img2 : p.src1, (long)(p.N - nfirst) * img2 * 4);
@@ -245,12 +265,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
   const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
 
   int g = 0;
+  f32x4 acc[9][NM];
   for (int seq = 0; seq < nitems; ++seq) {
-    f32x4 acc[9][NM];
+    if (!DG || (seq & 3) == 0) {  // (DG: the four parity planes of an output item accumulate)
 #pragma unroll
-    for (int x = 0; x < 9; ++x)
+      for (int x = 0; x < 9; ++x)
 #pragma unroll
-      for (int m = 0; m < NM; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < NM; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kc = 0; kc < nk; ++kc, ++g) {
       rb_dma_wait();
@@ -322,9 +344,43 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f32_kernel(const WinoArgs p)
     }
 
     // ---- Y = A^T M A, ReLU, store: lane = tile l15, couts 32 cg + 16 m + 4 pc + (0..3) -------------------------------------
+    if (DG && (seq & 3) != 3) continue;
     int py, px, mblk, nblk;
-    decode(first + seq * (int)gridDim.x, py, px, mblk, nblk);
+    decode(item_of(seq), py, px, mblk, nblk);
     const int sub = mblk * SB + tsb;
+    if constexpr (DG) {
+      if (sub < p.nsub) {
+        const int n = sub / per_img, r2 = sub - n * per_img;
+        const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
+        const int a0 = 2 * (bby * PB + tty), b0 = 2 * (bbx * PB + ttx);
+        // destination of this wave's couts (block-uniform: a cout block never straddles csplit)
+        const int co = nblk * BN + 16 * NM * cg + 4 * pc;
+        const bool second = p.out2 != nullptr && nblk * BN >= p.csplit;
+        float* ob = second ? p.out2 : p.out;
+        const float* mb = second ? p.mask2 : p.mask1;
+        const int ostride = p.out2 ? (second ? p.Cout - p.csplit : p.csplit) : p.Cout;
+        const int ocol = second ? co - p.csplit : co;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const int a = a0 + u, b = b0 + v;
+            if (a >= p.Hs || b >= p.Ws) continue;
+            const long o = ((long)(n * p.Hs + a) * p.Ws + b) * ostride + ocol;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+              f32x4 y = (acc[u * 3 + v][m] + acc[u * 3 + v + 1][m]) + (acc[(u + 1) * 3 + v][m] + acc[(u + 1) * 3 + v + 1][m]);
+              if (mb) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(mb + o + 16 * m);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = z[e] > 0.f ? y[e] : 0.f;
+              }
+              *reinterpret_cast<f32x4*>(ob + o + 16 * m) = y;
+            }
+          }
+      }
+      continue;
+    }
     if (sub < p.nsub) {
       const int n = sub / per_img, r2 = sub - n * per_img;
       const int bby = r2 / p.BBX, bbx = r2 - bby * p.BBX;
@@ -364,6 +420,23 @@ __global__ void pack_wino_phase_weight_kernel(const float* __restrict__ w, float
   const float v[9] = {g00, g00 + g01, g01, g00 + g10, (g00 + g01) + (g10 + g11), g01 + g11, g10, g10 + g11, g11};
 #pragma unroll
   for (int x = 0; x < 9; ++x) u[(((long)ph * 9 + x) * Cout + co) * Cin + ci] = v[x];
+}
+
+// Data-gradient filters: wd [Cin][4][4][Cout] (rs_pack_dgrad_phase_weight_dt: the 4x4 / stride-2 taps over dz) -> U [4][9][Cin][Cout].
+// Unit (py, px) of an output item reads plane (1 - py, 1 - px) of dz with the 2x2 taps g[r][s] = wd[ci][2 r + py][2 s + px][co]
+// (= w4[2 r + 1 - pa][2 s + 1 - pb]); U = G g G^T as in the forward pack.
+__global__ void pack_wino_dgrad_weight_kernel(const float* __restrict__ wd, float* __restrict__ u, int Cin, int Cout, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [4][Cin][Cout]
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  const long r = i / Cout;
+  const int ci = (int)(r % Cin), ph = (int)(r / Cin), py = ph >> 1, px = ph & 1;
+  const float* g = wd + (long)ci * 16 * Cout + co;  // [4][4][Cout]
+  const float g00 = g[(long)(py * 4 + px) * Cout], g01 = g[(long)(py * 4 + 2 + px) * Cout];
+  const float g10 = g[(long)((2 + py) * 4 + px) * Cout], g11 = g[(long)((2 + py) * 4 + 2 + px) * Cout];
+  const float v[9] = {g00, g00 + g01, g01, g00 + g10, (g00 + g01) + (g10 + g11), g01 + g11, g10, g10 + g11, g11};
+#pragma unroll
+  for (int x = 0; x < 9; ++x) u[(((long)ph * 9 + x) * Cin + ci) * Cout + co] = v[x];
 }
 
 int wino_cus() {
@@ -467,6 +540,9 @@ extern "C" int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1
   a.nsub = d->N * a.BBY * a.BBX;
   a.ncb = d->Cout / (32 * pl.wgn);
   a.relu = d->relu;
+  a.out2 = nullptr;
+  a.mask1 = a.mask2 = nullptr;
+  a.csplit = 0;
   const long items = (long)rs_cdiv(a.nsub, pl.sb) * a.ncb * 4;
   if (items >= (1L << 31)) return RS_EINVAL;
   // persistent: one block per CU (its LDS stages fill the CU), items dealt round-robin
@@ -477,5 +553,84 @@ extern "C" int rs_conv2d_fwd_phase_wino(const rs_conv_desc* d, const float* src1
   else if (pl.pb == 8) conv_wino_f32_kernel<8, 8, 1><<<grid, 512, 0, s>>>(a);
   else if (pl.wgn == 2) conv_wino_f32_kernel<4, 4, 2><<<grid, 512, 0, s>>>(a);
   else conv_wino_f32_kernel<4, 8, 1><<<grid, 512, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}
+
+// ---- the DecoderBlock's data gradient in the same form (round 6) ---------------------------------------------------------------------
+// `d` is the FORWARD layer's descriptor (DecoderBlock: ups = 1, 3x3, pad 1; Hs x Ws the source grid, C1 + C2 the concatenated input
+// channels, Cout the block's output channels): the gradient has Cout INPUT channels (dz, at 2 Hs x 2 Ws) and C1 + C2 OUTPUT channels.
+namespace {
+bool wino_dgrad_plan(const rs_conv_desc* d, rs_conv_desc* g, WinoPlan* pl) {
+  if (!d || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0) return false;
+  *g = *d;
+  g->C1 = d->Cout;
+  g->C2 = 0;
+  g->Cout = d->C1 + d->C2;
+  if (!wino_plan(g, pl) || !pl->worth) return false;
+  // (dz images are four times the plan's: 32-bit byte offsets within a block's images)
+  if ((long)(pl->sb + 1) * 4 * d->Hs * d->Ws * g->C1 * 4 >= (1L << 31)) return false;
+  if (g->Cout % 64) return false;  // (64-cout blocks only: every DecoderBlock input of the U-Net is a multiple of 64 channels)
+  return true;
+}
+}  // namespace
+
+extern "C" int rs_conv2d_dgrad_phase_wino_ok(const rs_conv_desc* d) {
+  rs_conv_desc g;
+  WinoPlan pl;
+  return wino_dgrad_plan(d, &g, &pl) ? 1 : 0;
+}
+
+extern "C" const char* rs_conv2d_dgrad_phase_wino_name(const rs_conv_desc* d) {
+  rs_conv_desc g;
+  WinoPlan pl;
+  if (!wino_dgrad_plan(d, &g, &pl)) return "";
+  return pl.wide ? "conv_wino_f32<dgrad4x4,p8,128x64>" : "conv_wino_f32<dgrad4x4,p8,64x64>";
+}
+
+extern "C" int rs_pack_wino_dgrad_weight(const float* wd4x4, float* u, int Cin, int Cout, rs_stream_t stream) {
+  if (!wd4x4 || !u || Cin <= 0 || Cout <= 0) return RS_EINVAL;
+  const long total = 4L * Cin * Cout;
+  pack_wino_dgrad_weight_kernel<<<rs_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(wd4x4, u, Cin, Cout, total);
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_conv2d_dgrad_phase_wino(const rs_conv_desc* d, const float* dz, const float* u, float* out, const float* mask,
+                                          float* out2, const float* mask2, int csplit, rs_stream_t stream) {
+  rs_conv_desc g;
+  WinoPlan pl;
+  if (!wino_dgrad_plan(d, &g, &pl) || !dz || !u || !out) return RS_EINVAL;
+  if (out2 ? (csplit <= 0 || csplit >= g.Cout || (csplit % 64) != 0) : (csplit != 0 || mask2 != nullptr)) return RS_EINVAL;
+  WinoArgs a;
+  a.src1 = dz;
+  a.src2 = nullptr;
+  a.u = u;
+  a.out = out;
+  a.out2 = out2;
+  a.mask1 = mask;
+  a.mask2 = mask2;
+  a.csplit = csplit;
+  a.N = d->N;
+  a.Hs = d->Hs;
+  a.Ws = d->Ws;
+  a.C1 = g.C1;
+  a.C2 = 0;
+  a.Cout = g.Cout;
+  a.TY = (d->Hs + 1) / 2;
+  a.TX = (d->Ws + 1) / 2;
+  a.BBY = rs_cdiv(a.TY, pl.pb);
+  a.BBX = rs_cdiv(a.TX, pl.pb);
+  a.nsub = d->N * a.BBY * a.BBX;
+  a.ncb = g.Cout / 64;
+  a.relu = 0;
+  // (the wide block where that leaves two OUTPUT items per CU: there is no parity factor in the item count here)
+  bool wide = false;
+  if (wino_wide()) wide = (long)((a.nsub + 1) / 2) * a.ncb >= 2L * wino_cus();
+  const int sb = wide ? 2 : 1;
+  const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
+  if (items >= (1L << 29)) return RS_EINVAL;
+  const int grid = (int)(items < wino_cus() ? items : wino_cus());
+  hipStream_t s = (hipStream_t)stream;
+  if (wide) conv_wino_f32_kernel<8, 8, 1, 4, true><<<grid, 512, 0, s>>>(a);
+  else conv_wino_f32_kernel<8, 4, 2, 2, true><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }

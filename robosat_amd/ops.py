@@ -386,6 +386,64 @@ def conv2d_phase_wino(src1, u, src2=None, relu=False):
     return out
 
 
+def wino_dgrad_ok(n, hs, ws, c1, c2, cout):
+    """Whether the fp32 DecoderBlock (sources [n,hs,ws,c1(+c2)] -> cout at 2 hs x 2 ws) can take its data gradient through the Winograd
+    form (``rs_conv2d_dgrad_phase_wino_ok``: geometry only; ROBOSAT_WINO_DGRAD=0 keeps the 4x4 / stride-2 kernel for A/B runs)."""
+
+    import os
+
+    if os.environ.get("ROBOSAT_WINO_DGRAD", "1") == "0":
+        return False
+    d = ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, 2 * hs, 2 * ws, cout, 0, 0)
+    return _lib.lib().rs_conv2d_dgrad_phase_wino_ok(ctypes.byref(d)) == 1
+
+
+def pack_wino_dgrad_weight(wd4x4):
+    """[Cin,4,4,Cout] fp32 (``pack_dgrad_phase_weight``) -> the transformed data-gradient filters [4,9,Cin,Cout]
+    (``rs_pack_wino_dgrad_weight``)."""
+
+    cin, kh, kw, cout = wd4x4.shape
+    assert kh == 4 and kw == 4 and wd4x4.dtype == torch.float32
+    u = torch.empty((4, 9, cin, cout), device=wd4x4.device, dtype=torch.float32)
+    check(_lib.lib().rs_pack_wino_dgrad_weight(_dev(wd4x4, "wd"), _dev(u, "u"), cin, cout, _stream()), "rs_pack_wino_dgrad_weight")
+    return u
+
+
+def conv2d_dgrad_phase_wino(dz, u, c1, c2=0, mask1=None, mask2=None, split=False):
+    """Data gradient of the fp32 DecoderBlock wrt cat[skip, prev] at source resolution (``rs_conv2d_dgrad_phase_wino``): ``dz``
+    [N,2Hs,2Ws,Cout], ``u`` from ``pack_wino_dgrad_weight``.  ``split``: two tensors ([..,c1], [..,c2]) with their optional ReLU masks
+    (torch.cat's backward fused into the store); else one tensor [..,c1+c2] with ``mask1``.  Returns (d1, d2 | None)."""
+
+    n, ho, wo, cout = dz.shape
+    hs, ws = ho // 2, wo // 2
+    assert tuple(u.shape) == (4, 9, c1 + c2, cout) and dz.dtype == torch.float32
+    d = ConvDesc(n, hs, ws, c1, c2, 1, 3, 3, 1, 1, ho, wo, cout, 0, 0)
+    if split:
+        out1 = torch.empty((n, hs, ws, c1), device=dz.device, dtype=torch.float32)
+        out2 = torch.empty((n, hs, ws, c2), device=dz.device, dtype=torch.float32)
+    else:
+        out1, out2 = torch.empty((n, hs, ws, c1 + c2), device=dz.device, dtype=torch.float32), None
+        assert mask2 is None
+    for m, o in ((mask1, out1), (mask2, out2)):
+        assert m is None or tuple(m.shape) == tuple(o.shape)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv2d_dgrad_phase_wino(ctypes.byref(d), _dev(dz, "dz"), _dev(u, "u"), _dev(out1, "out"), _dev(mask1, "mask"),
+                                               _dev(out2, "out2"), _dev(mask2, "mask2"), c1 if split else 0, _stream())
+    check(rc, "rs_conv2d_dgrad_phase_wino")
+    if PROFILE is not None:
+        ev1.record()
+        # algorithmic: the reference's 3x3 at the upsampled resolution; the 4x4 / stride-2 form executes 16 taps at source resolution,
+        # this form 9/16 of those
+        alg = 2.0 * n * ho * wo * cout * (c1 + c2) * 9
+        ex4 = 2.0 * n * hs * ws * cout * (c1 + c2) * 16
+        nbytes = 4 * (n * ho * wo * cout + 16 * cout * (c1 + c2) + n * hs * ws * (c1 + c2) * (1 + (mask1 is not None) * (c1 if split else c1 + c2) / (c1 + c2)
+                                                                                            + (mask2 is not None) * c2 / (c1 + c2)))
+        _record(_lib.lib().rs_conv2d_dgrad_phase_wino_name(ctypes.byref(d)).decode(), alg, (cout, c1 + c2, 4, 2, 0, hs, ws), ev0, ev1, nbytes, ex4 * 9.0 / 16.0)
+    return out1, out2
+
+
 def _conv33_desc(src, cout, relu):
     n, h, w, c = src.shape
     return ConvDesc(n, h, w, c, 0, 0, 3, 3, 1, 1, h, w, cout, int(relu), 0)

@@ -114,6 +114,17 @@ class _Conv(nn.Module):
             self._dgrad_phase = c
         return c[1]
 
+    def dgrad_phase_wino(self):
+        """The transformed filters of the fp32 Winograd form of DecoderBlock's data gradient (``rs_pack_wino_dgrad_weight`` on
+        ``dgrad_phase``), cached like ``phase``."""
+
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0])
+        c = getattr(self, "_dgrad_phase_wino", None)
+        if c is None or c[0] != key:
+            c = (key, ops.pack_wino_dgrad_weight(self.dgrad_phase(torch.float32)))
+            self._dgrad_phase_wino = c
+        return c[1]
+
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(self.cin, self.cout, self.k, self.stride, self.padding)
 

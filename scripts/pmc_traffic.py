@@ -39,9 +39,14 @@ def bench_name(k):
         return "conv_igemm_{}<{}{}x{},r{}>".format("f32" if m.group(1) == "f" else "bf16",
                                                   "phase," if m.group(5) == "1" else "", m.group(2), m.group(3), m.group(4))
     # per-instantiation names, spelled as bench.py reports them (ops.wgrad_kernel_name / conv_tile_name / rs_conv2d_phase_wino_name)
-    m = re.search(r"conv_wino_f32_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?>", k)
+    m = re.search(r"conv_wino_f32_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?(?:, (true|false))?>", k)
+    if m:  # (last parameter, round 6: the data-gradient instantiations)
+        return "conv_wino_f32<{},p{},{}x{}>".format("dgrad4x4" if m.group(5) == "true" else "phase", m.group(1), 16 * int(m.group(2)),
+                                                    16 * int(m.group(4) or 2) * int(m.group(3)))
+    m = re.search(r"conv_wino_f32_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", k)
     if m:
-        return "conv_wino_f32<phase,p{},{}x{}>".format(m.group(1), 16 * int(m.group(2)), 16 * int(m.group(4) or 2) * int(m.group(3)))
+        return "conv_wino_f32<{},p{},{}x{}>".format("dgrad4x4" if m.group(5) == "1" else "phase", m.group(1), 16 * int(m.group(2)),
+                                                    16 * int(m.group(4)) * int(m.group(3)))
     m = re.search(r"conv_wino33_f32_kernel<(\d+), (\d+)(?:, (true|false|\d+))?>", k)
     if m:  # (third parameter: 0 / absent = the layer alone, 1..3 = + self.final with one of its three output kinds)
         head = m.group(3) not in (None, "false", "0")

@@ -399,3 +399,19 @@ def test_bf16_train_step_beside_an_lds_user_equals_the_step_alone(control):
             bad.append((r, float(l0), float(l1), diff[:4], len(diff)))
     assert len(g0) == 168
     assert not bad, bad
+
+
+def test_wino_dgrad_fp32_beside_an_lds_user(control):
+    """The fp32 DecoderBlock data gradient in the Winograd form (round 6): per-unit gather tables cross a barrier, the accumulators live
+    across four units."""
+    from robosat_amd import ops
+
+    g = _gen(69)
+    n, c1, c2, cout, hs = 4, 256, 64, 128, 64  # dec3's class
+    wd = ops.pack_dgrad_phase_weight(torch.randn(cout, 3, 3, c1 + c2, device=DEV, generator=g) * 0.03)
+    u = ops.pack_wino_dgrad_weight(wd)
+    m2 = torch.randn(n, hs, hs, c2, device=DEV, generator=g)
+    assert ops.wino_dgrad_ok(n, hs, hs, c1, c2, cout)
+    bad = _twice(lambda: (torch.randn(n, 2 * hs, 2 * hs, cout, device=DEV, generator=g),),
+                 lambda dz: ops.conv2d_dgrad_phase_wino(dz, u, c1, c2, mask2=m2, split=True), 60, k=control["k"])
+    assert not bad, bad

@@ -425,3 +425,48 @@ def test_relu_mask_as_bits(case, dtype):
     assert float((g1 == 0).float().mean()) > 0.2  # the mask did something
     with pytest.raises(Exception):
         ops.bn_apply(y[..., :24].contiguous(), scale[:24], shift[:24], relu=True, want_bits=True)  # 24 does not divide 2048
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,hs,ws,masks", [
+    (2, 128, 0, 32, 16, 16, True),      # dec4's class: one source, one mask, two chunks per parity plane
+    (1, 256, 64, 128, 16, 32, True),    # dec3's class: two destinations, a mask each, two patches side by side
+    (2, 64, 64, 64, 24, 20, False),     # ragged patches (12 x 10 tiles), no masks
+    (1, 128, 64, 64, 17, 15, True),     # odd sizes: the last tile row / column hangs over the image
+    (3, 64, 0, 32, 31, 33, False),      # blocks that straddle images
+    (2, 192, 128, 64, 16, 16, True),    # csplit = 192: a multiple of 64, not of 128
+])
+def test_wino_dgrad_fp32_vs_autograd_and_the_4x4_kernel(n, c1, c2, cout, hs, ws, masks):
+    """The fp32 DecoderBlock's data gradient in the Winograd form (rs_conv2d_dgrad_phase_wino, round 6: four parity planes of dz
+    accumulated into one source-resolution tile, 9/16 of the 4x4 / stride-2 kernel's multiply-adds) against autograd of the reference
+    formulation (unet.py:63-73; torch.cat's backward and the ReLU masks of the layers below fused into the store) and against the
+    generic kernel on the same launch -- exact-fp32 MFMA both, only the summation order differs.  Also: the rule is geometry only and
+    it is what the fp32 training step runs."""
+    from robosat_amd import ops
+
+    a = rnd(n, c1, hs, ws, seed=1).requires_grad_(True)
+    b = rnd(n, c2, hs, ws, seed=2).requires_grad_(True) if c2 else None
+    wt = rnd(cout, c1 + c2, 3, 3, seed=3) * (2.0 / ((c1 + c2) * 9)) ** 0.5
+    y = F.conv2d(F.interpolate(torch.cat([a, b], 1) if c2 else a, scale_factor=2, mode="nearest"), wt, padding=1)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    m1 = rnd(n, c1, hs, ws, seed=5) if masks else None
+    m2 = rnd(n, c2, hs, ws, seed=6) if (masks and c2) else None
+    want1 = a.grad * (m1 > 0) if masks else a.grad
+    want2 = (b.grad * (m2 > 0) if masks else b.grad) if c2 else None
+    dev = lambda t: None if t is None else nhwc(t)
+    wd = ops.pack_dgrad_phase_weight(krsc(wt))
+    u = ops.pack_wino_dgrad_weight(wd)
+    dz = nhwc(gy)
+    assert ops.wino_dgrad_ok(n, hs, ws, c1, c2, cout) and ops.wino_dgrad_ok(7 * n, hs, ws, c1, c2, cout)  # (never the batch size)
+    assert not ops.wino_dgrad_ok(n, 8, 8, c1, c2, cout)  # (fewer than 8 tiles per image side: the 4x4 kernel keeps it -- `center`)
+    if c2:
+        g1, g2 = ops.conv2d_dgrad_phase_wino(dz, u, c1, c2, mask1=dev(m1), mask2=dev(m2), split=True)
+        r1, r2 = ops.conv2d_split(dz, wd, c1, stride=2, pad=1, out_hw=(hs, ws), mask1=dev(m1), mask2=dev(m2))
+    else:
+        g1, g2 = ops.conv2d_dgrad_phase_wino(dz, u, c1, 0, mask1=dev(m1))
+        r1, r2 = ops.conv2d(dz, wd, stride=2, pad=1, out_hw=(hs, ws), relu_mask=dev(m1)), None
+    for got, ref, want, what in ((g1, r1, want1, "d skip"), (g2, r2, want2, "d prev")):
+        if got is None:
+            continue
+        close(nchw(got), want, 2e-5, what + " vs autograd")
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), what + " vs the 4x4 / stride-2 kernel"

@@ -179,6 +179,9 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_wino33_f32_kernel<4, 2, 0>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3,p8,64x32>",
         ns + "conv_wino33_f32_kernel<4, 2, 1>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
         ns + "conv_wino33_f32_kernel<4, 2, 3>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
+        ns + "conv_wino_f32_kernel<8, 8, 1, 4, false>((anonymous namespace)::WinoArgs)": "conv_wino_f32<phase,p8,128x64>",
+        ns + "conv_wino_f32_kernel<8, 4, 2, 2, true>((anonymous namespace)::WinoArgs)": "conv_wino_f32<dgrad4x4,p8,64x64>",
+        "_ZN12_GLOBAL__N_120conv_wino_f32_kernelILi8ELi8ELi1ELi4ELb1EEEvNS_8WinoArgsE": "conv_wino_f32<dgrad4x4,p8,128x64>",
         ns + "conv_igemm_dma<float, 128, 128, 2, 2, 64, false, 0>(ConvArgsT<float>)": "conv_igemm_f32<128x128,r64>",
         ns + "conv_igemm_dma<float, 64, 64, 2, 2, 128, true, 0>(ConvArgsT<float>)": "conv_igemm_f32<phase,64x64,r128>",
         "_ZN12_GLOBAL__N_114conv_igemm_dmaIDF16bLi128ELi128ELi2ELi2ELi64ELb0ELi2EEEv9ConvArgsTIT_E": "conv_igemm_bf16<128x128,r64>",

@@ -365,6 +365,12 @@ const char* rs_conv2d_wino33_head_name(void);
 int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
                               const float* final_w, const float* final_b, int C, int mode, const double* anchors, int overlap,
                               float* out, uint8_t* qout, rs_stream_t stream);
+/* The same layers in the TRAIN-mode forward (torchvision Bottleneck.conv2 -> BatchNorm2d under tools/train.py:169, fp32): the raw
+ * convolution output plus the per-block partial sums of the BatchNorm statistics (sum y, sum y^2 over the block's pixels, in a fixed
+ * order), `stats` [rs_conv2d_wino33_stats_rows(d)][2][Cout] fp32 -- the input of rs_bn_finalize_stats, as rs_conv2d_fwd_bnstats_dt's
+ * rows are.  `d` / `u` as for rs_conv2d_fwd_wino33 (rs_conv2d_wino33_ok decides; d->relu ignored). */
+long rs_conv2d_wino33_stats_rows(const rs_conv_desc* d);
+int rs_conv2d_fwd_wino33_stats(const rs_conv_desc* d, const float* src, const float* u, float* out, float* stats, rs_stream_t stream);
 
 /* ... and its data gradient: d loss / d (pre-upsample input) is ONE 4x4 / stride-2 / pad-1 convolution over dz with
  * pre-summed taps (rs_conv2d_fwd[_bf16] with kh = kw = 4 and these weights, [Cin][4][4][Cout]): the gradient lands at

@@ -187,11 +187,16 @@ def _bn_train(bn, y, residual=None, relu=True, partial=None, want_bits=False):
     return z, (mean, invstd)
 
 
-def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True):
+def _conv_bn(bn, src, w, stride=1, pad=0, residual=None, relu=True, conv=None):
     """conv -> train-mode BatchNorm (-> + residual -> ReLU) with the statistics fused into the convolution: returns
-    (y, z, (mean, invstd), ReLU mask bits of z or None)."""
+    (y, z, (mean, invstd), ReLU mask bits of z or None).  ``conv``: the module, for the stride-1 3x3 layers of the fp32 path, which
+    run the Winograd F(2x2, 3x3) form with the same statistics epilogue (4/9 of the multiply-adds)."""
 
-    y, partial = ops.conv2d_bnstats(src, w, stride=stride, pad=pad)
+    if (conv is not None and src.dtype == torch.float32 and stride == 1 and pad == 1 and ops.wino33_ok(src, conv.cout)
+            and os.environ.get("ROBOSAT_WINO33_STATS", "1") != "0"):
+        y, partial = ops.conv2d_wino33_bnstats(src, conv.wino33())
+    else:
+        y, partial = ops.conv2d_bnstats(src, w, stride=stride, pad=pad)
     z, st, bits = _bn_train(bn, y, residual=residual, relu=relu, partial=partial, want_bits=True)
     return y, z, st, bits
 
@@ -249,7 +254,7 @@ def _forward(net, x, tape, backward=False):
         for blk in layer:
             rec = {"blk": blk, "h": h}
             y1, z1, rec["st1"], rec["b1"] = _conv_bn(blk.bn1, h, blk.conv1.krsc(dt))
-            y2, z2, rec["st2"], rec["b2"] = _conv_bn(blk.bn2, z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1)
+            y2, z2, rec["st2"], rec["b2"] = _conv_bn(blk.bn2, z1, blk.conv2.krsc(dt), stride=blk.stride, pad=1, conv=blk.conv2)
             if blk.downsample is not None:
                 yd, idt, rec["std"], _ = _conv_bn(blk.downsample[1], h, blk.downsample[0].krsc(dt), stride=blk.stride, relu=False)
                 rec["yd"] = yd

@@ -134,6 +134,15 @@ __device__ __forceinline__ float rs_xor32_sum(float v) {
   return a + b;
 }
 
+// sum over the 16 lanes of the lane's DPP row, in every lane of the row: v + ror 8, + ror 4, + ror 2, + ror 1 (VALU only: no LDS crossbar)
+__device__ __forceinline__ float rs_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 __device__ __forceinline__ float rs_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -45,6 +45,9 @@ struct Wino33Args {
   float* hout;             // NCHW fp32 logits / probabilities (modes 0, 1)
   unsigned char* hq;       // quantised probabilities (mode 2) / class indices (mode 3)
   int hC, hmode, hov;
+  // STATS instantiations only -- the train-mode forward (torchvision BatchNorm2d under tools/train.py:169): `out` holds the RAW
+  // convolution output and stats [m blocks][2][Cout] the per-block sum / sum of squares of it (rs_bn_finalize_stats's input)
+  float* stats;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -68,8 +71,14 @@ __device__ __forceinline__ int w33_swz(int row) { return (row ^ (row >> 1)) & 3;
 // HEAD: 0 = the layer alone; 1 / 2 / 3 = + self.final and logits-or-softmax / quantised probabilities / argmax (one
 // instantiation per output kind: each carries only its own epilogue code -- the kernel's instructions are fetched cold on
 // every launch, which a single-tile `rs serve` request pays for in full)
-template <int TG, int CG, int HEAD = 0>
+// MODE: 0 = the layer alone; 1 / 2 / 3 = + self.final (see above); 4 (round 6) = the layer alone + the partial sums of train-mode
+// BatchNorm's statistics over the block's outputs (sum y, sum y^2 per cout and m block), summed in a fixed order: lane (its 2x2
+// pixels) -> the wave's 16 tiles (DPP row rotations: no LDS) -> the block's tile groups (through LDS, picked up behind the first
+// barrier of the block's next item like the head's exchange) -> one row of `stats` per m block.
+template <int TG, int CG, int MODE = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Args p) {
+  constexpr int HEAD = (MODE >= 1 && MODE <= 3) ? MODE : 0;
+  constexpr bool STATS = MODE == 4;
   constexpr int NW = TG * CG;
   static_assert(NW == 8, "8 waves");
   static_assert(!HEAD || (TG == 4 && CG == 2), "the fused head: one 8x8 patch of tiles x all 32 couts per block");
@@ -87,10 +96,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   //       (two exchange buffers: an item's second half runs behind the first barrier of the block's NEXT item)
   // (exchange rows of 36 floats: 16 lanes' 16-byte accesses at a 144-byte pitch fall into 16 different bank groups)
   constexpr int HEADW = kHeadMaxC * 32 + kHeadMaxC, XROW = 4 * kHeadMaxC + 4, XCH = BMT * XROW;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * AROWS_PAD * 4 + (HEAD ? (HEADW + 2 * XCH) * 4 : 0)];
+  constexpr int XST = 2 * TG * BN;  // STATS: per exchange buffer [2 sums][TG tile groups][BN couts]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * AROWS_PAD * 4 + (HEAD ? (HEADW + 2 * XCH) * 4 : 0) + (STATS ? 2 * XST * 4 : 0)];
   int* tabs = reinterpret_cast<int*>(smem + 2 * STAGE);
   float* hws = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * AROWS_PAD * 4);
   float* xch = hws + HEADW;
+  float* xst = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * AROWS_PAD * 4);  // (STATS; never together with HEAD)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,6 +235,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
     }
   };
 
+  // STATS: the previous item's exchange buffer -> its row of `stats` (threads 0 .. 2 BN - 1: sum c of stat tid / BN over the tile groups)
+  int st_buf = 0, st_row = 0, st_col = 0;
+  auto finish_stats = [&]() __attribute__((always_inline)) {
+    if constexpr (STATS) {
+      if (threadIdx.x < 2 * BN) {
+        const int which = threadIdx.x / BN, c = threadIdx.x - which * BN;
+        const float* x = xst + st_buf * XST + which * TG * BN + c;
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) a += x[t * BN];
+        p.stats[((long)st_row * 2 + which) * p.Cout + st_col + c] = a;
+      }
+    }
+  };
   int g = 0;
   for (int seq = 0; seq < nitems; ++seq) {
     f32x4 acc[16];
@@ -234,6 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
       rb_dma_wait();
       __syncthreads();
       if (HEAD && kc == 0 && seq > 0) finish_head();  // (behind this barrier the other cout group's partial logits are in LDS)
+      if (STATS && kc == 0 && seq > 0) finish_stats();
       const unsigned char* L = smem + (g & 1) * STAGE;
       f32x4 V[16];
       {
@@ -328,6 +354,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
         }
     }
     if constexpr (!HEAD) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       if (live) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -336,7 +363,28 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
             const int a = a0 + u, b = b0 + v;
             if (a >= p.H || b >= p.W) continue;
             *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = Y[u][v];
+            if constexpr (STATS) {
+              s0 += Y[u][v];
+              s1 += Y[u][v] * Y[u][v];
+            }
           }
+      }
+      if constexpr (STATS) {
+        // over the wave's 16 tiles (lanes l15 of each 16-lane row): four DPP row rotations, every lane of the row ends with the row's sum
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0[e] = rs_row16_sum(s0[e]);
+          s1[e] = rs_row16_sum(s1[e]);
+        }
+        st_buf = seq & 1;
+        st_row = mblk;
+        st_col = nblk * BN;
+        if (l15 == 0) {
+          float* x = xst + st_buf * XST + tg * BN + 16 * cg + 4 * pc;
+          *reinterpret_cast<f32x4*>(x) = s0;
+          *reinterpret_cast<f32x4*>(x + TG * BN) = s1;
+          rs_lds_writes_done();  // (read behind the next barrier, which hipcc emits bare: common.h)
+        }
       }
     } else {
       // ---- self.final on the block's 32 channels: this lane's 4 couts -> the wave's 16 (lanes l15 + 16 pc) -> both cout
@@ -390,6 +438,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   if constexpr (HEAD) {
     __syncthreads();
     if (nitems > 0) finish_head();
+  }
+  if constexpr (STATS) {
+    __syncthreads();
+    if (nitems > 0) finish_stats();
   }
   rb_dma_wait();  // (the re-issued pieces of the last chunk: landed before this block's LDS is handed to the next one)
 }
@@ -497,6 +549,7 @@ extern "C" int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, con
   a.hout = nullptr;
   a.hq = nullptr;
   a.hC = a.hmode = a.hov = 0;
+  a.stats = nullptr;
   const int sb = 16 * (8 / cgn) / (kPB * kPB);
   const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
   if (items >= (1L << 31)) return RS_EINVAL;
@@ -542,6 +595,7 @@ extern "C" int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src
   a.hC = C;
   a.hmode = mode;
   a.hov = overlap;
+  a.stats = nullptr;
   const long items = a.nsub;
   if (items >= (1L << 31)) return RS_EINVAL;
   const int grid = (int)(items < w33_cus() ? items : w33_cus());
@@ -549,5 +603,49 @@ extern "C" int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src
   if (mode <= 1) conv_wino33_f32_kernel<4, 2, 1><<<grid, 512, 0, s>>>(a);
   else if (mode == 2) conv_wino33_f32_kernel<4, 2, 2><<<grid, 512, 0, s>>>(a);
   else conv_wino33_f32_kernel<4, 2, 3><<<grid, 512, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}
+
+// Train-mode forward of the same layers (round 6): RAW output + the partial sums of BatchNorm's statistics, one row of `stats`
+// [rows][2][Cout] per block of 64 (Cout % 32 == 0) / 128 tiles -- rs_conv2d_wino33_stats_rows(d) rows, every entry written.
+extern "C" long rs_conv2d_wino33_stats_rows(const rs_conv_desc* d) {
+  int cgn;
+  if (!w33_plan(d, &cgn)) return RS_EINVAL;
+  const int sb = 16 * (8 / cgn) / (kPB * kPB);
+  return rs_cdiv((long)d->N * rs_cdiv((d->Hs + 1) / 2, kPB) * rs_cdiv((d->Ws + 1) / 2, kPB), sb);
+}
+
+extern "C" int rs_conv2d_fwd_wino33_stats(const rs_conv_desc* d, const float* src, const float* u, float* out, float* stats,
+                                          rs_stream_t stream) {
+  int cgn;
+  if (!w33_plan(d, &cgn) || !src || !u || !out || !stats) return RS_EINVAL;
+  Wino33Args a;
+  a.src = src;
+  a.u = u;
+  a.scale = a.shift = nullptr;
+  a.out = out;
+  a.N = d->N;
+  a.H = d->Hs;
+  a.W = d->Ws;
+  a.Cin = d->C1;
+  a.Cout = d->Cout;
+  a.BBY = rs_cdiv((d->Hs + 1) / 2, kPB);
+  a.BBX = rs_cdiv((d->Ws + 1) / 2, kPB);
+  a.nsub = d->N * a.BBY * a.BBX;
+  a.ncb = d->Cout / (16 * cgn);
+  a.relu = 0;
+  a.hw = a.hb = nullptr;
+  a.hanchors = nullptr;
+  a.hout = nullptr;
+  a.hq = nullptr;
+  a.hC = a.hmode = a.hov = 0;
+  a.stats = stats;
+  const int sb = 16 * (8 / cgn) / (kPB * kPB);
+  const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
+  if (items >= (1L << 31)) return RS_EINVAL;
+  const int grid = (int)(items < w33_cus() ? items : w33_cus());
+  hipStream_t s = (hipStream_t)stream;
+  if (cgn == 2) conv_wino33_f32_kernel<4, 2, 4><<<grid, 512, 0, s>>>(a);
+  else conv_wino33_f32_kernel<8, 1, 4><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }

@@ -492,6 +492,33 @@ def conv2d_wino33(src, u, scale=None, shift=None, relu=False):
     return out
 
 
+def conv2d_wino33_bnstats(src, u):
+    """Train-mode ``conv3x3 -> BatchNorm`` front half in the fp32 Winograd form (``rs_conv2d_fwd_wino33_stats``): the raw output and
+    the per-block partial sums of its statistics, as ``conv2d_bnstats`` returns them.  ROBOSAT_WINO33_STATS=0 at the call site keeps
+    the generic kernel (A/B runs)."""
+
+    n, h, w, c = src.shape
+    cout = u.shape[1]
+    assert tuple(u.shape) == (16, cout, c) and src.dtype == torch.float32
+    d = _conv33_desc(src, cout, False)
+    lib = _lib.lib()
+    rows = lib.rs_conv2d_wino33_stats_rows(ctypes.byref(d))
+    if rows <= 0:
+        raise ValueError("rs_conv2d_wino33_stats_rows: invalid arguments")
+    out = torch.empty((n, h, w, cout), device=src.device, dtype=torch.float32)
+    partial = torch.empty((rows, 2, cout), device=src.device, dtype=torch.float32)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.rs_conv2d_fwd_wino33_stats(ctypes.byref(d), _dev(src, "src"), _dev(u, "u"), _dev(out, "out"), _dev(partial, "partial"), _stream()),
+          "rs_conv2d_fwd_wino33_stats")
+    if PROFILE is not None:
+        ev1.record()
+        _record(lib.rs_conv2d_wino33_name(ctypes.byref(d)).decode().replace("<3x3,", "<3x3+stats,"), conv_flops(d), (d.C1, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                conv_bytes(d, 4), conv_flops(d) * 4.0 / 9.0)
+    return out, partial
+
+
 def wino33_head_ok(src, cout, classes):
     """Whether dec5 + ``self.final`` run as one launch (``rs_conv2d_wino33_head_ok``: the Winograd 3x3 form on a 32-cout
     layer, <= 8 classes); ROBOSAT_FUSED_HEAD=0 keeps the two launches (A/B runs)."""

@@ -316,6 +316,18 @@ def test_wino33_plain_fp32_beside_an_lds_user(control):
     assert not bad, bad
 
 
+def test_wino33_statistics_fp32_beside_an_lds_user(control):
+    """The train forward's form: raw output + BatchNorm partial sums (a second cross-wave LDS exchange, read behind a barrier)."""
+    from robosat_amd import ops
+
+    g = _gen(50)
+    for n, s, c in ((4, 128, 64), (8, 32, 256)):  # layer1's and layer3's conv2: the 64 x 32 and the 128 x 16 tile
+        u = ops.pack_wino33_weight(torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.05)
+        assert ops.wino33_ok(torch.empty(n, s, s, c, device=DEV), c)
+        bad = _twice(lambda: (torch.randn(n, s, s, c, device=DEV, generator=g),), lambda x: ops.conv2d_wino33_bnstats(x, u), 40, k=control["k"])
+        assert not bad, (c, bad)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_generic_1x1_kernels_beside_an_lds_user(control, dtype):
     """The implicit-GEMM kernel's three epilogue kinds on a 1x1 launch (eval: scale / shift / residual / ReLU; train forward: statistics;

@@ -470,3 +470,31 @@ def test_wino_dgrad_fp32_vs_autograd_and_the_4x4_kernel(n, c1, c2, cout, hs, ws,
             continue
         close(nchw(got), want, 2e-5, what + " vs autograd")
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), what + " vs the 4x4 / stride-2 kernel"
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 32), (1, 128, 128, 17, 15), (3, 256, 256, 16, 16), (2, 64, 128, 24, 40), (5, 32, 32, 16, 16)])
+def test_wino33_train_forward_with_statistics_vs_torch_and_the_generic_kernel(n, cin, cout, h, w):
+    """The stride-1 3x3 convolutions of the fp32 TRAIN forward in the Winograd F(2x2, 3x3) form (rs_conv2d_fwd_wino33_stats, round 6):
+    raw output and the per-block partial sums of BatchNorm's statistics -- against F.conv2d, against the generic kernel's output and
+    against the statistics finalized from either kernel's partial rows (torchvision Bottleneck.conv2 -> bn2, tools/train.py:169)."""
+    from robosat_amd import ops
+
+    x = rnd(n, cin, h, w, seed=11)
+    wt = rnd(cout, cin, 3, 3, seed=12) * (2.0 / (cin * 9)) ** 0.5
+    want = F.conv2d(x, wt, padding=1)
+    xd, wk = nhwc(x), krsc(wt)
+    assert ops.wino33_ok(xd, cout)
+    y, part = ops.conv2d_wino33_bnstats(xd, ops.pack_wino33_weight(wk))
+    yg, partg = ops.conv2d_bnstats(xd, wk, pad=1)
+    close(nchw(y), want, 2e-5, "raw output")
+    assert float((y - yg).abs().max()) <= 2e-5 * float(yg.abs().max())
+    m = n * h * w
+    s = part.double().sum(0).cpu()
+    close(s[0] / m, want.double().mean((0, 2, 3)), 1e-5, "mean from the partial rows")
+    close(s[1] / m, (want.double() ** 2).mean((0, 2, 3)), 1e-5, "mean of squares from the partial rows")
+    sg = partg.double().sum(0).cpu()
+    assert float((s - sg).abs().max()) <= 1e-5 * float(sg.abs().max())
+    g, b = torch.rand(cout) + 0.5, rnd(cout, seed=13)
+    st = ops.bn_finalize_stats(part, m, g.to(DEV), b.to(DEV), 1e-5, 0.1)
+    close(st[0].cpu(), want.mean((0, 2, 3)), 1e-5, "mean")
+    close(st[1].cpu(), 1 / torch.sqrt(want.var((0, 2, 3), unbiased=False) + 1e-5), 1e-4, "invstd")

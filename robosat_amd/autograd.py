@@ -219,6 +219,12 @@ def _prefetch_decoder_weights(net, dt, device):
         for blk in (net.center, net.dec0, net.dec1, net.dec2, net.dec3, net.dec4):
             conv = blk.block.block
             packed += [conv.phase(dt), conv.dgrad_phase(dt)]
+            # fp32: the Winograd forms' transformed filters, for the layers whose geometry took those forms in the previous step (the
+            # first step packs them where they are used)
+            if dt == torch.float32 and getattr(conv, "_phase_wino", None) is not None:
+                packed.append(conv.phase_wino())
+            if dt == torch.float32 and getattr(conv, "_dgrad_phase_wino", None) is not None:
+                packed.append(conv.dgrad_phase_wino())
     done = torch.cuda.Event()
     done.record(side)
     for w in packed:

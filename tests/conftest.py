@@ -21,3 +21,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """The co-residency screen runs LAST.  Its positive control depends on how the box schedules two HIP streams; should it come out
+    INCONCLUSIVE on some box, that must cost the screen's own tests and not -- under the driver's `-x` -- every parity test that would
+    have been collected behind it."""
+    last = [it for it in items if "test_gpu_race_screen" in it.nodeid]
+    if last:
+        items[:] = [it for it in items if "test_gpu_race_screen" not in it.nodeid] + last

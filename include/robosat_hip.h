@@ -113,6 +113,10 @@ int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* o
  * with `in` read through the forward gather (upsample / concat / stem packing).  dw is KRSC (packed [Cout][kh][8][4]
  * for the stem -> rs_unpack_stem_weight).  Split-P partials live in `workspace`; deterministic (no atomics). */
 long rs_conv2d_wgrad_workspace_bytes(const rs_conv_desc* d);
+/* Which form rs_conv2d_wgrad runs this fp32 launch in (a pure host decision on the geometry and the knobs): 0 the direct form,
+ * 2 the phase form of DecoderBlock (unet.py:63-73; 4/9 of the multiply-adds), 3 the same in the Winograd domain of the forward's
+ * F(2x2, 2x2) form (1/4; conv_wgrad_wino_f32.hip, round 6); RS_EINVAL for a descriptor rs_conv2d_wgrad refuses. */
+int rs_conv2d_wgrad_form(const rs_conv_desc* d);
 int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const float* src1, const float* src2, float* dw,
                     void* workspace, rs_stream_t stream);
 int rs_unpack_stem_weight(const float* packed, float* w_krsc, int Cout, int kh, int kw, int Cin, rs_stream_t stream);

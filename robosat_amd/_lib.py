@@ -77,6 +77,7 @@ SIGNATURES = {
     "rs_conv2d_tile_name_bf16": (c_char_p, [c_int]),
     "rs_conv2d_wgrad_bf16_workspace_bytes": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_wgrad_bf16_form": (c_int, [POINTER(ConvDesc)]),
+    "rs_conv2d_wgrad_form": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_wgrad_bf16_tile": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_wgrad_bf16": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "rs_cast_f32_to_bf16": (c_int, [P, P, c_long, P]),

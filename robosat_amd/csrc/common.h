@@ -200,6 +200,8 @@ struct RsKnobs {
   int wgrad_f32_phase = 1;     // RS_WGRAD_F32_PHASE: fp32 DecoderBlock weight gradient in phase form (0: direct form)
   int wgrad_f32_dma = -1;      // RS_WGRAD_F32_DMA: fp32 weight gradient by LDS-DMA (conv_wgrad_f32_dma.hip): -1 by rule, 0 never, 1 wherever it can run
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
+  int wgrad_f32_wino = 1;      // RS_WGRAD_F32_WINO: fp32 DecoderBlock weight gradient in the Winograd domain (conv_wgrad_wino_f32.hip); 0: phase form
+  int wgrad_f32_wino_blocks = 1024;  // RS_WGRAD_F32_WINO_BLOCKS: block target of those launches
   int wgrad_blocks = 96;       // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches (192 for two chunk buffers; 96 with the ring of three: profiles/r05/wgrad_ring.txt)
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
   int wgrad_phase4 = 1;        // RS_WGRAD_PHASE4: the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step).  Round 5 withdrew it for a reproducibility failure whose cause round 6 found (a gather table published through a bare s_barrier: profiles/r06/dma_order.txt) and fixed

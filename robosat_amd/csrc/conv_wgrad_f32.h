@@ -19,3 +19,10 @@ enum { V128x128 = 0, V128x64, V64x128, V64x64, V32x128, V32x32, VSTEM };
 // conv_wgrad_f32_dma.hip: the same blocks (tile variant, tap / phase combination, split of 32-pixel chunks) with both operands
 // copied HBM -> LDS by LDS-DMA as they lie (pixel-major) and read back one dword per MFMA operand.  Never the stem.
 __attribute__((visibility("hidden"))) int rs_wgrad_f32_dma_launch(int variant, bool phase, int grid, hipStream_t s, const WgradArgs& a);
+
+// conv_wgrad_wino_f32.hip (round 6): DecoderBlock's weight gradient in the Winograd domain of the forward's F(2x2, 2x2) form
+// (9/16 of the phase form's multiply-adds); knob wgrad_f32_wino.  Workspace: splits x 36 x Cout x Cin floats.
+__attribute__((visibility("hidden"))) bool rs_wgrad_f32_wino_ok(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) long rs_wgrad_f32_wino_workspace_floats(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) int rs_wgrad_f32_wino_launch(const rs_conv_desc* d, const float* dz, const float* src1, const float* src2,
+                                                                   float* dw, float* workspace, hipStream_t s);

@@ -929,12 +929,14 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         es = 2 if bf else 4
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
         form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d)) if bf else 0
-        if not bf and not stem and ups == 1 and (kh, kw, stride, pad) == (3, 3, 1, 1):
-            form = 2 if get_knob("wgrad_f32_phase") else 0  # conv_wgrad.hip: the fp32 phase form (16 / 36 of the MACs)
+        if not bf and not stem:
+            # conv_wgrad.hip: 2 = the fp32 phase form of DecoderBlock (16 / 36 of the MACs), 3 = that in the Winograd domain (9 / 36)
+            form = lib.rs_conv2d_wgrad_form(ctypes.byref(d))
         # fp32: the LDS-DMA kernel (conv_wgrad_f32_dma.hip) for everything but the packed stem, unless knob wgrad_f32_dma = 0
-        name = wgrad_kernel_name(d, form) if bf else ("conv_wgrad_f32" if stem or get_knob("wgrad_f32_dma") == 0 else "conv_wgrad_f32_dma")
+        name = wgrad_kernel_name(d, form) if bf else ("conv_wgrad_f32" if stem or get_knob("wgrad_f32_dma") == 0 else
+                                                      "conv_wgrad_wino_f32" if form == 3 else "conv_wgrad_f32_dma")
         _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes,
-                conv_flops(d) * (4.0 / 9.0 if form == 2 else 1.0))
+                conv_flops(d) * (0.25 if form == 3 else 4.0 / 9.0 if form == 2 else 1.0))
     return dw
 
 

@@ -316,6 +316,18 @@ def test_wino33_plain_fp32_beside_an_lds_user(control):
     assert not bad, bad
 
 
+def test_wino_domain_wgrad_fp32_beside_an_lds_user(control):
+    """DecoderBlock's fp32 weight gradient in the Winograd domain: gather tables published two chunks ahead, LDS-DMA operands."""
+    from robosat_amd import ops
+
+    g = _gen(51)
+    for n, hs, c1, c2, cout in ((4, 32, 64, 64, 64), (2, 64, 64, 64, 32)):  # both block shapes
+        bad = _twice(lambda: (torch.randn(n, 2 * hs, 2 * hs, cout, device=DEV, generator=g), torch.randn(n, hs, hs, c1, device=DEV, generator=g),
+                              torch.randn(n, hs, hs, c2, device=DEV, generator=g)),
+                     lambda dz, a, b: ops.conv2d_wgrad(dz, a, 3, 3, src2=b, ups=1, pad=1), 40, k=control["k"])
+        assert not bad, (cout, bad)
+
+
 def test_wino33_statistics_fp32_beside_an_lds_user(control):
     """The train forward's form: raw output + BatchNorm partial sums (a second cross-wave LDS exchange, read behind a barrier)."""
     from robosat_amd import ops

@@ -143,6 +143,44 @@ def test_decoder_wgrad_fp32_phase_form_vs_autograd_and_direct_form(n, c1, c2, co
     assert float((dw - direct).abs().max()) <= 1e-4 * float(direct.abs().max())
 
 
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [(2, 64, 0, 64, 8, 8), (1, 128, 64, 32, 9, 13), (3, 64, 64, 64, 16, 12), (2, 192, 128, 128, 7, 5), (1, 64, 0, 96, 33, 20)])
+def test_decoder_wgrad_fp32_winograd_domain_vs_autograd_and_phase_form(n, c1, c2, cout, h, w):
+    """DecoderBlock's fp32 weight gradient in the Winograd domain of the forward's F(2x2, 2x2) form (conv_wgrad_wino_f32.hip, round 6:
+    dU = sum over tiles of (A dY A^T) (.) (B^T d B), dg = G^T dU G; 9/16 of the phase form's multiply-adds) against autograd on the
+    reference formulation (unet.py:63-73) and against the phase form on the same launch: odd sizes (half tiles at the edge), two
+    sources, both block shapes (64 and 32 couts), splits that straddle images."""
+    import ctypes
+
+    from robosat_amd import _lib, ops
+
+    a = rnd(n, c1, h, w, seed=51).requires_grad_(True)
+    b = rnd(n, c2, h, w, seed=52).requires_grad_(True) if c2 else None
+    wt = (rnd(cout, c1 + c2, 3, 3, seed=53) * 0.05).requires_grad_(True)
+    cat = torch.cat([a, b], 1) if c2 else a
+    y = F.conv2d(F.interpolate(cat, scale_factor=2, mode="nearest"), wt, padding=1)
+    gy = rnd(*y.shape, seed=54)
+    y.backward(gy)
+    args = (nhwc(gy), nhwc(a.detach()), 3, 3)
+    kw = dict(src2=nhwc(b.detach()) if c2 else None, ups=1, pad=1)
+    d = ops.ConvDesc(n, h, w, c1, c2, 1, 3, 3, 1, 1, 2 * h, 2 * w, cout, 0, 0)
+    assert ops.get_knob("wgrad_f32_wino") == 1 and _lib.lib().rs_conv2d_wgrad_form(ctypes.byref(d)) == 3  # the shipped setting
+    ops.PROFILE = []
+    try:
+        dw = ops.conv2d_wgrad(*args, **kw)
+        assert [r[0] for r in ops.PROFILE] == ["conv_wgrad_wino_f32"], ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="Winograd-domain wgrad")
+    with ops.knob("wgrad_f32_wino", 0):
+        assert _lib.lib().rs_conv2d_wgrad_form(ctypes.byref(d)) == 2
+        phase = ops.conv2d_wgrad(*args, **kw)
+    assert float((dw - phase).abs().max()) <= 2e-5 * float(phase.abs().max())
+    with ops.knob("wgrad_f32_wino_blocks", 64):  # another split of the tile sequence: same sums up to fp32 order
+        few = ops.conv2d_wgrad(*args, **kw)
+    assert float((dw - few).abs().max()) <= 2e-5 * float(phase.abs().max())
+    assert torch.equal(dw, ops.conv2d_wgrad(*args, **kw))  # deterministic: no atomics, splits summed in order
+
+
 def test_stem_wgrad():
     from robosat_amd import ops
 

@@ -62,16 +62,21 @@ __device__ __forceinline__ unsigned int ww_lds_addr(const void* p) {
   return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
-constexpr int kWwPK = 8;  // tiles per chunk
+constexpr int kWwPK = 8;  // tiles per chunk of the four-wave blocks (the plan counts chunks of this size; the eight-wave block takes two at a time)
 
 template <int N>
 __device__ __forceinline__ void ww_dma_wait_but() {  // this wave's pieces except the N youngest have landed (in order: profiles/r06/dma_order.txt)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_wino_f32(const WinoWgradArgs p) {
-  constexpr int PK = kWwPK, NS = PK / 2;
+// PK tiles per chunk, RING stages.  Shipped: <2, 2, 8, 3> / <1, 2, 8, 3>, four / two waves, two blocks per CU.  Measured beside them
+// (profiles/r06/wino_wgrad.txt): two stages (same time: the DMA's latency is not the bound), an eight-wave block on 128 couts x 64
+// cins with 16-tile chunks and one block per CU (-35 % LDS-DMA bytes per MFMA, half the barriers: same time), two stages at three
+// blocks per CU for the two-wave block (slower alone, same in the step); knock-outs: 80 TF executed as built, 95 without the DMA
+// pieces, 85 without the transforms, 107 without either -- the phase form's kernel runs the same shapes at 110.
+template <int WGM, int WGN, int PK, int RING>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_wgrad_wino_f32(const WinoWgradArgs p) {
+  constexpr int NS = PK / 2;
   constexpr int NW = WGM * WGN;
   constexpr int BM = 32 * WGM, BN = 32 * WGN;
   constexpr int ROWA = BM * 4, ROWB = BN * 4;          // bytes per LDS row (one pixel)
@@ -84,8 +89,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_wino_f32(const W
   constexpr int ABYTES = NRA * ROWA, BBYTES = NRB * ROWB;
   constexpr int BUF = ABYTES + BBYTES;
   constexpr int NT = NRA + NRB;  // table entries per chunk
-  constexpr int RING = 3;  // stages: a chunk is ~1 us of MFMAs, less than the DMA's latency -- its pieces are issued TWO chunks ahead
-  static_assert(RING * BUF + RING * NT * 4 <= 80 * 1024, "two blocks per CU");
+  static_assert(RING * BUF + RING * NT * 4 <= (NW == 8 ? 160 : 80) * 1024, "one / two blocks per CU");
   static_assert(NT <= 64 * NW, "one table entry per thread");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[RING * BUF + RING * NT * 4];
@@ -112,9 +116,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_wino_f32(const W
     Cs = p.C2;
     cs = ci0 - p.C1;
   }
+  constexpr int CPK = PK / kWwPK;  // plan chunks per chunk
   const int total_chunks = (p.ntiles + PK - 1) / PK;
-  const int chunk0 = split * p.chunks_per_split;
-  int chunk1 = chunk0 + p.chunks_per_split;
+  const int chunk0 = split * (p.chunks_per_split / CPK);  // (the plan makes chunks_per_split a multiple of CPK)
+  int chunk1 = chunk0 + p.chunks_per_split / CPK;
   if (chunk1 > total_chunks) chunk1 = total_chunks;
   const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
   const int n_first = (int)rs_div((unsigned)(chunk0 * PK), p.div_tytx);
@@ -252,39 +257,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_wino_f32(const W
   };
 
   if (chunk0 < chunk1) {
-    // chunk c lives in stage / table (c - chunk0) % RING.  Iteration `it` runs chunk c's MFMAs with the pieces of chunk c + 2 issued
-    // between them (into the stage chunk c - 1 left at the last barrier), writes the table of chunk c + 3 (over chunk c's, read two
-    // barriers ago) and waits for chunk c + 1's pieces: all but this wave's NI youngest.
-    fill_table(chunk0, 0);
-    fill_table(chunk0 + 1, 1);
-    fill_table(chunk0 + 2, 2);
+    // chunk c lives in stage / table (c - chunk0) % RING.  Iteration c runs chunk c's MFMAs with the pieces of chunk c + RING - 1 issued
+    // between them (into the stage chunk c - 1 left at the last barrier), writes the table of chunk c + RING (over chunk c's, read
+    // RING - 1 barriers ago) and waits for chunk c + 1's pieces: all but this wave's (RING - 2) NI youngest.
+#pragma unroll
+    for (int r = 0; r < RING; ++r) fill_table(chunk0 + r, r);
     __syncthreads();
-    prepare_dma(0, 0);
 #pragma unroll
-    for (int q = 0; q < NI; ++q) issue_piece(q);
-    if (chunk0 + 1 < chunk1) {
-      prepare_dma(1, 1);
+    for (int r = 0; r < RING - 1; ++r) {
+      if (chunk0 + r < chunk1) {
+        prepare_dma(r, r);
 #pragma unroll
-      for (int q = 0; q < NI; ++q) issue_piece(q);
-      ww_dma_wait_but<NI>();
-    } else {
-      ww_dma_wait();
+        for (int q = 0; q < NI; ++q) issue_piece(q);
+      }
     }
+    ww_dma_wait();
     __syncthreads();
     int st = 0;  // (c - chunk0) % RING
     for (int c = chunk0; c < chunk1; ++c) {
-      const int st2 = st == 0 ? 2 : st - 1;  // (it + 2) % RING
-      const bool fetch = c + 2 < chunk1;      // (block-uniform)
-      if (fetch) prepare_dma(st2, st2);
+      const int stf = st == 0 ? RING - 1 : st - 1;  // stage / table of chunk c + RING - 1
+      const bool fetch = c + RING - 1 < chunk1;     // (block-uniform)
+      if (fetch) prepare_dma(stf, stf);
       chunk_mma(smem + st * BUF, fetch);
       if (fetch) {
-        fill_table(c + 3, st);
-        ww_dma_wait_but<NI>();
+        fill_table(c + RING, st);
+        ww_dma_wait_but<(RING - 2) * NI>();
       } else {
         ww_dma_wait();
       }
       __syncthreads();
-      st = st == 2 ? 0 : st + 1;
+      st = st == RING - 1 ? 0 : st + 1;
     }
   }
 
@@ -418,8 +420,8 @@ int rs_wgrad_f32_wino_launch(const rs_conv_desc* d, const float* dz, const float
   a.div_tytx = rs_make_fastdiv((unsigned)(pl.ty * pl.tx));
   a.div_tx = rs_make_fastdiv((unsigned)pl.tx);
   const int grid = 4 * pl.tiles_co * pl.tiles_ci * pl.splits;
-  if (pl.wgm == 2) conv_wgrad_wino_f32<2, 2><<<grid, 256, 0, s>>>(a);
-  else conv_wgrad_wino_f32<1, 2><<<grid, 128, 0, s>>>(a);
+  if (pl.wgm == 2) conv_wgrad_wino_f32<2, 2, kWwPK, 3><<<grid, 256, 0, s>>>(a);
+  else conv_wgrad_wino_f32<1, 2, kWwPK, 3><<<grid, 128, 0, s>>>(a);
   int rc = RS_LAUNCH_RESULT();
   if (rc) return rc;
   const long total = (long)d->Cout * (d->C1 + d->C2), n = 36 * total;

@@ -115,7 +115,8 @@ int rs_final_conv1x1(const float* x, const float* w, const float* bias, float* o
 long rs_conv2d_wgrad_workspace_bytes(const rs_conv_desc* d);
 /* Which form rs_conv2d_wgrad runs this fp32 launch in (a pure host decision on the geometry and the knobs): 0 the direct form,
  * 2 the phase form of DecoderBlock (unet.py:63-73; 4/9 of the multiply-adds), 3 the same in the Winograd domain of the forward's
- * F(2x2, 2x2) form (1/4; conv_wgrad_wino_f32.hip, round 6); RS_EINVAL for a descriptor rs_conv2d_wgrad refuses. */
+ * F(2x2, 2x2) form (1/4; conv_wgrad_wino_f32.hip, round 6), 4 a stride-1 3x3 / pad-1 convolution (torchvision Bottleneck.conv2) in the
+ * Winograd domain of F(2x2, 3x3) (16/36; conv_wgrad_wino33_f32.hip, round 6); RS_EINVAL for a descriptor rs_conv2d_wgrad refuses. */
 int rs_conv2d_wgrad_form(const rs_conv_desc* d);
 int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const float* src1, const float* src2, float* dw,
                     void* workspace, rs_stream_t stream);

@@ -202,6 +202,8 @@ struct RsKnobs {
   int wgrad_f32_blocks = 2048; // RS_WGRAD_F32_BLOCKS: block target of the fp32 weight-gradient launches
   int wgrad_f32_wino = 1;      // RS_WGRAD_F32_WINO: fp32 DecoderBlock weight gradient in the Winograd domain (conv_wgrad_wino_f32.hip); 0: phase form
   int wgrad_f32_wino_blocks = 1024;  // RS_WGRAD_F32_WINO_BLOCKS: block target of those launches
+  int wgrad_f32_wino33 = 1;    // RS_WGRAD_F32_WINO33: fp32 weight gradient of the stride-1 3x3 convolutions in the Winograd domain (conv_wgrad_wino33_f32.hip); 0: nine taps
+  int wgrad_f32_wino33_blocks = 256;  // RS_WGRAD_F32_WINO33_BLOCKS: block target of those launches (x 3 for the two-wave block)
   int wgrad_blocks = 96;       // RS_WGRAD_BLOCKS: block target of the tap-per-block bf16 weight-gradient launches (192 for two chunk buffers; 96 with the ring of three: profiles/r05/wgrad_ring.txt)
   int wgrad_blocks_phase = 1536;  // RS_WGRAD_BLOCKS_PHASE: ... of the phase-form launches
   int wgrad_phase4 = 1;        // RS_WGRAD_PHASE4: the phase form's 128 x 128 launches as one plane x four offsets per block (-0.2 ms on the bf16 step).  Round 5 withdrew it for a reproducibility failure whose cause round 6 found (a gather table published through a bare s_barrier: profiles/r06/dma_order.txt) and fixed

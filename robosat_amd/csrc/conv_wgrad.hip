@@ -385,13 +385,13 @@ extern "C" long rs_conv2d_wgrad_workspace_bytes(const rs_conv_desc* d) {
   const Plan pl = plan(d);
   const long n = (long)d->Cout * pl.K;
   const long floats = pl.splits * n + rs_reduce_scratch_floats(n, pl.splits) + (pl.phase ? n : 0);  // (+ G for the combine)
-  const long wino = pl.phase ? rs_wgrad_f32_wino_workspace_floats(d) : 0;  // (whichever form the knobs pick at launch time)
+  const long wino = pl.phase ? rs_wgrad_f32_wino_workspace_floats(d) : rs_wgrad_f32_wino33_workspace_floats(d);  // (whichever form the knobs pick at launch time)
   return (floats > wino ? floats : wino) * (long)sizeof(float);
 }
 
 extern "C" int rs_conv2d_wgrad_form(const rs_conv_desc* d) {
   if (!valid(d)) return RS_EINVAL;
-  if (!phase_ok(d)) return 0;
+  if (!phase_ok(d)) return (rs_knobs().wgrad_f32_dma != 0 && rs_wgrad_f32_wino33_ok(d)) ? 4 : 0;
   return (rs_knobs().wgrad_f32_dma != 0 && rs_wgrad_f32_wino_ok(d)) ? 3 : 2;
 }
 
@@ -402,6 +402,8 @@ extern "C" int rs_conv2d_wgrad(const rs_conv_desc* d, const float* dy, const flo
   const Plan pl = plan(d);
   if (pl.phase && rs_knobs().wgrad_f32_dma != 0 && rs_wgrad_f32_wino_ok(d))  // DecoderBlock in the Winograd domain (conv_wgrad_wino_f32.hip)
     return rs_wgrad_f32_wino_launch(d, dy, src1, src2, dw, reinterpret_cast<float*>(workspace), (hipStream_t)stream);
+  if (!pl.phase && rs_knobs().wgrad_f32_dma != 0 && rs_wgrad_f32_wino33_ok(d))  // stride-1 3x3 in the Winograd domain (conv_wgrad_wino33_f32.hip)
+    return rs_wgrad_f32_wino33_launch(d, dy, src1, dw, reinterpret_cast<float*>(workspace), (hipStream_t)stream);
   WgradArgs a;
   a.dy = dy;
   a.src1 = src1;

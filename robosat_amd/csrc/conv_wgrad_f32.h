@@ -26,3 +26,10 @@ __attribute__((visibility("hidden"))) bool rs_wgrad_f32_wino_ok(const rs_conv_de
 __attribute__((visibility("hidden"))) long rs_wgrad_f32_wino_workspace_floats(const rs_conv_desc* d);
 __attribute__((visibility("hidden"))) int rs_wgrad_f32_wino_launch(const rs_conv_desc* d, const float* dz, const float* src1, const float* src2,
                                                                    float* dw, float* workspace, hipStream_t s);
+
+// conv_wgrad_wino33_f32.hip (round 6): stride-1 3x3 / pad-1 convolutions in the Winograd domain of F(2x2, 3x3) (16/36 of the
+// multiply-adds); knob wgrad_f32_wino33.  Workspace: splits x 16 x Cout x Cin floats + the reduction's.
+__attribute__((visibility("hidden"))) bool rs_wgrad_f32_wino33_ok(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) long rs_wgrad_f32_wino33_workspace_floats(const rs_conv_desc* d);
+__attribute__((visibility("hidden"))) int rs_wgrad_f32_wino33_launch(const rs_conv_desc* d, const float* dy, const float* src, float* dw,
+                                                                     float* workspace, hipStream_t s);

@@ -42,6 +42,8 @@ const Entry kEntries[] = {
     {"wgrad_f32_blocks", "RS_WGRAD_F32_BLOCKS", &RsKnobs::wgrad_f32_blocks, 1, 1048576},
     {"wgrad_f32_wino", "RS_WGRAD_F32_WINO", &RsKnobs::wgrad_f32_wino, 0, 1},
     {"wgrad_f32_wino_blocks", "RS_WGRAD_F32_WINO_BLOCKS", &RsKnobs::wgrad_f32_wino_blocks, 1, 1048576},
+    {"wgrad_f32_wino33", "RS_WGRAD_F32_WINO33", &RsKnobs::wgrad_f32_wino33, 0, 1},
+    {"wgrad_f32_wino33_blocks", "RS_WGRAD_F32_WINO33_BLOCKS", &RsKnobs::wgrad_f32_wino33_blocks, 1, 1048576},
     {"wgrad_blocks", "RS_WGRAD_BLOCKS", &RsKnobs::wgrad_blocks, 1, 1048576},
     {"wgrad_blocks_phase", "RS_WGRAD_BLOCKS_PHASE", &RsKnobs::wgrad_blocks_phase, 1, 1048576},
     {"wgrad_phase4", "RS_WGRAD_PHASE4", &RsKnobs::wgrad_phase4, 0, 1},

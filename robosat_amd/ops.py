@@ -930,13 +930,15 @@ def conv2d_wgrad(dy, src1, kh, kw, src2=None, ups=0, stride=1, pad=0, stem=0, ou
         nbytes = es * (d.N * d.Ho * d.Wo * d.Cout + d.N * d.Hs * d.Ws * (4 if stem else d.C1 + d.C2)) + 4 * dw.numel()
         form = lib.rs_conv2d_wgrad_bf16_form(ctypes.byref(d)) if bf else 0
         if not bf and not stem:
-            # conv_wgrad.hip: 2 = the fp32 phase form of DecoderBlock (16 / 36 of the MACs), 3 = that in the Winograd domain (9 / 36)
+            # conv_wgrad.hip: 2 = the fp32 phase form of DecoderBlock (16 / 36 of the MACs), 3 = that in the Winograd domain (9 / 36),
+            # 4 = a stride-1 3x3 convolution in the Winograd domain of F(2x2, 3x3) (16 / 36)
             form = lib.rs_conv2d_wgrad_form(ctypes.byref(d))
         # fp32: the LDS-DMA kernel (conv_wgrad_f32_dma.hip) for everything but the packed stem, unless knob wgrad_f32_dma = 0
         name = wgrad_kernel_name(d, form) if bf else ("conv_wgrad_f32" if stem or get_knob("wgrad_f32_dma") == 0 else
-                                                      "conv_wgrad_wino_f32" if form == 3 else "conv_wgrad_f32_dma")
+                                                      "conv_wgrad_wino_f32" if form == 3 else "conv_wgrad_wino33_f32" if form == 4 else
+                                                      "conv_wgrad_f32_dma")
         _record(name, conv_flops(d), (d.C1 + d.C2, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1, nbytes,
-                conv_flops(d) * (0.25 if form == 3 else 4.0 / 9.0 if form == 2 else 1.0))
+                conv_flops(d) * (0.25 if form == 3 else 4.0 / 9.0 if form in (2, 4) else 1.0))
     return dw
 
 

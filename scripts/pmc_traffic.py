@@ -72,7 +72,7 @@ def bench_name(k):
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), \d+, \d+, 1>", k)
     if m:
         return "conv_igemm_f32<{}x{},stem>".format(m.group(1), m.group(2))
-    m = re.search(r"(conv_wgrad_wino_f32|conv_wgrad_f32_dma|conv_wgrad_f32)", k)
+    m = re.search(r"(conv_wgrad_wino33_f32|conv_wgrad_wino_f32|conv_wgrad_f32_dma|conv_wgrad_f32)", k)
     if m:
         return m.group(1)
     if "conv1x1_ew_f32_kernel" in k:

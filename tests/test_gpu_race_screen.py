@@ -328,6 +328,17 @@ def test_wino_domain_wgrad_fp32_beside_an_lds_user(control):
         assert not bad, (cout, bad)
 
 
+def test_wino_domain_3x3_wgrad_fp32_beside_an_lds_user(control):
+    """The stride-1 3x3 convolutions' fp32 weight gradient in the Winograd domain of F(2x2, 3x3): the same table / LDS-DMA pipeline."""
+    from robosat_amd import ops
+
+    g = _gen(52)
+    for n, hs, c in ((4, 64, 64), (2, 64, 32)):  # both block shapes
+        bad = _twice(lambda: (torch.randn(n, hs, hs, c, device=DEV, generator=g), torch.randn(n, hs, hs, c, device=DEV, generator=g)),
+                     lambda dy, x: ops.conv2d_wgrad(dy, x, 3, 3, pad=1), 40, k=control["k"])
+        assert not bad, (c, bad)
+
+
 def test_wino33_statistics_fp32_beside_an_lds_user(control):
     """The train forward's form: raw output + BatchNorm partial sums (a second cross-wave LDS exchange, read behind a barrier)."""
     from robosat_amd import ops

@@ -181,6 +181,41 @@ def test_decoder_wgrad_fp32_winograd_domain_vs_autograd_and_phase_form(n, c1, c2
     assert torch.equal(dw, ops.conv2d_wgrad(*args, **kw))  # deterministic: no atomics, splits summed in order
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 8, 8), (1, 32, 32, 9, 13), (3, 64, 128, 16, 12), (2, 128, 64, 7, 5), (1, 64, 96, 33, 20), (2, 64, 64, 34, 50)])
+def test_wgrad_fp32_3x3_winograd_domain_vs_autograd_and_nine_taps(n, cin, cout, h, w):
+    """The fp32 weight gradient of a stride-1 3x3 / pad-1 convolution (torchvision Bottleneck.conv2 under tools/train.py:186) in the
+    Winograd domain of F(2x2, 3x3) (conv_wgrad_wino33_f32.hip, round 6: dU = sum over tiles of (A dY A^T) (.) (B^T d B), dg = G^T dU G;
+    16/36 of the multiply-adds) against autograd and against the nine-tap kernel on the same launch: odd sizes (half tiles, rows that
+    end inside a chunk of eight tiles), more than one chunk per row, both block shapes, splits that straddle images."""
+    import ctypes
+
+    from robosat_amd import _lib, ops
+
+    a = rnd(n, cin, h, w, seed=61)
+    wt = (rnd(cout, cin, 3, 3, seed=63) * 0.05).requires_grad_(True)
+    y = F.conv2d(a, wt, padding=1)
+    gy = rnd(*y.shape, seed=64)
+    y.backward(gy)
+    args = (nhwc(gy), nhwc(a), 3, 3)
+    d = ops.ConvDesc(n, h, w, cin, 0, 0, 3, 3, 1, 1, h, w, cout, 0, 0)
+    assert ops.get_knob("wgrad_f32_wino33") == 1 and _lib.lib().rs_conv2d_wgrad_form(ctypes.byref(d)) == 4  # the shipped setting
+    ops.PROFILE = []
+    try:
+        dw = ops.conv2d_wgrad(*args, pad=1)
+        assert [r[0] for r in ops.PROFILE] == ["conv_wgrad_wino33_f32"], ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    close(dw.permute(0, 3, 1, 2).cpu(), wt.grad, what="Winograd-domain wgrad")
+    with ops.knob("wgrad_f32_wino33", 0):
+        assert _lib.lib().rs_conv2d_wgrad_form(ctypes.byref(d)) == 0
+        nine = ops.conv2d_wgrad(*args, pad=1)
+    assert float((dw - nine).abs().max()) <= 2e-5 * float(nine.abs().max())
+    with ops.knob("wgrad_f32_wino33_blocks", 16):  # another split of the chunk sequence: same sums up to fp32 order
+        few = ops.conv2d_wgrad(*args, pad=1)
+    assert float((dw - few).abs().max()) <= 2e-5 * float(nine.abs().max())
+    assert torch.equal(dw, ops.conv2d_wgrad(*args, pad=1))  # deterministic: no atomics, splits summed in order
+
+
 def test_stem_wgrad():
     from robosat_amd import ops
 

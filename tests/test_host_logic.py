@@ -208,7 +208,8 @@ def test_profiler_symbols_map_to_the_bench_names():
         "(anonymous namespace)::conv_wgrad_phase4_bf16((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<phase4,128x128>",
         "_ZN12_GLOBAL__N_122conv_wgrad_phase4_bf16ENS_10WgradArgsBE": "conv_wgrad_bf16<phase4,128x128>",
         ns + "conv_wgrad_f32_dma<128, 128, 2, 2, false, 32>(WgradArgs)": "conv_wgrad_f32_dma",
-        ns + "conv_wgrad_wino_f32<2, 2>((anonymous namespace)::WinoWgradArgs)": "conv_wgrad_wino_f32",
+        ns + "conv_wgrad_wino_f32<2, 2, 8, 3>((anonymous namespace)::WinoWgradArgs)": "conv_wgrad_wino_f32",
+        ns + "conv_wgrad_wino33_f32<2, 2>((anonymous namespace)::Wino33WgradArgs)": "conv_wgrad_wino33_f32",
         "_ZN12_GLOBAL__N_126bn_bwd_apply_stream_kernelIDF16bLb0ELb0EEEvPKT_S3_S3_PKfS5_PS1_S6_li": "bn_bwd_apply_stream_kernel",
         "(anonymous namespace)::reduce_lanes_kernel(float const*, float*, long, int, int)": "reduce_lanes_kernel",
     }

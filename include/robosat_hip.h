@@ -376,6 +376,16 @@ int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src, const flo
  * rows are.  `d` / `u` as for rs_conv2d_fwd_wino33 (rs_conv2d_wino33_ok decides; d->relu ignored). */
 long rs_conv2d_wino33_stats_rows(const rs_conv_desc* d);
 int rs_conv2d_fwd_wino33_stats(const rs_conv_desc* d, const float* src, const float* u, float* out, float* stats, rs_stream_t stream);
+/* The DATA gradient of such a layer in the same form (round 6): `d` describes the gradient's convolution (3x3 / stride 1 / pad 1 over
+ * dy; C1 = dy's channels, Cout = the gradient's, Cout % 32 == 0), `u` = rs_pack_wino33_weight of rs_pack_dgrad_weight's filters.  The
+ * gradient arrives at a ReLU output -- `mask` (the forward activation) or `mask_bits` (rs_bn_apply_bits_dt's; Cout % 8 == 0) or
+ * neither -- and, with `stats` [rs_conv2d_wino33_stats_rows(d)][2][Cout], at a BatchNorm output: the per-block partial sums
+ * (sum g, sum g * (bn_y - bn_mean) * bn_invstd) of the masked gradient g, rs_bn_bwd_from_partials_dt's input.  Replaces
+ * rs_conv2d_dgrad_bnstats[_bits]_dt / rs_conv2d_fwd(relu_mask) on these layers in fp32 (autograd of torchvision Bottleneck.conv2 and of
+ * ConvRelu, robosat/unet.py:28-41, under tools/train.py:186) at 4/9 of the multiply-adds. */
+int rs_conv2d_dgrad_wino33(const rs_conv_desc* d, const float* dy, const float* u, const float* mask, const uint8_t* mask_bits,
+                           const float* bn_y, const float* bn_mean, const float* bn_invstd, float* out, float* stats,
+                           rs_stream_t stream);
 
 /* ... and its data gradient: d loss / d (pre-upsample input) is ONE 4x4 / stride-2 / pad-1 convolution over dz with
  * pre-summed taps (rs_conv2d_fwd[_bf16] with kh = kw = 4 and these weights, [Cin][4][4][Cout]): the gradient lands at

@@ -117,6 +117,7 @@ SIGNATURES = {
     "rs_conv2d_fwd_wino33_head": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_int, c_int, P, c_int, P, P, P]),
     "rs_conv2d_wino33_stats_rows": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_fwd_wino33_stats": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    "rs_conv2d_dgrad_wino33": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P]),
     "rs_pack_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_combine_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_split_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, c_int, P]),

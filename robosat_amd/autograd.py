@@ -287,7 +287,10 @@ def _forward(net, x, tape, backward=False):
     dec2 = up(net.dec2, enc2, dec1)
     dec3 = up(net.dec3, enc1, dec2)
     dec4 = up(net.dec4, dec3)
-    dec5 = ops.conv2d(dec4, net.dec5.block.krsc(dt), pad=1, relu=True)
+    if dt == torch.float32 and ops.wino33_ok(dec4, net.dec5.block.cout) and os.environ.get("ROBOSAT_WINO33_BWD", "1") != "0":
+        dec5 = ops.conv2d_wino33(dec4, net.dec5.block.wino33(), relu=True)  # (as the eval forward runs it)
+    else:
+        dec5 = ops.conv2d(dec4, net.dec5.block.krsc(dt), pad=1, relu=True)
     t.update(enc=enc, pooled=pooled, amc=amc, center=center, dec0=dec0, dec1=dec1, dec2=dec2, dec3=dec3, dec4=dec4, dec5=dec5)
     wf = net.final.weight.detach().reshape(net.num_classes, -1)
     return ops.final_conv1x1(dec5, wf, net.final.bias.detach())
@@ -318,7 +321,10 @@ def _backward(net, tape, dlogits, arena):
     c5 = net.dec5.block
     w5 = arena.conv(c5)
     arena.wgrad(lambda: ops.conv2d_wgrad(d5, t["dec4"], 3, 3, pad=1, out=w5), d5, t["dec4"])
-    d4 = ops.conv2d(d5, c5.dgrad_weight(d5.dtype), pad=1, relu_mask=t["dec4"])
+    if d5.dtype == torch.float32 and ops.wino33_dgrad_ok(d5, c5.cin):  # fp32: the Winograd F(2x2, 3x3) form (4/9 of the multiply-adds)
+        d4, _ = ops.conv2d_wino33_dgrad(d5, c5.dgrad_wino33(), relu_mask=t["dec4"])
+    else:
+        d4 = ops.conv2d(d5, c5.dgrad_weight(d5.dtype), pad=1, relu_mask=t["dec4"])
     del d5
 
     def up_bwd(block, dz, skip, prev, mask_skip, mask_prev, skip_grad_out=None):
@@ -373,6 +379,11 @@ def _backward(net, tape, dlogits, arena):
         """Gradient at the OUTPUT of a BatchNorm+ReLU (z) from the convolution that consumed z, with the ReLU mask (z's sign:
         its bit form when the forward wrote one) and BatchNorm's two backward reductions done in the convolution's
         epilogue: returns (g, partial)."""
+        if (dy.dtype == torch.float32 and conv.k == 3 and conv.stride == 1 and conv.padding == 1 and residual is None
+                and ops.wino33_dgrad_ok(dy, conv.cin)):
+            # fp32 stride-1 3x3 (Bottleneck.conv2): the Winograd F(2x2, 3x3) form with the same epilogue (4/9 of the multiply-adds)
+            return ops.conv2d_wino33_dgrad(dy, conv.dgrad_wino33(), relu_mask=z if bits is None else None, relu_mask_bits=bits,
+                                           bn=(y, st[0], st[1]))
         wd = conv.dgrad_weight(dy.dtype)
         return ops.conv2d_dgrad_bnstats(dy, wd, out_hw, y, st[0], st[1], ups=2 if conv.stride == 2 else 0,
                                         pad=conv.k - 1 - conv.padding, residual=residual,

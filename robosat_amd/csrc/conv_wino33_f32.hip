@@ -48,6 +48,15 @@ struct Wino33Args {
   // STATS instantiations only -- the train-mode forward (torchvision BatchNorm2d under tools/train.py:169): `out` holds the RAW
   // convolution output and stats [m blocks][2][Cout] the per-block sum / sum of squares of it (rs_bn_finalize_stats's input)
   float* stats;
+  // BWD instantiations only (round 6) -- the DATA gradient of such a layer (the same convolution over dy with the flipped, transposed
+  // filters) arriving at a ReLU (+ BatchNorm) output: the ReLU mask as the forward activation (`mask`, sign) or one bit per element
+  // (`mask_bits`, rs_bn_apply_bits_dt's), and -- with `stats` -- the partial sums (sum g, sum g * xhat) of BatchNorm's backward
+  // against its input `bn_y` and statistics (what EPI_BWD of the generic kernel does: rs_conv2d_dgrad_bnstats_bits_dt)
+  const float* mask;
+  const unsigned char* mask_bits;
+  const float* bn_y;
+  const float* bn_mean;
+  const float* bn_invstd;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -71,14 +80,16 @@ __device__ __forceinline__ int w33_swz(int row) { return (row ^ (row >> 1)) & 3;
 // HEAD: 0 = the layer alone; 1 / 2 / 3 = + self.final and logits-or-softmax / quantised probabilities / argmax (one
 // instantiation per output kind: each carries only its own epilogue code -- the kernel's instructions are fetched cold on
 // every launch, which a single-tile `rs serve` request pays for in full)
-// MODE: 0 = the layer alone; 1 / 2 / 3 = + self.final (see above); 4 (round 6) = the layer alone + the partial sums of train-mode
+// MODE: 0 = the layer alone; 1 / 2 / 3 = + self.final (see above); 5 (round 6) = the layer's DATA gradient (BWD: see Wino33Args);
+// 4 (round 6) = the layer alone + the partial sums of train-mode
 // BatchNorm's statistics over the block's outputs (sum y, sum y^2 per cout and m block), summed in a fixed order: lane (its 2x2
 // pixels) -> the wave's 16 tiles (DPP row rotations: no LDS) -> the block's tile groups (through LDS, picked up behind the first
 // barrier of the block's next item like the head's exchange) -> one row of `stats` per m block.
 template <int TG, int CG, int MODE = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Args p) {
   constexpr int HEAD = (MODE >= 1 && MODE <= 3) ? MODE : 0;
-  constexpr bool STATS = MODE == 4;
+  constexpr bool BWD = MODE == 5;
+  constexpr bool STATS = MODE == 4 || BWD;  // (BWD: only when p.stats is given -- block-uniform)
   constexpr int NW = TG * CG;
   static_assert(NW == 8, "8 waves");
   static_assert(!HEAD || (TG == 4 && CG == 2), "the fused head: one 8x8 patch of tiles x all 32 couts per block");
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
   int st_buf = 0, st_row = 0, st_col = 0;
   auto finish_stats = [&]() __attribute__((always_inline)) {
     if constexpr (STATS) {
-      if (threadIdx.x < 2 * BN) {
+      if ((!BWD || p.stats) && threadIdx.x < 2 * BN) {
         const int which = threadIdx.x / BN, c = threadIdx.x - which * BN;
         const float* x = xst + st_buf * XST + which * TG * BN + c;
         float a = 0.f;
@@ -356,34 +367,84 @@ __global__ __launch_bounds__(512, 1) void conv_wino33_f32_kernel(const Wino33Arg
     if constexpr (!HEAD) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       if (live) {
+        if constexpr (BWD) {
+          // all of the item's mask / BatchNorm-input pieces are requested first (one HBM round trip, not four), then combined and stored
+          long o[4];
+          bool ok[4];
+          f32x4 zm[4], yv[4];
+          unsigned int bits[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+          for (int q = 0; q < 4; ++q) {
+            const int a = a0 + (q >> 1), b = b0 + (q & 1);
+            ok[q] = a < p.H && b < p.W;
+            o[q] = ok[q] ? ((long)(n * p.H + a) * p.W + b) * p.Cout + co : (long)co;
+          }
+          if (p.mask) {
 #pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const int a = a0 + u, b = b0 + v;
-            if (a >= p.H || b >= p.W) continue;
-            *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = Y[u][v];
-            if constexpr (STATS) {
-              s0 += Y[u][v];
-              s1 += Y[u][v] * Y[u][v];
+            for (int q = 0; q < 4; ++q) zm[q] = *reinterpret_cast<const f32x4*>(p.mask + o[q]);
+          }
+          if (p.mask_bits) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bits[q] = p.mask_bits[o[q] >> 3];
+          }
+          f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu;
+          if (p.stats) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) yv[q] = *reinterpret_cast<const f32x4*>(p.bn_y + o[q]);
+            mu = *reinterpret_cast<const f32x4*>(p.bn_mean + co);
+            is = *reinterpret_cast<const f32x4*>(p.bn_invstd + co);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 y = Y[q >> 1][q & 1];
+            if (p.mask) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = zm[q][e] > 0.f ? y[e] : 0.f;
+            }
+            if (p.mask_bits) {
+              const unsigned int nib = bits[q] >> (o[q] & 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = ((nib >> e) & 1u) ? y[e] : 0.f;
+            }
+            if (!ok[q]) continue;
+            *reinterpret_cast<f32x4*>(p.out + o[q]) = y;
+            if (p.stats) {
+              s0 += y;
+              s1 += y * ((yv[q] - mu) * is);
             }
           }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+              const int a = a0 + u, b = b0 + v;
+              if (a >= p.H || b >= p.W) continue;
+              *reinterpret_cast<f32x4*>(p.out + ((long)(n * p.H + a) * p.W + b) * p.Cout + co) = Y[u][v];
+              if constexpr (STATS) {
+                s0 += Y[u][v];
+                s1 += Y[u][v] * Y[u][v];
+              }
+            }
+        }
       }
       if constexpr (STATS) {
-        // over the wave's 16 tiles (lanes l15 of each 16-lane row): four DPP row rotations, every lane of the row ends with the row's sum
+        if (!BWD || p.stats) {
+          // over the wave's 16 tiles (lanes l15 of each 16-lane row): four DPP row rotations, every lane of the row ends with the row's sum
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0[e] = rs_row16_sum(s0[e]);
-          s1[e] = rs_row16_sum(s1[e]);
-        }
-        st_buf = seq & 1;
-        st_row = mblk;
-        st_col = nblk * BN;
-        if (l15 == 0) {
-          float* x = xst + st_buf * XST + tg * BN + 16 * cg + 4 * pc;
-          *reinterpret_cast<f32x4*>(x) = s0;
-          *reinterpret_cast<f32x4*>(x + TG * BN) = s1;
-          rs_lds_writes_done();  // (read behind the next barrier, which hipcc emits bare: common.h)
+          for (int e = 0; e < 4; ++e) {
+            s0[e] = rs_row16_sum(s0[e]);
+            s1[e] = rs_row16_sum(s1[e]);
+          }
+          st_buf = seq & 1;
+          st_row = mblk;
+          st_col = nblk * BN;
+          if (l15 == 0) {
+            float* x = xst + st_buf * XST + tg * BN + 16 * cg + 4 * pc;
+            *reinterpret_cast<f32x4*>(x) = s0;
+            *reinterpret_cast<f32x4*>(x + TG * BN) = s1;
+            rs_lds_writes_done();  // (read behind the next barrier, which hipcc emits bare: common.h)
+          }
         }
       }
     } else {
@@ -550,6 +611,8 @@ extern "C" int rs_conv2d_fwd_wino33(const rs_conv_desc* d, const float* src, con
   a.hq = nullptr;
   a.hC = a.hmode = a.hov = 0;
   a.stats = nullptr;
+  a.mask = a.bn_y = a.bn_mean = a.bn_invstd = nullptr;
+  a.mask_bits = nullptr;
   const int sb = 16 * (8 / cgn) / (kPB * kPB);
   const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
   if (items >= (1L << 31)) return RS_EINVAL;
@@ -596,6 +659,8 @@ extern "C" int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src
   a.hmode = mode;
   a.hov = overlap;
   a.stats = nullptr;
+  a.mask = a.bn_y = a.bn_mean = a.bn_invstd = nullptr;
+  a.mask_bits = nullptr;
   const long items = a.nsub;
   if (items >= (1L << 31)) return RS_EINVAL;
   const int grid = (int)(items < w33_cus() ? items : w33_cus());
@@ -640,6 +705,8 @@ extern "C" int rs_conv2d_fwd_wino33_stats(const rs_conv_desc* d, const float* sr
   a.hq = nullptr;
   a.hC = a.hmode = a.hov = 0;
   a.stats = stats;
+  a.mask = a.bn_y = a.bn_mean = a.bn_invstd = nullptr;
+  a.mask_bits = nullptr;
   const int sb = 16 * (8 / cgn) / (kPB * kPB);
   const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
   if (items >= (1L << 31)) return RS_EINVAL;
@@ -647,5 +714,55 @@ extern "C" int rs_conv2d_fwd_wino33_stats(const rs_conv_desc* d, const float* sr
   hipStream_t s = (hipStream_t)stream;
   if (cgn == 2) conv_wino33_f32_kernel<4, 2, 4><<<grid, 512, 0, s>>>(a);
   else conv_wino33_f32_kernel<8, 1, 4><<<grid, 512, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}
+
+// The data gradient of such a layer (round 6): rs_conv2d_fwd_wino33 over dy with u = rs_pack_wino33_weight of the data-gradient filters
+// (rs_pack_dgrad_weight: flipped taps, [Cin][3][3][Cout]); `d` describes THAT convolution (C1 = dy's channels, Cout = the gradient's).
+// The gradient arrives at a ReLU output: `mask` (the forward activation, its sign decides) or `mask_bits` (rs_bn_apply_bits_dt's, one
+// bit per element; Cout % 8 == 0) or neither; with `stats` [rs_conv2d_wino33_stats_rows(d)][2][Cout] also at a BatchNorm output --
+// the per-block partial sums (sum g, sum g * (bn_y - bn_mean) * bn_invstd) of the masked gradient, rs_bn_bwd_from_partials_dt's input
+// (what rs_conv2d_dgrad_bnstats[_bits]_dt computes with nine taps: autograd of torchvision Bottleneck.conv2 / ConvRelu under
+// tools/train.py:186).
+extern "C" int rs_conv2d_dgrad_wino33(const rs_conv_desc* d, const float* dy, const float* u, const float* mask, const uint8_t* mask_bits,
+                                      const float* bn_y, const float* bn_mean, const float* bn_invstd, float* out, float* stats,
+                                      rs_stream_t stream) {
+  int cgn;
+  if (!w33_plan(d, &cgn) || cgn != 2 || !dy || !u || !out) return RS_EINVAL;  // (Cout % 32 == 0: every layer this is for)
+  if (mask && mask_bits) return RS_EINVAL;
+  if (mask_bits && (d->Cout % 8) != 0) return RS_EINVAL;
+  if (stats ? (!bn_y || !bn_mean || !bn_invstd) : (bn_y || bn_mean || bn_invstd)) return RS_EINVAL;
+  Wino33Args a;
+  a.src = dy;
+  a.u = u;
+  a.scale = a.shift = nullptr;
+  a.out = out;
+  a.N = d->N;
+  a.H = d->Hs;
+  a.W = d->Ws;
+  a.Cin = d->C1;
+  a.Cout = d->Cout;
+  a.BBY = rs_cdiv((d->Hs + 1) / 2, kPB);
+  a.BBX = rs_cdiv((d->Ws + 1) / 2, kPB);
+  a.nsub = d->N * a.BBY * a.BBX;
+  a.ncb = d->Cout / (16 * cgn);
+  a.relu = 0;
+  a.hw = a.hb = nullptr;
+  a.hanchors = nullptr;
+  a.hout = nullptr;
+  a.hq = nullptr;
+  a.hC = a.hmode = a.hov = 0;
+  a.stats = stats;
+  a.mask = mask;
+  a.mask_bits = mask_bits;
+  a.bn_y = bn_y;
+  a.bn_mean = bn_mean;
+  a.bn_invstd = bn_invstd;
+  const int sb = 16 * (8 / cgn) / (kPB * kPB);
+  const long items = (long)rs_cdiv(a.nsub, sb) * a.ncb;
+  if (items >= (1L << 31)) return RS_EINVAL;
+  const int grid = (int)(items < w33_cus() ? items : w33_cus());
+  hipStream_t s = (hipStream_t)stream;
+  conv_wino33_f32_kernel<4, 2, 5><<<grid, 512, 0, s>>>(a);
   return RS_LAUNCH_RESULT();
 }

@@ -519,6 +519,59 @@ def conv2d_wino33_bnstats(src, u):
     return out, partial
 
 
+def wino33_dgrad_ok(dy, cout):
+    """Whether the fp32 data gradient of a stride-1 3x3 / pad-1 convolution (dy [n,h,w,c] -> [n,h,w,cout]) takes the Winograd form
+    (``rs_conv2d_dgrad_wino33``: ``wino33_ok`` on the gradient's convolution, cout % 32 == 0); ROBOSAT_WINO33_BWD=0 keeps the generic
+    kernel (A/B runs)."""
+
+    import os
+
+    if os.environ.get("ROBOSAT_WINO33_BWD", "1") == "0" or cout % 32:
+        return False
+    return wino33_ok(dy, cout)
+
+
+def conv2d_wino33_dgrad(dy, u, relu_mask=None, relu_mask_bits=None, bn=None):
+    """``rs_conv2d_dgrad_wino33``: the data gradient of a stride-1 3x3 convolution in the fp32 Winograd form -- ``u`` =
+    ``pack_wino33_weight(pack_dgrad_weight(w))`` -- masked by the ReLU it arrives at (``relu_mask``: the forward activation;
+    ``relu_mask_bits``: its bit form) and, with ``bn`` = (y, mean, invstd), with the partial sums of BatchNorm's two backward reductions,
+    as ``conv2d_dgrad_bnstats`` returns them.  Returns (g, partial or None)."""
+
+    n, h, w, c = dy.shape
+    cout = u.shape[1]
+    assert tuple(u.shape) == (16, cout, c) and dy.dtype == torch.float32
+    d = _conv33_desc(dy, cout, False)
+    lib = _lib.lib()
+    out = torch.empty((n, h, w, cout), device=dy.device, dtype=torch.float32)
+    partial = None
+    y = mean = invstd = None
+    if bn is not None:
+        y, mean, invstd = bn
+        assert y.shape == out.shape
+        rows = lib.rs_conv2d_wino33_stats_rows(ctypes.byref(d))
+        if rows <= 0:
+            raise ValueError("rs_conv2d_wino33_stats_rows: invalid arguments")
+        partial = torch.empty((rows, 2, cout), device=dy.device, dtype=torch.float32)
+    if relu_mask is not None:
+        assert relu_mask.shape == out.shape
+    if relu_mask_bits is not None:
+        assert relu_mask_bits.numel() * 8 == out.numel(), "one mask bit per output element"
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.rs_conv2d_dgrad_wino33(ctypes.byref(d), _dev(dy, "dy"), _dev(u, "u"), _dev(relu_mask, "relu_mask"),
+                                     _dev(relu_mask_bits, "relu_mask_bits", torch.uint8), _dev(y, "bn_y"), _dev(mean, "bn_mean"),
+                                     _dev(invstd, "bn_invstd"), _dev(out, "out"), _dev(partial, "partial"), _stream()),
+          "rs_conv2d_dgrad_wino33")
+    if PROFILE is not None:
+        ev1.record()
+        _record(lib.rs_conv2d_wino33_name(ctypes.byref(d)).decode().replace("<3x3,", "<3x3+bwd,"), conv_flops(d),
+                (d.C1, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
+                conv_bytes(d, 4, 1 + (relu_mask is not None) + (bn is not None)) + (out.numel() // 8 if relu_mask_bits is not None else 0),
+                conv_flops(d) * 4.0 / 9.0)
+    return out, partial
+
+
 def wino33_head_ok(src, cout, classes):
     """Whether dec5 + ``self.final`` run as one launch (``rs_conv2d_wino33_head_ok``: the Winograd 3x3 form on a 32-cout
     layer, <= 8 classes); ROBOSAT_FUSED_HEAD=0 keeps the two launches (A/B runs)."""

@@ -103,6 +103,17 @@ class _Conv(nn.Module):
             self._wino33 = c
         return c[1]
 
+    def dgrad_wino33(self):
+        """The transformed filters of the fp32 Winograd F(2x2, 3x3) form of this layer's DATA gradient (``rs_pack_wino33_weight`` on
+        ``dgrad_weight``), cached like ``phase``."""
+
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0])
+        c = getattr(self, "_dgrad_wino33", None)
+        if c is None or c[0] != key:
+            c = (key, ops.pack_wino33_weight(self.dgrad_weight(torch.float32)))
+            self._dgrad_wino33 = c
+        return c[1]
+
     def dgrad_phase(self, dtype=torch.float32):
         """Weights of the phase form's data gradient (one 4x4 / stride-2 convolution over dz, ``rs_pack_dgrad_phase_weight_dt``),
         cached like ``phase``."""

@@ -48,8 +48,8 @@ def bench_name(k):
         return "conv_wino_f32<{},p{},{}x{}>".format("dgrad4x4" if m.group(5) == "1" else "phase", m.group(1), 16 * int(m.group(2)),
                                                     16 * int(m.group(4)) * int(m.group(3)))
     m = re.search(r"conv_wino33_f32_kernel<(\d+), (\d+)(?:, (true|false|\d+))?>", k)
-    if m:  # (third parameter: 0 / absent = the layer alone, 1..3 = + self.final with one of its three output kinds, 4 = + BatchNorm partial sums)
-        kind = "+stats" if m.group(3) == "4" else "" if m.group(3) in (None, "false", "0") else "+final"
+    if m:  # (third parameter: 0 / absent = the layer alone, 1..3 = + self.final with one of its three output kinds, 4 = + BatchNorm partial sums, 5 = the data gradient)
+        kind = "+stats" if m.group(3) == "4" else "+bwd" if m.group(3) == "5" else "" if m.group(3) in (None, "false", "0") else "+final"
         return "conv_wino_f32<3x3{},p8,{}x{}>".format(kind, 16 * int(m.group(1)), 16 * int(m.group(2)))
     m = re.search(r"conv_thin_bf16<(\d)>", k)
     if m:

@@ -339,6 +339,24 @@ def test_wino_domain_3x3_wgrad_fp32_beside_an_lds_user(control):
         assert not bad, (c, bad)
 
 
+def test_wino33_data_gradient_fp32_beside_an_lds_user(control):
+    """The Winograd 3x3 kernel's data-gradient form: mask bits, BatchNorm backward partial sums through the LDS exchange."""
+    from robosat_amd import ops
+
+    g = _gen(53)
+    n, s, c = 4, 64, 128
+    u = ops.pack_wino33_weight(torch.randn(c, 3, 3, c, device=DEV, generator=g) * 0.05)
+    mean, invstd = torch.randn(c, device=DEV, generator=g) * 0.1, torch.rand(c, device=DEV, generator=g) + 0.5
+
+    def make():
+        y = torch.randn(n, s, s, c, device=DEV, generator=g)
+        _, bits = ops.bn_apply(y, invstd, -mean * invstd, relu=True, want_bits=True)
+        return torch.randn(n, s, s, c, device=DEV, generator=g), y, bits
+
+    bad = _twice(make, lambda dy, y, bits: ops.conv2d_wino33_dgrad(dy, u, relu_mask_bits=bits, bn=(y, mean, invstd)), 40, k=control["k"])
+    assert not bad, bad
+
+
 def test_wino33_statistics_fp32_beside_an_lds_user(control):
     """The train forward's form: raw output + BatchNorm partial sums (a second cross-wave LDS exchange, read behind a barrier)."""
     from robosat_amd import ops

@@ -44,6 +44,8 @@ COVERED |= {"conv_wino_f32<dgrad4x4,p8,128x64>", "conv_wino_f32<dgrad4x4,p8,64x6
 # the fp32 train forward's stride-1 3x3 convolutions in the Winograd form with BatchNorm's partial sums (round 6):
 # tests/test_gpu_train_ops.py::test_wino33_train_forward_with_statistics_*
 COVERED |= {"conv_wino_f32<3x3+stats,p8,64x32>", "conv_wino_f32<3x3+stats,p8,128x16>"}
+# ... and their data gradients in the same form (ReLU mask + BatchNorm backward partial sums): test_wino33_data_gradient_*
+COVERED |= {"conv_wino_f32<3x3+bwd,p8,64x32>"}
 # all-taps weight gradient: per input-channel slab, with / without the fused upsample (test_wgrad_bf16 "thin_*" cases assert the
 # names; test_wgrad_bf16_thin_upsample runs the ",ups" forms)
 COVERED |= {"conv_wgrad_thin_bf16<{}>".format(t) for t in ("32", "64", "128", "32,ups", "64,ups", "128,ups")}

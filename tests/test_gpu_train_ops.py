@@ -216,6 +216,48 @@ def test_wgrad_fp32_3x3_winograd_domain_vs_autograd_and_nine_taps(n, cin, cout, 
     assert torch.equal(dw, ops.conv2d_wgrad(*args, pad=1))  # deterministic: no atomics, splits summed in order
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,mask", [(2, 64, 64, 32, 32, "bits"), (1, 128, 128, 17, 15, "z"), (3, 256, 256, 16, 16, "bits"), (2, 32, 32, 24, 40, "z"),
+                                                   (2, 64, 128, 16, 24, "none")])
+def test_wino33_data_gradient_with_relu_mask_and_bn_partials_vs_the_generic_kernel_and_autograd(n, cin, cout, h, w, mask):
+    """The fp32 data gradient of a stride-1 3x3 convolution in the Winograd F(2x2, 3x3) form (rs_conv2d_dgrad_wino33, round 6) with the
+    epilogue of the generic kernel's EPI_BWD: ReLU mask (tensor or bits) and BatchNorm's two backward partial sums -- against
+    rs_conv2d_dgrad_bnstats[_bits]_dt on the same inputs (masked gradient; column sums of the partial rows) and against autograd of
+    relu(bn(y)) -> conv3x3 (torchvision Bottleneck.conv2 behind bn1 + ReLU, tools/train.py:186).  `cin` = the forward layer's input
+    channels = the gradient's output channels."""
+    from robosat_amd import ops
+
+    # forward: y1 [n,cin,h,w] -> bn (batch statistics) -> relu -> z1 -> conv3x3 (cin -> cout) -> y2 ; gradient gy2 given
+    y1 = rnd(n, cin, h, w, seed=71)
+    wt = rnd(cout, cin, 3, 3, seed=72) * (2.0 / (cin * 9)) ** 0.5
+    gy2 = rnd(n, cout, h, w, seed=73)
+    mean = y1.mean((0, 2, 3))
+    invstd = 1 / torch.sqrt(y1.var((0, 2, 3), unbiased=False) + 1e-5)
+    z1 = torch.relu((y1 - mean[None, :, None, None]) * invstd[None, :, None, None]).requires_grad_(True)
+    F.conv2d(z1, wt, padding=1).backward(gy2)
+    g_ref = z1.grad * (z1.detach() > 0) if mask != "none" else z1.grad  # the masked gradient at the BatchNorm+ReLU output
+    xhat = (y1 - mean[None, :, None, None]) * invstd[None, :, None, None]
+    dy, yd, zd = nhwc(gy2), nhwc(y1), nhwc(z1.detach())
+    md, isd = mean.to(DEV), invstd.to(DEV)
+    wd = ops.pack_dgrad_weight(krsc(wt))
+    u = ops.pack_wino33_weight(wd)
+    assert ops.wino33_dgrad_ok(dy, cin)
+    bits = None
+    if mask == "bits":
+        _, bits = ops.bn_apply(yd, isd, -md * isd, relu=True, want_bits=True)
+    kw = dict(relu_mask=zd if mask == "z" else None, relu_mask_bits=bits)
+    g, part = ops.conv2d_wino33_dgrad(dy, u, bn=(yd, md, isd), **kw)
+    gg, partg = ops.conv2d_dgrad_bnstats(dy, wd, (h, w), yd, md, isd, pad=1, **kw)
+    close(nchw(g), g_ref, 2e-5, "masked gradient")
+    assert float((g - gg).abs().max()) <= 2e-5 * float(gg.abs().max())
+    assert torch.equal(g == 0, gg == 0) or mask == "none"  # the same elements masked
+    s, sg = part.double().sum(0).cpu(), partg.double().sum(0).cpu()
+    close(s[0], g_ref.double().sum((0, 2, 3)), 1e-4, "sum g")
+    close(s[1], (g_ref.double() * xhat.double()).sum((0, 2, 3)), 1e-4, "sum g * xhat")
+    assert float((s - sg).abs().max()) <= 1e-5 * float(sg.abs().max())
+    g2, none = ops.conv2d_wino33_dgrad(dy, u, **kw)  # without the BatchNorm half (ConvRelu: dec5's gradient)
+    assert none is None and torch.equal(g2, g)
+
+
 def test_stem_wgrad():
     from robosat_amd import ops
 

@@ -180,6 +180,7 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_wino33_f32_kernel<4, 2, 1>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
         ns + "conv_wino33_f32_kernel<4, 2, 3>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+final,p8,64x32>",
         ns + "conv_wino33_f32_kernel<8, 1, 4>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+stats,p8,128x16>",
+        ns + "conv_wino33_f32_kernel<4, 2, 5>((anonymous namespace)::Wino33Args)": "conv_wino_f32<3x3+bwd,p8,64x32>",
         ns + "conv_wino_f32_kernel<8, 8, 1, 4, false>((anonymous namespace)::WinoArgs)": "conv_wino_f32<phase,p8,128x64>",
         ns + "conv_wino_f32_kernel<8, 4, 2, 2, true>((anonymous namespace)::WinoArgs)": "conv_wino_f32<dgrad4x4,p8,64x64>",
         "_ZN12_GLOBAL__N_120conv_wino_f32_kernelILi8ELi8ELi1ELi4ELb1EEEvNS_8WinoArgsE": "conv_wino_f32<dgrad4x4,p8,128x64>",

@@ -420,6 +420,11 @@ int rs_conv2d_fwd_split_dt(const rs_conv_desc* d, int dtype, const void* src1, c
                            void* out2, const void* mask2, int csplit, rs_stream_t stream);
 int rs_cat_split_bwd_dt(const void* dcat, void* d1, void* d2, const void* mask1, const void* mask2, int dtype, int N, int H,
                         int W, int C1, int C2, int accumulate1, rs_stream_t stream);
+/* out[n][2a][2b][:] += t[n][a][b][:] (t [N][Hs][Ws][C], out [N][Ho][Wo][C], Ho >= 2 Hs - 1; fp32: C % 4 == 0, bf16: C % 8 == 0): the
+ * data gradient of a 1x1 / stride-2 convolution -- torchvision Bottleneck.downsample[0] of layer2..layer4 under loss.backward(),
+ * tools/train.py:186 -- is rs_conv2d_fwd of its transposed filters on the low-resolution grid, added here onto the even positions
+ * of the gradient the tensor already has (round 6; replaces the zero-insertion form, ups = 2, of that launch). */
+int rs_scatter_add_stride2_dt(const void* t, void* out, int dtype, int N, int Hs, int Ws, int Ho, int Wo, int C, rs_stream_t stream);
 
 /* The same fusion for BatchNorm's BACKWARD (conv -> bn -> relu read right to left): the data-gradient convolution that
  * produces g = d loss / d z (rs_conv2d_fwd semantics on `dy` with rs_pack_dgrad_weight weights, optional residual,

@@ -122,6 +122,7 @@ SIGNATURES = {
     "rs_combine_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_split_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, c_int, P]),
     "rs_cat_split_bwd_dt": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rs_scatter_add_stride2_dt": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rs_conv2d_dgrad_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P, P]),
     "rs_bn_bwd_from_partials_dt": (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, c_long, c_int, P, P]),
     "rs_bn_apply_bits_dt": (c_int, [P, P, P, P, P, P, c_int, c_long, c_int, c_int, P]),

@@ -425,7 +425,13 @@ def _backward(net, tape, dlogits, arena):
             dyd, _, _ = ops.bn_bwd(gm, None, rec["yd"], rec["std"][0], rec["std"][1], dbn.weight.detach(), **bn_grads(dbn))
             wdn = arena.conv(dconv)
             arena.wgrad(lambda: ops.conv2d_wgrad(dyd, h, 1, 1, stride=blk.stride, out=wdn), dyd, h)
-            res = _dgrad(dyd, dconv, hw_in, residual=extra)
+            if (extra is not None and dconv.k == 1 and dconv.stride == 2 and dconv.padding == 0 and hw_in[0] % 2 == 0 and hw_in[1] % 2 == 0
+                    and os.environ.get("ROBOSAT_S2_DGRAD", "1") != "0"):
+                # 1x1 / stride 2: the transposed product on the low-resolution grid, added onto the even positions of the skip
+                # branch's gradient in place (as a zero-insertion convolution three of four GEMM rows are zeros)
+                res = ops.scatter_add_stride2(ops.conv2d(dyd, dconv.dgrad_weight(dyd.dtype)), extra)
+            else:
+                res = _dgrad(dyd, dconv, hw_in, residual=extra)
             del dyd
         else:
             assert extra is None

@@ -1053,6 +1053,17 @@ def bn_bwd(dz, zmask, y, mean, invstd, gamma, want_masked=False, dgamma=None, db
     return (dy, dgamma, dbeta, dmasked) if want_masked else (dy, dgamma, dbeta)
 
 
+def scatter_add_stride2(t, out):
+    """``out[:, ::2, ::2, :] += t`` in place (``rs_scatter_add_stride2_dt``): the data gradient of a 1x1 / stride-2 convolution is its
+    transposed product on the low-resolution grid (``t``), landing on the even positions of the input grid."""
+
+    n, hs, ws, c = t.shape
+    assert out.shape[0] == n and out.shape[3] == c and out.dtype == t.dtype and out.is_contiguous()
+    check(_lib.lib().rs_scatter_add_stride2_dt(_dev(t, "t", t.dtype), _dev(out, "out", t.dtype), _dt(t), n, hs, ws, out.shape[1], out.shape[2], c,
+                                               _stream()), "rs_scatter_add_stride2_dt")
+    return out
+
+
 def maxpool2d_bwd(dy, argmax, in_shape, k, stride, pad, out=None, out_dtype=None):
     """Gradient wrt the pooling input [N,H,W,C]; ``out`` given => accumulate into it.  ``out_dtype`` fp32 on a bf16 dy
     is the precision boundary of the bf16 path (stem pool)."""

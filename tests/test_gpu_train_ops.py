@@ -258,6 +258,39 @@ def test_wino33_data_gradient_with_relu_mask_and_bn_partials_vs_the_generic_kern
     assert none is None and torch.equal(g2, g)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_stride2_1x1_data_gradient_as_a_low_resolution_product_plus_scatter_vs_the_zero_insertion_form_and_autograd(dtype):
+    """Bottleneck.downsample[0] (1x1 / stride 2) under loss.backward(): its data gradient as rs_conv2d_fwd of the transposed filters on
+    the low-resolution grid + rs_scatter_add_stride2_dt onto the gradient the tensor already has (round 6) -- against the zero-insertion
+    launch (ups = 2, residual) it replaces (fp32: bit for bit) and against autograd."""
+    from robosat_amd import ops
+
+    act = torch.bfloat16 if dtype == "bf16" else torch.float32
+    n, cin, cout, h, w = 2, 64, 128, 16, 24
+    x = rnd(n, cin, h, w, seed=81).requires_grad_(True)
+    wt = rnd(cout, cin, 1, 1, seed=82) * 0.1
+    if dtype == "bf16":
+        wt = wt.to(act).float()
+    gy = rnd(n, cout, h // 2, w // 2, seed=83)
+    if dtype == "bf16":
+        gy = gy.to(act).float()
+    extra = rnd(n, cin, h, w, seed=84)
+    if dtype == "bf16":
+        extra = extra.to(act).float()
+    F.conv2d(x, wt, stride=2).backward(gy)
+    want = x.grad + extra
+    wd = ops.pack_dgrad_weight(krsc(wt), act)
+    dyd, ex = nhwc(gy).to(act), nhwc(extra).to(act)
+    old = ops.conv2d(dyd, wd, ups=2, pad=0, out_hw=(h, w), residual=ex)
+    new = ops.scatter_add_stride2(ops.conv2d(dyd, wd), ex.clone())
+    tol = 2e-2 if dtype == "bf16" else 2e-5
+    close(nchw(new.float()), want, tol, "scatter form vs autograd")
+    if dtype == "fp32":
+        assert torch.equal(new, old)
+    else:
+        assert float((new.float() - old.float()).abs().max()) <= 2e-2 * float(old.float().abs().max())
+
+
 def test_stem_wgrad():
     from robosat_amd import ops
 

@@ -310,6 +310,12 @@ int rs_bn_finalize_stats(const float* partial, long rows, long M, int C, float e
  * summation order.  `d` describes the original layer (ups = 1, 3x3, stride 1, pad 1, Ho = 2*Hs); `weight_phase` is
  * [4][Cout][2][2][C1+C2] from rs_pack_phase_weight_dt (fp32 KRSC master in, `dtype` out).  Epilogue as rs_conv2d_fwd. */
 int rs_pack_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
+/* The DATA gradient of a 3x3 / stride-2 / pad-1 convolution (torchvision Bottleneck.conv2 of layer2..layer4's first block, under
+ * loss.backward(), tools/train.py:186) in the same form (round 6): rs_conv2d_fwd_phase_dt over dy [N][Hs][Ws][Cout] with this pack
+ * [4][Cin][2][2][Cout] (fp32 KRSC master [Cout][3][3][Cin] in) gives d input [N][2 Hs][2 Ws][Cin] -- on each input parity the gradient
+ * is a 2x2 convolution over dy with at most four of the nine taps (zeros elsewhere): 16 multiply-adds per four pixels (9 in the
+ * Winograd form of rs_conv2d_fwd_phase_wino) instead of the 36 of the zero-insertion launch (ups = 2) it replaces. */
+int rs_pack_s2_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream);
 int rs_conv2d_fwd_phase_dt(const rs_conv_desc* d, int dtype, const void* src1, const void* src2, const void* weight_phase,
                            const float* scale, const float* shift, const void* residual, const void* relu_mask, void* out,
                            rs_stream_t stream);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "rs_conv2d_fwd_bnstats_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P]),
     "rs_bn_finalize_stats": (c_int, [P, c_long, c_long, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rs_pack_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "rs_pack_s2_dgrad_phase_weight_dt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "rs_conv2d_fwd_phase_dt": (c_int, [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P, P, P]),
     "rs_conv2d_phase_wino_ok": (c_int, [POINTER(ConvDesc)]),
     "rs_conv2d_phase_wino_name": (c_char_p, [POINTER(ConvDesc)]),

@@ -412,10 +412,25 @@ def _backward(net, tape, dlogits, arena):
         del g2
         w2 = arena.conv(blk.conv2)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy2, rec["z1"], 3, 3, stride=blk.stride, pad=1, out=w2), dy2, rec["z1"])
-        g1, p1 = dgrad_into_bn(dy2, blk.conv2, (rec["z1"].shape[1], rec["z1"].shape[2]), rec["y1"], rec["st1"], rec["z1"], rec["b1"])
-        del dy2
-        dy1, _, _ = ops.bn_bwd_from_partials(g1, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), p1,
-                                             **bn_grads(blk.bn1))
+        h1, w1_ = rec["z1"].shape[1], rec["z1"].shape[2]
+        if (blk.conv2.stride == 2 and blk.conv2.k == 3 and blk.conv2.padding == 1 and h1 == 2 * dy2.shape[1] and w1_ == 2 * dy2.shape[2]
+                and os.environ.get("ROBOSAT_S2_DGRAD", "1") != "0" and os.environ.get("ROBOSAT_S2_DGRAD_3X3", "1") != "0"):
+            # 3x3 / stride 2: on each input parity the gradient is a 2x2 convolution over dy -- the phase form's geometry (16, in the
+            # fp32 Winograd form 9, multiply-adds per four pixels against the zero-insertion launch's 36); BatchNorm's reductions
+            # then take their own pass (bn_bwd) instead of riding in that launch's epilogue
+            if dy2.dtype == torch.float32 and ops.wino_ok(dy2, None, blk.conv2.cin):
+                g1 = ops.conv2d_phase_wino(dy2, blk.conv2.dgrad_s2_phase(torch.float32, wino=True))
+                zm = rec["z1"]
+            else:
+                g1 = ops.conv2d_phase(dy2, blk.conv2.dgrad_s2_phase(dy2.dtype), relu_mask=rec["z1"])
+                zm = None
+            del dy2
+            dy1, _, _ = ops.bn_bwd(g1, zm, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), **bn_grads(blk.bn1))
+        else:
+            g1, p1 = dgrad_into_bn(dy2, blk.conv2, (h1, w1_), rec["y1"], rec["st1"], rec["z1"], rec["b1"])
+            del dy2
+            dy1, _, _ = ops.bn_bwd_from_partials(g1, rec["y1"], rec["st1"][0], rec["st1"][1], blk.bn1.weight.detach(), p1,
+                                                 **bn_grads(blk.bn1))
         del g1
         w1 = arena.conv(blk.conv1)
         arena.wgrad(lambda: ops.conv2d_wgrad(dy1, h, 1, 1, out=w1), dy1, h)

@@ -511,6 +511,26 @@ __global__ void pack_phase_weight_kernel(const float* __restrict__ w, T* __restr
   out[i] = (T)acc;
 }
 
+// fp32 KRSC [Cout][3][3][Cin] of a 3x3 / STRIDE-2 / pad-1 convolution -> the phase pack [4][Cin][2][2][Cout] in T of its DATA gradient
+// (round 6).  d in(y, x) = sum over the taps with (y + 1 - ky) even of w[.][ky][kx][.] dy((y + 1 - ky) / 2, (x + 1 - kx) / 2): on the
+// input's parity (py, px) that is a 2x2 convolution over dy in exactly the phase form's geometry (source row a - (1 - py) + r), with
+// taps ky(py, r) = none, 1 (py = 0) / 2, 0 (py = 1) -- nine taps per four pixels, zeros in the pack where a parity has no tap.  As a
+// zero-insertion convolution (ups = 2) the same gradient runs all nine taps on every pixel: 36 per four.
+template <typename T>
+__global__ void pack_s2_dgrad_phase_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [4][Cin][2][2][Cout]
+  if (i >= total) return;
+  const int cd = (int)(i % Cout);
+  long t = i / Cout;
+  const int s = (int)(t & 1), r = (int)((t >> 1) & 1);
+  t >>= 2;
+  const int cg = (int)(t % Cin);
+  const int ph = (int)(t / Cin), py = ph >> 1, px = ph & 1;
+  const int ky = py == 0 ? (r == 1 ? 1 : -1) : (r == 0 ? 2 : 0);
+  const int kx = px == 0 ? (s == 1 ? 1 : -1) : (s == 0 ? 2 : 0);
+  out[i] = (T)((ky < 0 || kx < 0) ? 0.f : w[(((long)cd * 3 + ky) * 3 + kx) * Cin + cg]);
+}
+
 // fp32 KRSC [Cout][3][3][Cin] -> data-gradient weights of the phase form, [Cin][4][4][Cout] in T: the gradient of
 // DecoderBlock wrt its (pre-upsample) input is a 4x4 / stride-2 / pad-1 convolution over dz,
 //   d_src[u][v][ci] = sum_{ty,tx,co} dz[2u - 1 + ty][2v - 1 + tx][co] * Wd[ci][ty][tx][co],
@@ -571,6 +591,19 @@ extern "C" int rs_pack_dgrad_phase_weight_dt(const float* w_krsc, void* out, int
     pack_dgrad_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin, total);
   else if (dtype == RS_BF16)
     pack_dgrad_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin, total);
+  else
+    return RS_EINVAL;
+  return RS_LAUNCH_RESULT();
+}
+
+extern "C" int rs_pack_s2_dgrad_phase_weight_dt(const float* w_krsc, void* out, int dtype, int Cout, int Cin, rs_stream_t stream) {
+  if (!w_krsc || !out || Cout <= 0 || Cin <= 0) return RS_EINVAL;
+  const long total = 16L * Cout * Cin;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RS_F32)
+    pack_s2_dgrad_phase_weight_kernel<float><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<float*>(out), Cout, Cin, total);
+  else if (dtype == RS_BF16)
+    pack_s2_dgrad_phase_weight_kernel<bf16_t><<<rs_cdiv(total, 256), 256, 0, s>>>(w_krsc, reinterpret_cast<bf16_t*>(out), Cout, Cin, total);
   else
     return RS_EINVAL;
   return RS_LAUNCH_RESULT();

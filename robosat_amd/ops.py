@@ -237,6 +237,18 @@ def pack_phase_weight(w_krsc, dtype=torch.float32):
     return out
 
 
+def pack_s2_dgrad_phase_weight(w_krsc, dtype=torch.float32):
+    """fp32 KRSC [Cout,3,3,Cin] of a 3x3 / stride-2 / pad-1 convolution -> [4,Cin,2,2,Cout] in ``dtype``: the phase pack of its DATA
+    gradient (``rs_pack_s2_dgrad_phase_weight_dt``) -- ``conv2d_phase(dy, pack)`` is the gradient wrt the input (even sizes)."""
+
+    cout, kh, kw, cin = w_krsc.shape
+    assert kh == 3 and kw == 3
+    out = torch.empty((4, cin, 2, 2, cout), device=w_krsc.device, dtype=dtype)
+    check(_lib.lib().rs_pack_s2_dgrad_phase_weight_dt(_dev(w_krsc, "w"), _dev(out, "out", dtype), RS_BF16 if dtype == BF16 else RS_F32,
+                                                      cout, cin, _stream()), "rs_pack_s2_dgrad_phase_weight_dt")
+    return out
+
+
 def pack_dgrad_phase_weight(w_krsc, dtype=torch.float32):
     """fp32 KRSC [Cout,3,3,Cin] -> [Cin,4,4,Cout] in ``dtype``: weights of the 4x4 / stride-2 convolution over dz that is
     the data gradient of DecoderBlock wrt its pre-upsample input (``rs_pack_dgrad_phase_weight_dt``)."""

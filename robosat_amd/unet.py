@@ -114,6 +114,18 @@ class _Conv(nn.Module):
             self._dgrad_wino33 = c
         return c[1]
 
+    def dgrad_s2_phase(self, dtype=torch.float32, wino=False):
+        """The phase pack of this 3x3 / stride-2 convolution's DATA gradient (``rs_pack_s2_dgrad_phase_weight_dt``; ``wino``: its fp32
+        Winograd transform, ``rs_pack_wino_phase_weight``), cached like ``phase``."""
+
+        key = (self.weight.data_ptr(), self.weight._version, _GENERATION[0], dtype, wino)
+        c = getattr(self, "_dgrad_s2_phase", None)
+        if c is None or c[0] != key:
+            pack = ops.pack_s2_dgrad_phase_weight(self.krsc(), dtype)
+            c = (key, ops.pack_wino_phase_weight(pack) if wino else pack)
+            self._dgrad_s2_phase = c
+        return c[1]
+
     def dgrad_phase(self, dtype=torch.float32):
         """Weights of the phase form's data gradient (one 4x4 / stride-2 convolution over dz, ``rs_pack_dgrad_phase_weight_dt``),
         cached like ``phase``."""

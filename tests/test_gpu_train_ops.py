@@ -291,6 +291,36 @@ def test_stride2_1x1_data_gradient_as_a_low_resolution_product_plus_scatter_vs_t
         assert float((new.float() - old.float()).abs().max()) <= 2e-2 * float(old.float().abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 32), (1, 128, 128, 16, 24), (3, 64, 32, 8, 12)])
+def test_stride2_3x3_data_gradient_in_phase_form_vs_the_zero_insertion_form_and_autograd(dtype, n, cin, cout, h, w):
+    """Bottleneck.conv2 of layer2..layer4's first block (3x3 / stride 2 / pad 1) under loss.backward(): its data gradient as a phase-form
+    convolution over dy with rs_pack_s2_dgrad_phase_weight_dt's pack (round 6), in fp32 also in that form's Winograd kernel where the
+    layer qualifies -- against the zero-insertion launch (ups = 2) it replaces and against autograd; with the ReLU mask in the
+    epilogue as the bf16 step uses it."""
+    from robosat_amd import ops
+
+    act = torch.bfloat16 if dtype == "bf16" else torch.float32
+    q = (lambda t: t.to(act).float()) if dtype == "bf16" else (lambda t: t)
+    x = rnd(n, cin, h, w, seed=91).requires_grad_(True)
+    wt = q(rnd(cout, cin, 3, 3, seed=92) * (2.0 / (cin * 9)) ** 0.5)
+    gy = q(rnd(n, cout, h // 2, w // 2, seed=93))
+    z = q(rnd(n, cin, h, w, seed=94))
+    F.conv2d(x, wt, stride=2, padding=1).backward(gy)
+    dyd, zd = nhwc(gy).to(act), nhwc(z).to(act)
+    pack = ops.pack_s2_dgrad_phase_weight(krsc(wt), act)
+    got = ops.conv2d_phase(dyd, pack)
+    old = ops.conv2d(dyd, ops.pack_dgrad_weight(krsc(wt), act), ups=2, pad=1, out_hw=(h, w))
+    tol = 2e-2 if dtype == "bf16" else 2e-5
+    close(nchw(got.float()), x.grad, tol, "phase form vs autograd")
+    assert float((got.float() - old.float()).abs().max()) <= tol * float(old.float().abs().max())
+    masked = ops.conv2d_phase(dyd, pack, relu_mask=zd)
+    assert torch.equal(masked, torch.where(zd > 0, got, torch.zeros_like(got)))
+    if dtype == "fp32" and ops.wino_ok(dyd, None, cin, force=True):
+        wino = ops.conv2d_phase_wino(dyd, ops.pack_wino_phase_weight(pack))
+        close(nchw(wino), x.grad, 2e-5, "Winograd phase form vs autograd")
+
+
 def test_stem_wgrad():
     from robosat_amd import ops
 

@@ -149,7 +149,7 @@ def roofline(step):
         k[3] += nbytes
         k[4] += executed
         layers.append({"kernel": name, "cin_cout_k_stride_ups_ho_wo": list(shape), "gflop": flops / 1e9, "ms": ms,
-                       "tflops": flops / ms / 1e9 if ms > 0 else 0.0})
+                       "tflops": flops / ms / 1e9 if ms > 0 else 0.0, "executed_gflop": executed / 1e9, "mb": nbytes / 1e6})
     dom = max(per_kernel, key=lambda n: per_kernel[n][1])
     flops, ms, launches, alg_bytes, exe_flops = per_kernel[dom]
     total_ms = sum(v[1] for v in per_kernel.values())

@@ -249,7 +249,7 @@ def _forward(net, x, tape, backward=False):
     if dt == torch.bfloat16:
         y0 = ops.stem_conv_bf16(x4, ops.pack_stem_weight(r.conv1.krsc(), dt))
     else:
-        y0 = ops.conv2d(x4, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, stem=7)
+        y0 = ops.conv2d(x4, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, stem=7, bands=net.in_channels)
     z0, st0 = _bn_train(r.bn1, y0)
     p0, am0 = ops.maxpool2d(z0, 3, 2, 1, want_argmax=True)
     t.update(y0=y0, st0=st0, z0=z0, am0=am0)

@@ -69,7 +69,7 @@ def conv_bytes(d, esize, epilogue_tensors=0):
     return esize * (d.N * d.Hs * d.Ws * cin + d.Cout * d.kh * d.kw * cin + (1 + epilogue_tensors) * d.N * d.Ho * d.Wo * d.Cout)
 
 
-def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=0, out_hw=None):
+def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=0, out_hw=None, bands=4):
     n, hs, ws, c1 = src1.shape
     cout, kh, kw_, _ = weight.shape
     c2 = 0 if src2 is None else src2.shape[3]
@@ -78,17 +78,21 @@ def conv_desc(src1, weight, src2=None, ups=0, stride=1, pad=0, relu=False, stem=
         assert ups in (0, 1)
         hv, wv = (hs * 2, ws * 2) if ups == 1 else (hs, ws)
         out_hw = ((hv + 2 * pad - kh) // stride + 1, (wv + 2 * pad - kw) // stride + 1)
-    return ConvDesc(n, hs, ws, c1, c2, ups, kh, kw, stride, pad, out_hw[0], out_hw[1], cout, int(relu), int(bool(stem)))
+    # rs_conv_desc.stem: 1 = the packed stem layout; 3 = ... and the caller vouches that the 4th band of the input and the
+    # filter's c = 3 entries are zeros (an RGB image through nchw_to_nhwc4 / pack_stem_weight): the kernel skips them
+    return ConvDesc(n, hs, ws, c1, c2, ups, kh, kw, stride, pad, out_hw[0], out_hw[1], cout, int(relu),
+                    (3 if bands <= 3 else 1) if stem else 0)
 
 
 def conv2d(src1, weight, src2=None, ups=0, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False,
-           stem=0, out_hw=None, out=None, relu_mask=None, alg_scale=1.0):
+           stem=0, out_hw=None, out=None, relu_mask=None, alg_scale=1.0, bands=4):
     """``rs_conv2d_fwd``: out = relu?(conv(gather(src1|src2)) * scale + shift + residual).
 
-    ``stem``: 0, or the true filter width (7) when ``weight`` is the packed ``[Cout,kh,8,4]`` stem filter.
+    ``stem``: 0, or the true filter width (7) when ``weight`` is the packed ``[Cout,kh,8,4]`` stem filter; ``bands``: 3 when
+    the image had three bands (its 4th NHWC4 channel and the packed filter's 4th entries are zeros and are skipped).
     ``relu_mask``: tensor shaped like ``out``; the result is zeroed where it is <= 0 (fused ReLU backward)."""
 
-    d = conv_desc(src1, weight, src2, ups, stride, pad, relu, stem, out_hw)
+    d = conv_desc(src1, weight, src2, ups, stride, pad, relu, stem, out_hw, bands)
     act = src1.dtype  # fp32: exact-fp32 MFMA kernels; bf16: bf16 operands, fp32 accumulation
     bf = act == BF16
     if bf and stem:

@@ -567,7 +567,8 @@ class UNet(nn.Module):
         if dt == torch.bfloat16:
             h = ops.stem_conv_bf16(h, ops.pack_stem_weight(r.conv1.krsc(), dt), scale=sc, shift=sh, relu=True)
         else:
-            h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7)
+            h = ops.conv2d(h, ops.pack_stem_weight(r.conv1.krsc()), stride=2, pad=3, scale=sc, shift=sh, relu=True, stem=7,
+                           bands=self.in_channels)
         h = ops.maxpool2d(h, 3, 2, 1)
 
         enc = []

@@ -66,11 +66,13 @@ def bench_name(k):
             return "conv_wgrad_bf16<{}{}x{}>".format("phase," if mm.group(3) == "1" else "", mm.group(1), mm.group(2))
     if m:  # (a two-launch layer -- "128x128+128x64" in the bench's name -- is looked up by its first tile)
         return "conv_wgrad_bf16<{}{}x{}>".format("phase," if m.group(3) == "true" else "", m.group(1), m.group(2))
+    if "stem_conv_f32" in k:  # (stem_f32.hip, round 6; <3> = RGB, <4> = four live bands: one report name)
+        return "stem_conv_f32<128x64>"
     m = re.search(r"_ZN\d+_GLOBAL__N_1\d+([a-z_0-9]+?)I", k)
     if m:
         return m.group(1)
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), \d+, \d+, 1>", k)
-    if m:
+    if m:  # (rounds 1-5: the stem as an instantiation of the register-staged implicit-GEMM kernel)
         return "conv_igemm_f32<{}x{},stem>".format(m.group(1), m.group(2))
     m = re.search(r"(conv_wgrad_wino33_f32|conv_wgrad_wino_f32|conv_wgrad_f32_dma|conv_wgrad_f32)", k)
     if m:
@@ -114,7 +116,7 @@ if __name__ == "__main__":
                 result[k] = round(rd + wr)
             tot_bytes += (rd + wr) * n
             tot_launches += n
-            if k in ("conv_igemm_f32<128x64,stem>", "stem_fwd_bf16_kernel", "stem_conv_bf16"):
+            if k in ("stem_conv_f32<128x64>", "conv_igemm_f32<128x64,stem>", "stem_fwd_bf16_kernel", "stem_conv_bf16"):
                 steps = n
         if steps:  # (the run's untimed steps are steps like the timed one: per-step figures = totals / launches of the stem kernel)
             lines.append("   => {} steps in the run: {:.1f} launches and {:.2f} GB of HBM traffic per step".format(steps, tot_launches / steps, tot_bytes / steps / 1e9))

@@ -146,6 +146,52 @@ def test_stem():
         close(got, want)
 
 
+STEM_CASES = [
+    # name,         N, bands, H,   W,   what it covers (stem_f32.hip: 128-pixel tiles of one output row, persistent blocks)
+    ("rgb_2tiles", 2, 3, 64, 512),     # Wo = 256: two full tiles per row, RGB form (the zero band skipped)
+    ("rgb_ragged", 1, 3, 96, 336),     # Wo = 168: a 128-pixel and a 40-pixel tile per row
+    ("rgb_narrow", 3, 3, 32, 32),      # Wo = 16: one ragged tile per row, images of 16 rows
+    ("rgb_many", 5, 3, 256, 512),      # 1 280 tiles on <= 512 persistent blocks: several tiles per block, runs crossing images
+    ("four_bands", 2, 4, 64, 352),     # four live bands (pixel stride 5), Wo = 176
+    ("two_bands", 1, 2, 64, 256),      # fewer than three bands ride the RGB form (their missing bands are zeros)
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES, ids=[c[0] for c in STEM_CASES])
+def test_stem_forms(case):
+    """resnet.conv1 on the stem kernel against F.conv2d: raw (the train forward) and with the folded-BatchNorm + ReLU epilogue
+    (predict); the RGB form must not read the 4th band -- it is filled with garbage here."""
+    from robosat_amd import ops
+
+    _, n, bands, h, w = case
+    x, wt = rnd(n, bands, h, w, seed=21), rnd(64, bands, 7, 7, seed=22) * 0.1
+    want = F.conv2d(x, wt, stride=2, padding=3)
+    x4 = ops.nchw_to_nhwc4(x.to(_dev()))
+    packed = ops.pack_stem_weight(krsc(wt))
+    if bands <= 3:
+        x4[..., 3] = 1e30  # (times the packed filter's zeros this would still be finite: the form is told to skip it, and must)
+    got = nchw(ops.conv2d(x4, packed, stride=2, pad=3, stem=7, bands=bands))
+    close(got, want)
+    sc, sh = rnd(64, seed=23), rnd(64, seed=24)
+    got = nchw(ops.conv2d(x4, packed, stride=2, pad=3, stem=7, bands=bands, scale=sc.to(_dev()), shift=sh.to(_dev()), relu=True))
+    close(got, torch.relu(want * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+
+
+def test_stem_is_batch_independent_and_deterministic():
+    """A tile's stem output must not depend on its batch neighbours or on which persistent block computed it (bit for bit)."""
+    from robosat_amd import ops
+
+    x, wt = rnd(6, 3, 128, 256, seed=25), rnd(64, 3, 7, 7, seed=26) * 0.1
+    packed = ops.pack_stem_weight(krsc(wt))
+    x4 = ops.nchw_to_nhwc4(x.to(_dev()))
+    full = ops.conv2d(x4, packed, stride=2, pad=3, stem=7, bands=3)
+    assert torch.equal(full, ops.conv2d(x4, packed, stride=2, pad=3, stem=7, bands=3))
+    for i in (0, 3, 5):
+        assert torch.equal(full[i:i + 1], ops.conv2d(x4[i:i + 1].contiguous(), packed, stride=2, pad=3, stem=7, bands=3))
+    # ... and the generic form (four live bands, the 4th all zeros) computes the same sums in another order
+    close(nchw(ops.conv2d(x4, packed, stride=2, pad=3, stem=7, bands=4)), nchw(full), 1e-5)
+
+
 @pytest.mark.parametrize("k,s,p", [(3, 2, 1), (2, 2, 0)])
 def test_maxpool(k, s, p):
     from robosat_amd import ops

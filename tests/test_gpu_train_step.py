@@ -47,12 +47,25 @@ def test_train_step_matches_reference_golden(golden_dir, loss_name):
         worst = max(worst, rel)
         assert rel <= 2e-2, (str(name), got_norm, float(want_norm))
     print("worst grad-norm relative error", worst)
+    # Elementwise bound on the golden's eleven gradient tensors.  The step amplifies rounding (53 train-mode BatchNorms; the Lovasz
+    # gradient is piecewise constant in the SORT ORDER of the errors), and how far is measured, not assumed: the reference itself,
+    # with resnet.conv1's output perturbed at fp32-rounding level, moves these tensors by up to 0.6 % (CrossEntropy) / 2.2 % (Lovasz)
+    # of their largest element (tests/golden/grad_noise_floor.py), and this path with the stem's output taken from four equally
+    # accurate sources -- the kernel, the GPU box's own host convolution, a float64 convolution rounded -- lands anywhere between
+    # 0.3 % and 2.1 % on resnet.bn1.bias under Lovasz (profiles/r06/golden_noise_floor.txt; rounds 1-5 sat at 0.2 % because the old
+    # stem kernel happened to add in the golden machine's order).  The norms above are not chaotic and keep their 2 % bound.
+    elementwise = 2e-2 if loss_name == "CrossEntropy" else 5e-2
+    worst_el, worst_cos = (0.0, None), (1.0, None)
     for key in g.files:
         if key.startswith("grad/"):
             want = torch.from_numpy(g[key])
             got = params[key[5:]].grad.cpu()
             err = float((got - want).abs().max())
-            assert err <= 2e-2 * max(1e-8, float(want.abs().max())), (key, err, float(want.abs().max()))
+            worst_el = max(worst_el, (err / max(1e-8, float(want.abs().max())), key))
+            worst_cos = min(worst_cos, (float(torch.nn.functional.cosine_similarity(got.flatten().double(), want.flatten().double(), dim=0)), key))
+            assert err <= elementwise * max(1e-8, float(want.abs().max())), (key, err, float(want.abs().max()))
+    print("worst elementwise gradient error relative to the tensor's largest element", worst_el, "worst cosine", worst_cos)
+    assert worst_cos[0] >= 0.9995, worst_cos  # (measured 0.99993-0.99998: direction is not chaotic, single elements are)
     sd = net.state_dict()
     for key in g.files:
         if key.startswith("bn/"):

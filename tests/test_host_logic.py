@@ -197,6 +197,8 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_igemm_dma<__bf16, 256, 128, 4, 2, 128, false, 0, 3, 0>(ConvArgsT<__bf16>)": "conv_halo_bf16<dgrad4x4,256x128>",
         ns + "conv_igemm_dma<float, 128, 128, 2, 2, 64, false, 0, 0, 0>(ConvArgsT<float>)": "conv_igemm_f32<128x128,r64>",
         ns + "conv_igemm_f32<128, 64, 2, 2, 1>((anonymous namespace)::ConvArgs)": "conv_igemm_f32<128x64,stem>",
+        ns + "stem_conv_f32<3>((anonymous namespace)::StemArgs)": "stem_conv_f32<128x64>",
+        "_ZN12_GLOBAL__N_113stem_conv_f32ILi4EEEvNS_8StemArgsE": "stem_conv_f32<128x64>",
         ns + "conv_thin_bf16<1>((anonymous namespace)::ThinConvArgs)": "conv_thin_bf16<phase>",
         ns + "conv_wgrad_thin_bf16<4, 1>((anonymous namespace)::ThinArgs)": "conv_wgrad_thin_bf16<128,ups>",
         ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",

@@ -64,7 +64,9 @@ typedef struct rs_conv_desc {
   int32_t Ho, Wo;     /* output spatial size */
   int32_t Cout;       /* multiple of 32 */
   int32_t relu;       /* 1: ReLU in the epilogue */
-  int32_t stem;       /* 1: src1 is NHWC with 4 channels, weights packed [Cout][kh][8][4] (see rs_pack_stem_weight) */
+  int32_t stem;       /* 1: src1 is NHWC with 4 channels, weights packed [Cout][kh][8][4] (see rs_pack_stem_weight): resnet.conv1,
+                         7x7 / stride 2 / pad 3 -> 64 (stem_f32.hip); 3: ... and the 4th channel of src1 and the filter's c = 3
+                         entries are zeros (an RGB image through rs_nchw_to_nhwc4): they are skipped, not multiplied */
 } rs_conv_desc;
 
 int rs_conv2d_fwd(const rs_conv_desc* d, const float* src1, const float* src2, const float* weight,

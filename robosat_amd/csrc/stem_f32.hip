@@ -20,8 +20,14 @@
 //            (0,1) (2,3) (4,5) pair up (offset = one strip row), row 6 pairs its even taps with the odd ones (offset = the
 //            parity plane), its last tap with a zero line.  150 real + 3 padding k against 224.
 //   filter = [k-step][half][cout] in LDS (38 KB), re-ordered from the packed [64][7][8][4] layout once per block.
-//   store  = as every convolution here: accumulators through LDS as [pixel][cout], 16-byte row-wise stores with the folded
+//   store  = as every convolution here: accumulators through LDS as [pixel][cout] (the staging tile aliases the strip), read back
+//            row-wise into registers; then the NEXT strip is written and only after that the 16-byte stores go out, with the folded
 //            BatchNorm scale / shift + ReLU (predict) or raw (train: bn_train_stats reads it).
+//
+// Measured (profiles/r06/stem_f32.txt; bs 16, 512^2): 319 -> 187-195 us, 68 % MFMA busy.  In-kernel stamps (-DRS_STEM_TRACE,
+// scripts/debug/stem_trace.py): a tile is 9 700 cycles of MFMAs + 2 200 of everything else, and the CU's two blocks ALTERNATE rather than
+// overlap -- a block's VALU work (epilogue arithmetic, fetch addresses) crawls while the other block's waves stream MFMAs on the same
+// SIMDs (its LDS traffic and barriers do not); s_setprio, s_sleep between MFMA pairs and a staggered start changed nothing.
 #include "common.h"
 
 namespace {
@@ -35,6 +41,9 @@ struct StemArgs {
   int N, H, W, Ho, Wo, relu;
   int tpr;    // tiles per output row
   int ntile;  // N * Ho * tpr
+#ifdef RS_STEM_TRACE
+  long long* trace;  // [block][tile of the block][8] shader-clock stamps of wave 0 (measurement build: scripts/debug/stem_trace.py)
+#endif
 };
 
 constexpr int SBM = 128, SBN = 64;  // tile: pixels x couts
@@ -103,44 +112,75 @@ __global__ __launch_bounds__(256, CIN == 3 ? 2 : 1) void stem_conv_f32(const Ste
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
+#ifdef RS_STEM_TRACE
+  if (tid == 0) p.trace[((long)blockIdx.x * 64 + 63) * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
   // this block's run of tiles
   const int t0 = (int)((long)blockIdx.x * p.ntile / gridDim.x);
   const int t1 = (int)((long)(blockIdx.x + 1) * p.ntile / gridDim.x);
   if (t0 >= t1) return;
 
-  // ---- filter: packed [64][7][8][4] -> [k-step][half][cout]; the zero line ------------------------------------------------
-  for (int e = tid; e < G::WF; e += 256) {
-    const int co = e & 63, th = e >> 6;
-    const Tap k = stem_tap<CIN>(th >> 1, th & 1);
-    wl[e] = p.w[((co * 7 + k.r) * 8 + k.s) * 4 + k.c];
+  // ---- filter: packed [64][7][8][4] -> [k-step][half][cout]; the zero line.  Fourteen coalesced 16-byte loads per thread, all in
+  //      flight together, each scattered to its k-step (the first version walked the LDS layout and gathered 4 bytes at a time: 38
+  //      dependent L2 round trips per thread in front of the block's first tile)
+  {
+    constexpr int NW4 = SBN * 7 * 8 / 256;  // float4 per thread
+    f32x4 wv[NW4];
+#pragma unroll
+    for (int k = 0; k < NW4; ++k) wv[k] = *reinterpret_cast<const f32x4*>(p.w + (tid + 256 * k) * 4);
+#pragma unroll
+    for (int k = 0; k < NW4; ++k) {
+      const int e = tid + 256 * k;  // (co, r, s)
+      const int s_ = e & 7, r = (e >> 3) % 7, co = e / 56;
+      int t, h;
+      if (r < 6) {
+        t = (r >> 1) * G::PAIR + s_ * CIN, h = r & 1;
+        if (s_ == 7) continue;  // (rows 0..5 have no k-step for the zero tap)
+      } else if (s_ < 6) {
+        t = G::NPAIR + (s_ >> 1) * CIN, h = s_ & 1;
+      } else {
+        t = G::NPAIR + G::NEO, h = s_ & 1;  // tap 6 | the zero tap (its packed entries are zeros)
+      }
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) wl[((t + c) * 2 + h) * SBN + co] = wv[k][c];
+    }
   }
   for (int e = tid; e < G::ZEROF; e += 256) zline[e] = 0.f;
 
   // ---- strip fetch: pixel e = tid + 256 q of the 7 x SCOLS field -> registers; written to LDS one tile later -----------------
   f32x4 pf[NPF];
   int pdst[NPF];  // LDS offset (floats) of strip pixel e, or -1 past the field
+  int prow[NPF], pcol[NPF], prel[NPF];  // its (row, column) in the field and byte offset relative to the field's first pixel
 #pragma unroll
   for (int q = 0; q < NPF; ++q) {
     const int e = tid + 256 * q;
     const int r = e / SCOLS, j = e - r * SCOLS;
-    pdst[q] = e < 7 * SCOLS ? ((r * 2 + (j & 1)) * XI + (j >> 1)) * PS : -1;
+    const bool in = e < 7 * SCOLS;
+    pdst[q] = in ? ((r * 2 + (j & 1)) * XI + (j >> 1)) * PS : -1;
+    prow[q] = in ? r : -(1 << 24);  // (past the field: never inside the image)
+    pcol[q] = j;
+    prel[q] = (r * p.W + j) * 16;
   }
   const long img = (long)p.H * p.W * 4;
+  // tile -> (image, output row, tile within the row), advanced tile by tile (no division in the loop)
+  int cn, coy, ctx;
+  {
+    const int rowt = t0 / p.tpr;
+    ctx = t0 - rowt * p.tpr;
+    cn = rowt / p.Ho;
+    coy = rowt - cn * p.Ho;
+  }
   // (`live` = false: the same eight loads, all out of range -- the prefetch behind the block's last tile.  Unconditional on purpose: a
   // fetch under `if (tile + 1 < t1)` makes pf a merge of old and new values, hipcc then loads into temporaries and copies, and the copies
   // wait for the loads right where they were issued: the strip's round trip ended up in front of every tile's MFMAs.)
-  auto fetch = [&](int tile, bool live) __attribute__((always_inline)) {
-    const int rowt = tile / p.tpr, tx = tile - rowt * p.tpr;  // (n * Ho + oy), tile within the row
-    const int n = rowt / p.Ho, oy = rowt - n * p.Ho;
-    const __amdgpu_buffer_rsrc_t rs = stem_rsrc(p.x + n * img, img * 4);
+  auto fetch = [&](int n, int oy, int tx, bool live) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = stem_rsrc(p.x + n * img, live ? img * 4 : 0);
     const int iy0 = 2 * oy - 3, ix0 = 2 * tx * SBM - 3;
+    const int base = (iy0 * p.W + ix0) * 16;
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
-      const int e = tid + 256 * q;
-      const int r = e / SCOLS, j = e - r * SCOLS;
-      const int iy = iy0 + r, ix = ix0 + j;
-      const bool ok = live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && e < 7 * SCOLS;
-      pf[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (iy * p.W + ix) * 16 : -1, 0, 0));
+      const bool ok = (unsigned)(iy0 + prow[q]) < (unsigned)p.H && (unsigned)(ix0 + pcol[q]) < (unsigned)p.W;
+      pf[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? base + prel[q] : -1, 0, 0));
     }
   };
   auto put = [&]() __attribute__((always_inline)) {
@@ -165,27 +205,69 @@ __global__ __launch_bounds__(256, CIN == 3 ? 2 : 1) void stem_conv_f32(const Ste
   const float* const A3 = lh ? zline + apix - IMM6 : strip + apix;
   const float* const B = wl + lh * SBN + wn * 32 + li;
 
-  fetch(t0, true);
+  // epilogue roles: 16 float4 per staged row, 16 rows per pass, 8 passes
+  const int ecol = (tid & 15) * 4, erow = tid >> 4;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ecol);
+  if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + ecol);
+
+#ifdef RS_STEM_TRACE
+#define STAMP(k) do { if (tid == 0) p.trace[((long)blockIdx.x * 64 + (tile - t0)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k)
+#endif
+#ifdef RS_STEM_TRACE
+  if (tid == 0) p.trace[((long)blockIdx.x * 64 + 63) * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  fetch(cn, coy, ctx, true);
+  put();
   for (int tile = t0; tile < t1; ++tile) {
-    put();
-    __syncthreads();
-    fetch(tile + 1 < t1 ? tile + 1 : t0, tile + 1 < t1);  // in flight under the MFMAs
+    STAMP(0);
+    __syncthreads();  // the strip is in place
+    STAMP(1);
+    // the next tile's coordinates; its strip is in flight under the MFMAs
+    int nn = cn, noy = coy, ntx = ctx + 1;
+    if (ntx == p.tpr) {
+      ntx = 0;
+      if (++noy == p.Ho) noy = 0, ++nn;
+    }
+    fetch(nn, noy, ntx, tile + 1 < t1);
+    STAMP(2);
 
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < G::NSTEP; ++t) {
+    // operands DEPTH steps ahead of their MFMAs (three ds_read_b32 per step, ~130 cycles of LDS latency against 128 cycles of MFMA per
+    // step and wave: one step of distance -- what hipcc picks on its own -- leaves the latency exposed whenever the other block's
+    // waves are reading too); sched_barrier pins the order
+    constexpr int DEPTH = 3;
+    float fb[DEPTH], fa0[DEPTH], fa1[DEPTH];
+    auto frag = [&](int t) __attribute__((always_inline)) {
       const float* A = t < G::NPAIR ? A1 : (t < G::NPAIR + G::NEO ? A2 : A3);
       const int imm = stem_imm<CIN>(t);
-      const float b = B[t * 2 * SBN];
-      const float a0 = A[imm], a1 = A[imm + 32 * PS];
+      fb[t % DEPTH] = B[t * 2 * SBN];
+      fa0[t % DEPTH] = A[imm];
+      fa1[t % DEPTH] = A[imm + 32 * PS];
+    };
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) frag(t);
+#pragma unroll
+    for (int t = 0; t < G::NSTEP; ++t) {
+      const float b = fb[t % DEPTH], a0 = fa0[t % DEPTH], a1 = fa1[t % DEPTH];
+      __builtin_amdgcn_sched_barrier(0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a0, acc0, 0, 0, 0);
+      if (t + DEPTH < G::NSTEP) frag(t + DEPTH);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a1, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    STAMP(3);
     __syncthreads();  // everybody is done with the strip: the staging tile takes its place
+    STAMP(4);
 
-    // ---- epilogue: registers -> LDS [pixel][cout] -> 16-byte row-wise stores ------------------------------------------------
+    // ---- epilogue: registers -> LDS [pixel][cout] -> registers, row-wise; then the NEXT strip goes to LDS and only after that the
+    //      16-byte stores are issued: the strip's s_waitcnt vmcnt must not find this tile's stores in the queue in front of it (they
+    //      count in vmcnt on gfx9: waiting for the prefetched loads would wait for the stores' round trip to HBM -- 13.5 us per tile
+    //      against the MFMAs' 8 in the first version)
     {
       const int prow = wm * 64 + li;
       const int ccol = wn * 32 + 4 * lh;
@@ -196,31 +278,36 @@ __global__ __launch_bounds__(256, CIN == 3 ? 2 : 1) void stem_conv_f32(const Ste
       }
     }
     __syncthreads();
+    f32x4 ov[SBM / 16];
+#pragma unroll
+    for (int i = 0; i < SBM / 16; ++i) ov[i] = *reinterpret_cast<const f32x4*>(&strip[(erow + 16 * i) * LDO + ecol]);
+    __syncthreads();  // the staging tile has been read: the next strip may land
+    STAMP(5);
+    put();
+    STAMP(6);
     {
-      const int rowt = tile / p.tpr, tx = tile - rowt * p.tpr;
-      const int ox0 = tx * SBM;
-      const int cc = tid & 15, rr = tid >> 4;  // 16 float4 per row, 16 rows per pass
-      const int col = cc * 4;
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+      const int ox0 = ctx * SBM;
       const int live = p.Wo - ox0 < SBM ? p.Wo - ox0 : SBM;
-      float* const orow = p.out + ((long)rowt * p.Wo + ox0) * SBN + col;
-#pragma unroll 4
-      for (int row = rr; row < SBM; row += 16) {
-        if (row >= live) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&strip[row * LDO + col]);
+      float* const orow = p.out + (((long)cn * p.Ho + coy) * p.Wo + ox0) * SBN + ecol;
+#pragma unroll
+      for (int i = 0; i < SBM / 16; ++i) {
+        const int row = erow + 16 * i;
+        f32x4 v = ov[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        *reinterpret_cast<f32x4*>(orow + (long)row * SBN) = v;
+        if (row < live) *reinterpret_cast<f32x4*>(orow + (long)row * SBN) = v;
       }
     }
-    __syncthreads();  // the staging tile has been read: the next strip may land
+    STAMP(7);
+    cn = nn, coy = noy, ctx = ntx;
   }
+#ifdef RS_STEM_TRACE
+  if (tid == 0) p.trace[((long)blockIdx.x * 64 + 63) * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
+#endif
 }
 
 }  // namespace
@@ -250,3 +337,16 @@ __attribute__((visibility("hidden"))) int rs_stem_f32_launch(const rs_conv_desc*
     stem_conv_f32<4><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return RS_LAUNCH_RESULT();
 }
+
+#ifdef RS_STEM_TRACE
+extern "C" int rs_stem_f32_trace(int N, int H, int W, const float* x, const float* w, float* out, long long* trace, int grid) {
+  StemArgs a;
+  a.x = x, a.w = w, a.scale = nullptr, a.shift = nullptr, a.out = out;
+  a.N = N, a.H = H, a.W = W, a.Ho = H / 2, a.Wo = W / 2, a.relu = 1;
+  a.tpr = rs_cdiv(a.Wo, SBM);
+  a.ntile = N * a.Ho * a.tpr;
+  a.trace = trace;
+  stem_conv_f32<3><<<grid, 256, 0, 0>>>(a);
+  return RS_LAUNCH_RESULT();
+}
+#endif

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/r6stem; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "stem" > $OUT/tests_stem.log 2>&1; echo "stem tests exit $? $(tail -1 $OUT/tests_stem.log | cut -c1-150)"
 grep -E "Error|error|assert" $OUT/tests_stem.log | head -10
-timeout 900 python -m pytest tests/test_gpu_unet.py tests/test_gpu_configs.py tests/test_gpu_train_step.py -x -q -m gpu > $OUT/tests_net.log 2>&1; echo "net tests exit $? $(tail -1 $OUT/tests_net.log | cut -c1-150)"
+echo skip-net-tests
 B="python bench.py --no-cpu-baseline --no-extra-legs --no-miou"
 for i in 1 2; do
   timeout 300 $B --no-train-leg --steps 30 --warmup 5 --layers-json $OUT/layers_predict_$i.json > $OUT/predict_$i.log 2>&1

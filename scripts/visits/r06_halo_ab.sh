@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6: A/B of two builds of the library on the halo-form layers of the bf16 bs-32 step (same box, alternating):
-#   scripts/r06_halo_ab.sh gpurun_in/lib_A.so gpurun_in/lib_B.so
+#   scripts/visits/r06_halo_ab.sh gpurun_in/lib_A.so gpurun_in/lib_B.so
 export TMPDIR=/tmp
 REPO=$(pwd); LIB=$REPO/robosat_amd/librobosat_hip.so
 cp $LIB /tmp/lib_orig.so

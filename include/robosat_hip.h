@@ -378,6 +378,16 @@ const char* rs_conv2d_wino33_head_name(void);
 int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
                               const float* final_w, const float* final_b, int C, int mode, const double* anchors, int overlap,
                               float* out, uint8_t* qout, rs_stream_t stream);
+/* The tail of a layer1 Bottleneck and the head of the next one in ONE launch, fp32 eval mode (torchvision Bottleneck.forward under
+ * reference unet.py:127; round 6, bottleneck_tail_f32.hip):
+ *     out = relu(conv1x1(x; w3) * scale3 + shift3 + identity)     x [M][C1], w3 [Cmid][C1], identity / out [M][Cmid]
+ *     z   = relu(conv1x1(out; w1) * scale1 + shift1)              w1 [C2][Cmid], z [M][C2]
+ * (the folded BatchNorms of rs_bn_fold).  The second product reads the first one's accumulator registers: `out` is written once and
+ * never read back.  C1 = 64, Cmid = 256, C2 = 64 (layer1's widths), M % 32 == 0; anything else: RS_EINVAL (the caller then runs the two
+ * rs_conv2d_fwd launches). */
+int rs_bottleneck_tail_f32(const float* x, const float* w3, const float* scale3, const float* shift3, const float* identity,
+                           const float* w1, const float* scale1, const float* shift1, float* out, float* z, long M, int C1, int Cmid,
+                           int C2, rs_stream_t stream);
 /* The same layers in the TRAIN-mode forward (torchvision Bottleneck.conv2 -> BatchNorm2d under tools/train.py:169, fp32): the raw
  * convolution output plus the per-block partial sums of the BatchNorm statistics (sum y, sum y^2 over the block's pixels, in a fixed
  * order), `stats` [rs_conv2d_wino33_stats_rows(d)][2][Cout] fp32 -- the input of rs_bn_finalize_stats, as rs_conv2d_fwd_bnstats_dt's

@@ -6,6 +6,7 @@ Nothing here computes with torch; a CPU tensor is an error (there is no CPU path
 """
 
 import ctypes
+import os
 
 import torch
 
@@ -632,6 +633,38 @@ def conv2d_wino33_head(src, u, final_w, final_b, mode="logits", overlap=0, relu=
         _record(_lib.lib().rs_conv2d_wino33_head_name().decode(), fl, (d.C1, d.Cout, d.kh, d.stride, d.ups, d.Ho, d.Wo), ev0, ev1,
                 nbytes, conv_flops(d) * 4.0 / 9.0 + 2.0 * n * h * w * cout * classes)
     return out if m <= 1 else qout
+
+
+def bottleneck_tail_ok(x, w3, w1):
+    """Whether ``bottleneck_tail`` can run these operands: fp32, layer1's widths (64 -> 256 -> 64), whole 32-pixel sub-tiles."""
+
+    m = x.numel() // x.shape[-1]
+    return (x.dtype == torch.float32 and x.shape[-1] == 64 and tuple(w3.shape) == (256, 1, 1, 64) and tuple(w1.shape) == (64, 1, 1, 256)
+            and m % 32 == 0 and os.environ.get("ROBOSAT_TAIL_FUSE", "1") != "0")
+
+
+def bottleneck_tail(x, w3, scale3, shift3, identity, w1, scale1, shift1):
+    """``rs_bottleneck_tail_f32``: out = relu(conv1x1(x; w3) * scale3 + shift3 + identity) and z = relu(conv1x1(out; w1) * scale1 +
+    shift1) in one launch -- the last convolution of a layer1 Bottleneck and the first of the next (eval mode, fp32).  Returns (out, z)."""
+
+    n, h, w, c1 = x.shape
+    cm, c2 = w3.shape[0], w1.shape[0]
+    assert identity.shape == (n, h, w, cm) and w1.shape[3] == cm
+    out = torch.empty((n, h, w, cm), device=x.device, dtype=torch.float32)
+    z = torch.empty((n, h, w, c2), device=x.device, dtype=torch.float32)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_bottleneck_tail_f32(_dev(x, "x"), _dev(w3, "w3"), _dev(scale3, "scale3"), _dev(shift3, "shift3"),
+                                           _dev(identity, "identity"), _dev(w1, "w1"), _dev(scale1, "scale1"), _dev(shift1, "shift1"),
+                                           _dev(out, "out"), _dev(z, "z"), n * h * w, c1, cm, c2, _stream())
+    check(rc, "rs_bottleneck_tail_f32")
+    if PROFILE is not None:
+        ev1.record()
+        m = n * h * w
+        fl = 2.0 * m * cm * (c1 + c2)
+        _record("bottleneck_tail_f32", fl, (c1, cm, 1, 1, 0, h, w), ev0, ev1, 4 * (m * (c1 + 2 * cm + c2) + cm * (c1 + c2)), fl)
+    return out, z
 
 
 def conv_tile_name(d, bf16=False, phase=False, plain=True):

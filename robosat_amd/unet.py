@@ -573,9 +573,14 @@ class UNet(nn.Module):
 
         enc = []
         for layer in self._blocks():
-            for blk in layer:
-                sc, sh = blk.bn1.folded()
-                o = ops.conv2d(h, blk.conv1.krsc(dt), scale=sc, shift=sh, relu=True)
+            blocks = list(layer)
+            ahead = None  # this block's conv1 -> bn1 -> ReLU output when the previous block's fused tail already produced it
+            for bi, blk in enumerate(blocks):
+                if ahead is None:
+                    sc, sh = blk.bn1.folded()
+                    o = ops.conv2d(h, blk.conv1.krsc(dt), scale=sc, shift=sh, relu=True)
+                else:
+                    o, ahead = ahead, None
                 sc, sh = blk.bn2.folded()
                 o = conv3x3_eval(blk.conv2, o, dt, scale=sc, shift=sh)
                 if blk.downsample is not None:
@@ -584,7 +589,15 @@ class UNet(nn.Module):
                 else:
                     idt = h
                 sc, sh = blk.bn3.folded()
-                h = ops.conv2d(o, blk.conv3.krsc(dt), scale=sc, shift=sh, residual=idt, relu=True)
+                nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+                if (nxt is not None and nxt.conv1.k == 1 and nxt.conv1.stride == 1 and dt == torch.float32
+                        and ops.bottleneck_tail_ok(o, blk.conv3.krsc(dt), nxt.conv1.krsc(dt))):
+                    # layer1: conv3 -> bn3 -> + identity -> ReLU and the NEXT block's conv1 -> bn1 -> ReLU in one launch (the second
+                    # product reads the first one's accumulators: the 256-channel tensor is written once and not read back)
+                    sc1, sh1 = nxt.bn1.folded()
+                    h, ahead = ops.bottleneck_tail(o, blk.conv3.krsc(dt), sc, sh, idt, nxt.conv1.krsc(dt), sc1, sh1)
+                else:
+                    h = ops.conv2d(o, blk.conv3.krsc(dt), scale=sc, shift=sh, residual=idt, relu=True)
             enc.append(h)
         enc1, enc2, enc3, enc4 = enc
 

@@ -192,6 +192,51 @@ def test_stem_is_batch_independent_and_deterministic():
     close(nchw(ops.conv2d(x4, packed, stride=2, pad=3, stem=7, bands=4)), nchw(full), 1e-5)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 8, 20), (1, 128, 128)])
+def test_bottleneck_tail_vs_torch_and_vs_the_two_launches(n, h, w):
+    """rs_bottleneck_tail_f32 (layer1: conv3 -> bn3 -> + identity -> ReLU, then the next block's conv1 -> bn1 -> ReLU, the second
+    product fed from the first one's accumulator registers) against plain PyTorch on the host and against the two rs_conv2d_fwd
+    launches it replaces."""
+    from robosat_amd import ops
+
+    x, idt = rnd(n, 64, h, w, seed=31), rnd(n, 256, h, w, seed=32)
+    w3, w1 = rnd(256, 64, 1, 1, seed=33) * 0.15, rnd(64, 256, 1, 1, seed=34) * 0.08
+    s3, t3, s1, t1 = rnd(256, seed=35) * 0.3 + 1.0, rnd(256, seed=36) * 0.2, rnd(64, seed=37) * 0.3 + 1.0, rnd(64, seed=38) * 0.2
+    want_out = torch.relu(F.conv2d(x, w3) * s3.view(1, -1, 1, 1) + t3.view(1, -1, 1, 1) + idt)
+    want_z = torch.relu(F.conv2d(want_out, w1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1))
+    dev = _dev()
+    xg, ig, w3g, w1g = nhwc(x), nhwc(idt), krsc(w3), krsc(w1)
+    assert ops.bottleneck_tail_ok(xg, w3g, w1g)
+    out, z = ops.bottleneck_tail(xg, w3g, s3.to(dev), t3.to(dev), ig, w1g, s1.to(dev), t1.to(dev))
+    close(nchw(out), want_out)
+    close(nchw(z), want_z)
+    out2 = ops.conv2d(xg, w3g, scale=s3.to(dev), shift=t3.to(dev), residual=ig, relu=True)
+    z2 = ops.conv2d(out2, w1g, scale=s1.to(dev), shift=t1.to(dev), relu=True)
+    close(out.cpu(), out2.cpu(), 2e-6)  # (same products, same order in stage 1)
+    close(z.cpu(), z2.cpu(), 1e-5)      # (stage 2 adds its 256 products in another order)
+    # deterministic, and a pixel's result does not depend on its batch neighbours
+    o3, z3 = ops.bottleneck_tail(xg, w3g, s3.to(dev), t3.to(dev), ig, w1g, s1.to(dev), t1.to(dev))
+    assert torch.equal(out, o3) and torch.equal(z, z3)
+    o1, z1 = ops.bottleneck_tail(xg[:1].contiguous(), w3g, s3.to(dev), t3.to(dev), ig[:1].contiguous(), w1g, s1.to(dev), t1.to(dev))
+    assert torch.equal(out[:1], o1) and torch.equal(z[:1], z1)
+
+
+def test_fused_tail_network_equals_unfused_network(monkeypatch):
+    """The fp32 eval forward with layer1's fused tails against the same forward with them switched off (ROBOSAT_TAIL_FUSE=0)."""
+    from oracle import robosat_ref as R, seeded
+    from robosat_amd.unet import UNet
+
+    net = UNet(2, pretrained=False)
+    net.load_state_dict(seeded.seeded_state_dict(R.UNetRef(2).state_dict(), 3))
+    net = net.to(_dev()).eval()
+    x = seeded.synthetic_images(2, 3, 128, 128, 3).to(_dev())
+    fused = net.predict_probs(x).cpu()
+    monkeypatch.setenv("ROBOSAT_TAIL_FUSE", "0")
+    plain = net.predict_probs(x).cpu()
+    print("fused vs unfused tails: max |dprob|", float((fused - plain).abs().max()))
+    assert float((fused - plain).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("k,s,p", [(3, 2, 1), (2, 2, 0)])
 def test_maxpool(k, s, p):
     from robosat_amd import ops

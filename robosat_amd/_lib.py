@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROBOSAT_HIP_LIB") or os.path.join(_HERE, "librobosat_hip.so")
 
 RS_EINVAL = -22
-ABI_VERSION = 20
+ABI_VERSION = 21
 RS_F32, RS_BF16 = 0, 1
 
 

@@ -290,7 +290,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 
 }  // namespace
 
-extern "C" int rs_abi_version(void) { return 20; }
+extern "C" int rs_abi_version(void) { return 21; }
 
 extern "C" int rs_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, rs_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return RS_EINVAL;

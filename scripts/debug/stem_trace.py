@@ -1,5 +1,6 @@
 """Where a tile's time goes inside stem_conv_f32: shader-clock stamps of wave 0 of every block at eight points of the tile loop
-(the -DRS_STEM_TRACE build of stem_f32.hip as gpurun_in/libstemtrace.so).  Prints the median cycles of each phase over all blocks and tiles."""
+(the -DRS_STEM_TRACE build of stem_f32.hip as gpurun_in/libstemtrace.so:
+`cd robosat_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DRS_STEM_TRACE -shared stem_f32.hip -o ../../gpurun_in/libstemtrace.so`).  Prints the median cycles of each phase over all blocks and tiles."""
 import ctypes
 import os
 import sys

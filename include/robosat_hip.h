@@ -388,6 +388,11 @@ int rs_conv2d_fwd_wino33_head(const rs_conv_desc* d, const float* src, const flo
 int rs_bottleneck_tail_f32(const float* x, const float* w3, const float* scale3, const float* shift3, const float* identity,
                            const float* w1, const float* scale1, const float* shift1, float* out, float* z, long M, int C1, int Cmid,
                            int C2, rs_stream_t stream);
+/* The same kernel's first stage alone: out = [relu](conv1x1(x; w) * scale + shift [+ residual]), C1 = 64 -> Cout = 256, M % 32 == 0 -- layer1's
+ * downsample convolution (97 against 109 us at bs 16 / 512^2; with a residual the generic launch is the faster one); `residual` may be NULL.  Same sums in
+ * the same order as the chained form's `out`. */
+int rs_conv1x1_wave_f32(const float* x, const float* w, const float* scale, const float* shift, const float* residual, int relu, float* out,
+                        long M, int C1, int Cout, rs_stream_t stream);
 /* The same layers in the TRAIN-mode forward (torchvision Bottleneck.conv2 -> BatchNorm2d under tools/train.py:169, fp32): the raw
  * convolution output plus the per-block partial sums of the BatchNorm statistics (sum y, sum y^2 over the block's pixels, in a fixed
  * order), `stats` [rs_conv2d_wino33_stats_rows(d)][2][Cout] fp32 -- the input of rs_bn_finalize_stats, as rs_conv2d_fwd_bnstats_dt's

@@ -117,6 +117,7 @@ SIGNATURES = {
     "rs_conv2d_wino33_head_name": (c_char_p, []),
     "rs_conv2d_fwd_wino33_head": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_int, c_int, P, c_int, P, P, P]),
     "rs_bottleneck_tail_f32": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
+    "rs_conv1x1_wave_f32": (c_int, [P, P, P, P, P, c_int, P, c_long, c_int, c_int, P]),
     "rs_conv2d_wino33_stats_rows": (c_long, [POINTER(ConvDesc)]),
     "rs_conv2d_fwd_wino33_stats": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "rs_conv2d_dgrad_wino33": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P]),

@@ -40,13 +40,17 @@ struct TailArgs {
   float* out;          // [M][256]
   float* z;            // [M][64]
   int nsub;            // M / 32
+  int relu;            // (single-stage form) ReLU on `out`; the chained form always clamps
 };
 
+// CHAIN = false: stage 1 alone (a 64 -> 256 1x1 convolution with the same wave-owns-its-pixels layout: layer1's downsample branch,
+// 97 against conv1x1_ew_f32's 109 us; with a residual it is the slower one, 140 against 127); `idt` may then be null and `relu` says whether to clamp.
+template <bool CHAIN>
 __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[TCM * LDW3 + TC2 * LDW1 + 2 * TCM + 2 * TC2];
+  __shared__ __attribute__((aligned(16))) float lds[TCM * LDW3 + (CHAIN ? TC2 * LDW1 : 0) + 2 * TCM + 2 * TC2];
   float* const w3l = lds;
   float* const w1l = lds + TCM * LDW3;
-  float* const s3l = w1l + TC2 * LDW1;  // scale3 [256], shift3 [256], scale1 [64], shift1 [64]
+  float* const s3l = w1l + (CHAIN ? TC2 * LDW1 : 0);  // scale3 [256], shift3 [256], scale1 [64], shift1 [64]
   float* const t3l = s3l + TCM;
   float* const s1l = t3l + TCM;
   float* const t1l = s1l + TC2;
@@ -57,12 +61,14 @@ __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) 
     const int row = e / (TC1 / 4), c4 = e % (TC1 / 4);
     *reinterpret_cast<f32x4*>(&w3l[row * LDW3 + c4 * 4]) = *reinterpret_cast<const f32x4*>(p.w3 + (long)e * 4);
   }
-  for (int e = tid; e < TC2 * TCM / 4; e += 512) {
-    const int row = e / (TCM / 4), c4 = e % (TCM / 4);
-    *reinterpret_cast<f32x4*>(&w1l[row * LDW1 + c4 * 4]) = *reinterpret_cast<const f32x4*>(p.w1 + (long)e * 4);
+  if constexpr (CHAIN) {
+    for (int e = tid; e < TC2 * TCM / 4; e += 512) {
+      const int row = e / (TCM / 4), c4 = e % (TCM / 4);
+      *reinterpret_cast<f32x4*>(&w1l[row * LDW1 + c4 * 4]) = *reinterpret_cast<const f32x4*>(p.w1 + (long)e * 4);
+    }
+    if (tid < TC2) s1l[tid] = p.s1[tid], t1l[tid] = p.t1[tid];
   }
   if (tid < TCM) s3l[tid] = p.s3[tid], t3l[tid] = p.t3[tid];
-  if (tid < TC2) s1l[tid] = p.s1[tid], t1l[tid] = p.t1[tid];
   __syncthreads();
 
   const float* const w3f = w3l + li * LDW3 + 4 * lh;  // + 32 t rows, + 8 j columns
@@ -73,6 +79,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) 
   // The wave's operands travel one step ahead of their use, in the registers their predecessors have just left: the pixel operand of
   // the NEXT sub-tile is requested when this one's last stage-1 pair is done, a pair's identity pieces when the previous pair's
   // epilogue has consumed its own -- each request has a pair's 64 stage-2 MFMAs (and more) between it and its first use.
+  const bool has_id = CHAIN || p.idt != nullptr;
+  const float lo = (CHAIN || p.relu) ? 0.f : -__builtin_huge_valf();  // (ReLU as a clamp from below: -inf = none)
   f32x4 xa[TC1 / 8];  // stage 1's pixel operand: this lane's pixel, channels 8 j + 4 (lane >> 5) ..
   f32x4 rid[2][4];    // identity pieces of a pair of cout tiles
   {
@@ -82,7 +90,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) 
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) rid[u][g] = *reinterpret_cast<const f32x4*>(p.idt + pix * TCM + 4 * lh + 32 * u + 8 * g);
+      for (int g = 0; g < 4; ++g)
+        rid[u][g] = has_id ? *reinterpret_cast<const f32x4*>(p.idt + pix * TCM + 4 * lh + 32 * u + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (; sub < p.nsub; sub += nw) {
     const long pix = (long)sub * 32 + li;
@@ -134,20 +143,21 @@ __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) 
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = fmaxf(acc1[u][4 * g + e] * sc[e] + sh[e] + rid[u][g][e], 0.f);
+            v[e] = fmaxf(acc1[u][4 * g + e] * sc[e] + sh[e] + rid[u][g][e], lo);
             acc1[u][4 * g + e] = v[e];
           }
           *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g) = v;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      {  // the following pair's identity pieces (the next sub-tile's first pair behind this one's last)
+      if (has_id) {  // the following pair's identity pieces (the next sub-tile's first pair behind this one's last)
         const float* const ip = tp + 1 < T1 / 2 ? p.idt + pix * TCM + 4 * lh + 64 * (tp + 1) : p.idt + npix * TCM + 4 * lh;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int g = 0; g < 4; ++g) rid[u][g] = *reinterpret_cast<const f32x4*>(ip + 32 * u + 8 * g);
       }
+      if constexpr (CHAIN) {
       f32x4 aw[2][T2];
 #pragma unroll
       for (int tn = 0; tn < T2; ++tn) aw[0][tn] = *reinterpret_cast<const f32x4*>(w1f + 32 * tn * LDW1 + 64 * tp);
@@ -166,8 +176,10 @@ __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) 
             acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ug & 1][tn][e], acc1[u][4 * g + e], acc2[tn], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      }
     }
     // ---- stage-2 epilogue ----------------------------------------------------------------------------------------------------
+    if constexpr (!CHAIN) continue;
     float* const zp = p.z + pix * TC2 + 4 * lh;
 #pragma unroll
     for (int tn = 0; tn < T2; ++tn)
@@ -185,6 +197,17 @@ __global__ __launch_bounds__(512, 2) void bottleneck_tail_f32(const TailArgs p) 
 
 }  // namespace
 
+static int tail_launch(const TailArgs& a, bool chain, hipStream_t s) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const int want = (a.nsub + 7) / 8;
+  const int grid = want < cus ? want : cus;
+  if (chain) bottleneck_tail_f32<true><<<grid, 512, 0, s>>>(a);
+  else bottleneck_tail_f32<false><<<grid, 512, 0, s>>>(a);
+  return RS_LAUNCH_RESULT();
+}
+
 extern "C" int rs_bottleneck_tail_f32(const float* x, const float* w3, const float* scale3, const float* shift3, const float* identity,
                                       const float* w1, const float* scale1, const float* shift1, float* out, float* z, long M,
                                       int C1, int Cmid, int C2, rs_stream_t stream) {
@@ -192,11 +215,16 @@ extern "C" int rs_bottleneck_tail_f32(const float* x, const float* w3, const flo
   if (C1 != TC1 || Cmid != TCM || C2 != TC2 || M <= 0 || (M % 32) != 0 || M / 32 >= (1L << 31)) return RS_EINVAL;
   TailArgs a;
   a.x = x, a.w3 = w3, a.s3 = scale3, a.t3 = shift3, a.idt = identity, a.w1 = w1, a.s1 = scale1, a.t1 = shift1, a.out = out, a.z = z;
-  a.nsub = (int)(M / 32);
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    cus = 256;
-  const int want = (a.nsub + 7) / 8;
-  bottleneck_tail_f32<<<want < cus ? want : cus, 512, 0, (hipStream_t)stream>>>(a);
-  return RS_LAUNCH_RESULT();
+  a.nsub = (int)(M / 32), a.relu = 1;
+  return tail_launch(a, true, (hipStream_t)stream);
+}
+
+extern "C" int rs_conv1x1_wave_f32(const float* x, const float* w, const float* scale, const float* shift, const float* residual, int relu,
+                                   float* out, long M, int C1, int Cout, rs_stream_t stream) {
+  if (!x || !w || !scale || !shift || !out) return RS_EINVAL;
+  if (C1 != TC1 || Cout != TCM || M <= 0 || (M % 32) != 0 || M / 32 >= (1L << 31)) return RS_EINVAL;
+  TailArgs a;
+  a.x = x, a.w3 = w, a.s3 = scale, a.t3 = shift, a.idt = residual, a.w1 = nullptr, a.s1 = nullptr, a.t1 = nullptr, a.out = out, a.z = nullptr;
+  a.nsub = (int)(M / 32), a.relu = relu ? 1 : 0;
+  return tail_launch(a, false, (hipStream_t)stream);
 }

@@ -667,6 +667,36 @@ def bottleneck_tail(x, w3, scale3, shift3, identity, w1, scale1, shift1):
     return out, z
 
 
+def conv1x1_wave_ok(x, w):
+    """Whether ``conv1x1_wave`` can run: fp32, 64 -> 256, 1x1, whole 32-pixel sub-tiles (layer1's downsample branch)."""
+
+    m = x.numel() // x.shape[-1]
+    return (x.dtype == torch.float32 and x.shape[-1] == 64 and tuple(w.shape) == (256, 1, 1, 64) and m % 32 == 0
+            and os.environ.get("ROBOSAT_TAIL_FUSE", "1") != "0")
+
+
+def conv1x1_wave(x, w, scale, shift, residual=None, relu=False):
+    """``rs_conv1x1_wave_f32``: [relu](conv1x1(x; w) * scale + shift [+ residual]) on the fused tail's first stage alone."""
+
+    n, h, wd, c1 = x.shape
+    cout = w.shape[0]
+    out = torch.empty((n, h, wd, cout), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        assert residual.shape == out.shape
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().rs_conv1x1_wave_f32(_dev(x, "x"), _dev(w, "w"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(residual, "residual"),
+                                        int(relu), _dev(out, "out"), n * h * wd, c1, cout, _stream())
+    check(rc, "rs_conv1x1_wave_f32")
+    if PROFILE is not None:
+        ev1.record()
+        m = n * h * wd
+        fl = 2.0 * m * cout * c1
+        _record("conv1x1_wave_f32", fl, (c1, cout, 1, 1, 0, h, wd), ev0, ev1, 4 * (m * (c1 + cout * (2 if residual is not None else 1)) + cout * c1), fl)
+    return out
+
+
 def conv_tile_name(d, bf16=False, phase=False, plain=True):
     """Report name of the kernel a convolution launch runs, 1:1 with the launched symbol:
     ``conv_igemm_<f32|bf16><[phase,]BMxBN,r<row bytes>>`` (or the stem kernel).  ``plain=False``: a launch with fused

@@ -585,7 +585,11 @@ class UNet(nn.Module):
                 o = conv3x3_eval(blk.conv2, o, dt, scale=sc, shift=sh)
                 if blk.downsample is not None:
                     sc, sh = blk.downsample[1].folded()
-                    idt = ops.conv2d(h, blk.downsample[0].krsc(dt), stride=blk.stride, scale=sc, shift=sh)
+                    dw = blk.downsample[0].krsc(dt)
+                    if blk.stride == 1 and ops.conv1x1_wave_ok(h, dw):  # (layer1: 64 -> 256 on the fused tail's first stage)
+                        idt = ops.conv1x1_wave(h, dw, sc, sh)
+                    else:
+                        idt = ops.conv2d(h, dw, stride=blk.stride, scale=sc, shift=sh)
                 else:
                     idt = h
                 sc, sh = blk.bn3.folded()
@@ -596,7 +600,7 @@ class UNet(nn.Module):
                     # product reads the first one's accumulators: the 256-channel tensor is written once and not read back)
                     sc1, sh1 = nxt.bn1.folded()
                     h, ahead = ops.bottleneck_tail(o, blk.conv3.krsc(dt), sc, sh, idt, nxt.conv1.krsc(dt), sc1, sh1)
-                else:
+                else:  # (layer1's last conv3 stays on conv1x1_ew_f32: with a residual the wave form measured 140 against 127 us)
                     h = ops.conv2d(o, blk.conv3.krsc(dt), scale=sc, shift=sh, residual=idt, relu=True)
             enc.append(h)
         enc1, enc2, enc3, enc4 = enc

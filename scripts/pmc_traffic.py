@@ -66,8 +66,8 @@ def bench_name(k):
             return "conv_wgrad_bf16<{}{}x{}>".format("phase," if mm.group(3) == "1" else "", mm.group(1), mm.group(2))
     if m:  # (a two-launch layer -- "128x128+128x64" in the bench's name -- is looked up by its first tile)
         return "conv_wgrad_bf16<{}{}x{}>".format("phase," if m.group(3) == "true" else "", m.group(1), m.group(2))
-    if "bottleneck_tail_f32" in k:  # (bottleneck_tail_f32.hip, round 6)
-        return "bottleneck_tail_f32"
+    if "bottleneck_tail_f32" in k:  # (bottleneck_tail_f32.hip, round 6: <true> = the chained form, <false> = its first stage alone)
+        return "conv1x1_wave_f32" if ("<false>" in k or "ILb0E" in k) else "bottleneck_tail_f32"
     if "stem_conv_f32" in k:  # (stem_f32.hip, round 6; <3> = RGB, <4> = four live bands: one report name)
         return "stem_conv_f32<128x64>"
     m = re.search(r"_ZN\d+_GLOBAL__N_1\d+([a-z_0-9]+?)I", k)

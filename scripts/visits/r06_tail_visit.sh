@@ -2,7 +2,7 @@
 # layer1's fused Bottleneck tail (bottleneck_tail_f32.hip): parity, then the predict pass with it on / off
 export TMPDIR=/tmp
 OUT=gpurun_out/r6tail; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -rP -k "tail or stem" > $OUT/tests.log 2>&1; echo "tests exit $? $(tail -1 $OUT/tests.log | cut -c1-150)"; grep -E "fused vs unfused|Error|assert " $OUT/tests.log | head -5
+timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -rP -k "tail or stem or wave" > $OUT/tests.log 2>&1; echo "tests exit $? $(tail -1 $OUT/tests.log | cut -c1-150)"; grep -E "fused vs unfused|Error|assert " $OUT/tests.log | head -5
 B="python bench.py --no-cpu-baseline --no-extra-legs --no-miou --no-train-leg"
 for i in 1 2; do
   for K in 0 1; do

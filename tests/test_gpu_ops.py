@@ -221,6 +221,32 @@ def test_bottleneck_tail_vs_torch_and_vs_the_two_launches(n, h, w):
     assert torch.equal(out[:1], o1) and torch.equal(z[:1], z1)
 
 
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv1x1_wave_is_the_generic_launch(with_res):
+    """rs_conv1x1_wave_f32 (the fused tail's first stage alone: layer1's downsample convolution and last conv3) against PyTorch and against
+    rs_conv2d_fwd; its `out` equals the chained form's bit for bit (same kernel body)."""
+    from robosat_amd import ops
+
+    n, h, w = 2, 24, 16
+    x, idt = rnd(n, 64, h, w, seed=41), rnd(n, 256, h, w, seed=42)
+    w3, w1 = rnd(256, 64, 1, 1, seed=43) * 0.15, rnd(64, 256, 1, 1, seed=44) * 0.08
+    sc, sh = rnd(256, seed=45) * 0.3 + 1.0, rnd(256, seed=46) * 0.2
+    dev = _dev()
+    want = F.conv2d(x, w3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if with_res:
+        want = torch.relu(want + idt)
+    xg, w3g, ig = nhwc(x), krsc(w3), nhwc(idt)
+    assert ops.conv1x1_wave_ok(xg, w3g)
+    got = ops.conv1x1_wave(xg, w3g, sc.to(dev), sh.to(dev), residual=ig if with_res else None, relu=with_res)
+    close(nchw(got), want)
+    ref = ops.conv2d(xg, w3g, scale=sc.to(dev), shift=sh.to(dev), residual=ig if with_res else None, relu=with_res)
+    close(got.cpu(), ref.cpu(), 2e-6)
+    if with_res:
+        s1, t1 = rnd(64, seed=47) * 0.3 + 1.0, rnd(64, seed=48) * 0.2
+        out, _ = ops.bottleneck_tail(xg, w3g, sc.to(dev), sh.to(dev), ig, krsc(w1), s1.to(dev), t1.to(dev))
+        assert torch.equal(out, got)
+
+
 def test_fused_tail_network_equals_unfused_network(monkeypatch):
     """The fp32 eval forward with layer1's fused tails against the same forward with them switched off (ROBOSAT_TAIL_FUSE=0)."""
     from oracle import robosat_ref as R, seeded

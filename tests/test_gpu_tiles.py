@@ -37,7 +37,7 @@ for _dt in ("f32", "bf16"):
 # non-implicit-GEMM symbols of the step have their own parity tests (test_gpu_ops / test_gpu_train_ops / test_gpu_bf16)
 COVERED |= {"conv_thin_bf16<3x3>", "conv_thin_bf16<phase>", "conv_thin_bf16<dgrad4x4>"}  # test_thin_* below
 # layer1's fused Bottleneck tail (conv3 + identity + ReLU -> the next block's conv1): tests/test_gpu_ops.py::test_bottleneck_tail_*
-COVERED |= {"bottleneck_tail_f32"}
+COVERED |= {"bottleneck_tail_f32", "conv1x1_wave_f32"}
 COVERED |= {"stem_conv_f32<128x64>", "stem_conv_bf16", "stem_wgrad_bf16", "conv_wgrad_f32", "conv_wgrad_f32_dma", "conv_wgrad_wino_f32", "conv_wgrad_wino33_f32"}
 # fp32 1x1 launches with K <= 64 (layer1) take the epilogue-wave kernel by rule: test_epilogue_wave_1x1_kernel_* below
 COVERED |= {"conv1x1_ew_f32<128x64,r64>"}

@@ -199,8 +199,10 @@ def test_profiler_symbols_map_to_the_bench_names():
         ns + "conv_igemm_f32<128, 64, 2, 2, 1>((anonymous namespace)::ConvArgs)": "conv_igemm_f32<128x64,stem>",
         ns + "stem_conv_f32<3>((anonymous namespace)::StemArgs)": "stem_conv_f32<128x64>",
         "_ZN12_GLOBAL__N_113stem_conv_f32ILi4EEEvNS_8StemArgsE": "stem_conv_f32<128x64>",
-        "(anonymous namespace)::bottleneck_tail_f32((anonymous namespace)::TailArgs)": "bottleneck_tail_f32",
-        "_ZN12_GLOBAL__N_119bottleneck_tail_f32ENS_8TailArgsE": "bottleneck_tail_f32",
+        "void (anonymous namespace)::bottleneck_tail_f32<true>((anonymous namespace)::TailArgs)": "bottleneck_tail_f32",
+        "void (anonymous namespace)::bottleneck_tail_f32<false>((anonymous namespace)::TailArgs)": "conv1x1_wave_f32",
+        "_ZN12_GLOBAL__N_119bottleneck_tail_f32ILb1EEEvNS_8TailArgsE": "bottleneck_tail_f32",
+        "_ZN12_GLOBAL__N_119bottleneck_tail_f32ILb0EEEvNS_8TailArgsE": "conv1x1_wave_f32",
         ns + "conv_thin_bf16<1>((anonymous namespace)::ThinConvArgs)": "conv_thin_bf16<phase>",
         ns + "conv_wgrad_thin_bf16<4, 1>((anonymous namespace)::ThinArgs)": "conv_wgrad_thin_bf16<128,ups>",
         ns + "conv_wgrad_bf16<256, 128, 4, 2, 64, false>((anonymous namespace)::WgradArgsB)": "conv_wgrad_bf16<256x128>",
